@@ -1,0 +1,166 @@
+/*
+ * scpose.h -- C ABI of the MI355X (gfx950) HRNet -> heatmap decode -> EPnP/RANSAC library.
+ *
+ * The reference (mohsij/spacecraft-pose-estimation) has no FFI for this path; the path sits
+ * behind Python call signatures.  Each entry point below names the reference interface it
+ * replaces (paths relative to the reference repo root).  INTEGRATION.md shows the ctypes
+ * stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns int32 status: 0 = ok, <0 = SCPOSE_E_*; the message of the last
+ *     failure on the calling thread is returned by scpose_last_error().  Nothing throws.
+ *   - OWNERSHIP: the host (PyTorch) allocates and owns every device buffer passed in
+ *     (inputs, outputs, workspace).  The library owns only the opaque handle and the packed
+ *     weights it uploads at create time (freed by scpose_hrnet_destroy).
+ *   - STREAMS: every launch function takes a hipStream_t as void*; nothing synchronises
+ *     internally, nothing allocates in a launch function (hipGraph-capturable).
+ *   - THREADING: a handle is bound to the device current at create time and is not
+ *     thread-safe; distinct handles are independent; there is no global mutable state.
+ *   - "blocked" activation layout used between layers: [N][C/8][H][W][8] 16-bit elements
+ *     (bf16 or f16), C a multiple of 8.
+ */
+#ifndef SCPOSE_H
+#define SCPOSE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCPOSE_ABI_VERSION 1
+
+enum {
+  SCPOSE_OK = 0,
+  SCPOSE_E_INVALID = -1,   /* bad argument / unsupported shape */
+  SCPOSE_E_MISSING = -2,   /* a required checkpoint tensor was not supplied */
+  SCPOSE_E_HIP = -3,       /* a HIP runtime call failed */
+  SCPOSE_E_WORKSPACE = -4, /* workspace too small */
+  SCPOSE_E_NOMEM = -5
+};
+
+/* 16-bit storage / MFMA operand type of the network (accumulation is always fp32). */
+enum { SCPOSE_DT_BF16 = 0, SCPOSE_DT_F16 = 1 };
+
+/* input formats of scpose_hrnet_forward */
+enum {
+  SCPOSE_IN_F32_NCHW = 0,  /* normalised float32 N x 3 x H x W: what the reference module's
+                              forward(x) receives (landmark_regression/tools/test.py:106-114) */
+  SCPOSE_IN_U8_NHWC = 1    /* raw uint8 N x H x W x 3 RGB crop; ToTensor + Normalize(mean,std)
+                              of tools/test.py:106-108 is fused into the stem kernel */
+};
+
+int32_t scpose_abi_version(void);
+const char* scpose_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * HRNet.  Replaces models.pose_hrnet.get_pose_net(cfg, is_train=False) + load_state_dict +
+ * PoseHighResolutionNet.forward
+ * (landmark_regression/lib/models/pose_hrnet.py:274-331, :425-460, :495-501;
+ *  call sites landmark_regression/tools/test.py:84-98, lib/core/function.py:341).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct scpose_hrnet_desc {
+  int32_t num_joints;          /* cfg.MODEL.NUM_JOINTS */
+  int32_t final_conv_kernel;   /* cfg.MODEL.EXTRA.FINAL_CONV_KERNEL (1 or 3) */
+  int32_t num_stages;          /* always 3 (STAGE2..STAGE4) */
+  int32_t num_modules[3];      /* EXTRA.STAGEk.NUM_MODULES */
+  int32_t num_branches[3];     /* EXTRA.STAGEk.NUM_BRANCHES (2,3,4) */
+  int32_t num_blocks[3][4];    /* EXTRA.STAGEk.NUM_BLOCKS (BASIC blocks per branch) */
+  int32_t num_channels[3][4];  /* EXTRA.STAGEk.NUM_CHANNELS */
+  int32_t dtype;               /* SCPOSE_DT_* */
+  float mean[3], std[3];       /* Normalize() constants for SCPOSE_IN_U8_NHWC */
+} scpose_hrnet_desc;
+
+typedef struct scpose_hrnet* scpose_hrnet_t;
+
+/* names/ptrs/numels: the checkpoint's state_dict as HOST float32 arrays (conv weights OIHW),
+ * keyed exactly as the reference module's state_dict ("conv1.weight", "bn1.running_var",
+ * "stage3.2.fuse_layers.1.0.0.0.weight", "final_layer.bias", ...).  Unknown keys are ignored
+ * (num_batches_tracked etc.); a missing required key fails with SCPOSE_E_MISSING unless
+ * allow_missing != 0, in which case the tensor takes the reference constructor's default
+ * (strict=False behaviour of tools/test.py:90: BN -> identity, conv -> zeros).
+ * BatchNorm (eval, eps 1e-5) is folded into the conv weights/bias here and the result is
+ * packed for the MFMA kernels and uploaded. */
+int32_t scpose_hrnet_create(const scpose_hrnet_desc* desc, const char* const* names,
+                            const float* const* ptrs, const int64_t* numels, int32_t count,
+                            int32_t allow_missing, scpose_hrnet_t* out);
+int32_t scpose_hrnet_destroy(scpose_hrnet_t h);
+
+/* bytes of device workspace scpose_hrnet_forward needs for a batch of n frames of h x w. */
+int32_t scpose_hrnet_workspace_bytes(scpose_hrnet_t h, int32_t n, int32_t height, int32_t width,
+                                     size_t* bytes);
+/* number of kernel launches of one forward and total conv FLOPs (2*MAC) per frame. */
+int32_t scpose_hrnet_stats(scpose_hrnet_t h, int32_t height, int32_t width, int32_t* launches,
+                           double* flops_per_frame, double* act_bytes_per_frame);
+
+/* in: device pointer in in_fmt; heatmaps: device float32 N x J x H/4 x W/4 (NCHW, raw scores,
+ * exactly what the reference forward returns).  H and W must be multiples of 32. */
+int32_t scpose_hrnet_forward(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n,
+                             int32_t height, int32_t width, float* heatmaps, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Heatmap decode.  Replaces get_max_preds + get_final_preds + transform_preds
+ * (landmark_regression/lib/core/inference.py:18-79, lib/utils/transforms.py:49-110) and the
+ * all_preds assembly of validate() (lib/core/function.py:389-393).
+ *   heatmaps  device f32 N x J x H x W
+ *   center    device f32 N x 2, scale device f32 N x 2 (meta['center'], meta['scale'])
+ *   preds_xyc device f32 N x J x 3 = [x_img, y_img, maxval]
+ * post_process = cfg.TEST.POST_PROCESS.  One wavefront per (n, j) map.
+ * ---------------------------------------------------------------------------------------- */
+int32_t scpose_decode(const float* heatmaps, int32_t n, int32_t j, int32_t h, int32_t w,
+                      const float* center, const float* scale, int32_t post_process,
+                      float* preds_xyc, void* stream);
+/* get_max_preds alone: coords device f32 N x J x 2 (heatmap px), maxvals device f32 N x J. */
+int32_t scpose_max_preds(const float* heatmaps, int32_t n, int32_t j, int32_t h, int32_t w,
+                         float* coords, float* maxvals, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched PnP.  Replaces, per frame, the confidence filter + cv2.solvePnPRansac(...,
+ * flags=SOLVEPNP_EPNP, iterationsCount, reprojectionError) + cv2.Rodrigues of
+ * pose_estimation/export_predicted_poses_real.py:186-203.  One wavefront per frame, fp64.
+ *   kp_xyc     device f32 N x J x 3 (x, y, confidence) -- rows of pred.mat
+ *   landmarks  device f64 J x 3, K device f64 3x3 row-major, dist device f64[5] (k1,k2,p1,p2,k3)
+ *   conf_thr0 / min_pts / thr_decay / thr_iters: the threshold loop of :188-197
+ *              (0.95, 15, 0.8, 100 in the reference)
+ *   rot        device f64 N x 9 row-major rotation matrix (= cv2.Rodrigues(rvec)[0])
+ *   tvec       device f64 N x 3
+ *   rvec       device f64 N x 3 (may be NULL)
+ *   status     device i32 N: >=0 number of RANSAC inliers; <0 failure code
+ *              (-1: fewer than 4 usable points [the reference raises], -2: RANSAC found no model)
+ * ---------------------------------------------------------------------------------------- */
+int32_t scpose_pnp_epnp_ransac(const float* kp_xyc, const double* landmarks, const double* K,
+                               const double* dist, int32_t n, int32_t j, float conf_thr0,
+                               int32_t min_pts, float thr_decay, int32_t thr_iters,
+                               int32_t max_iters, double reproj_err, double confidence,
+                               double* rot, double* tvec, double* rvec, int32_t* status,
+                               void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Single-layer entry points (unit-level parity of the kernels the forward is made of).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct scpose_conv* scpose_conv_t;
+/* weight: host f32 OIHW (already BN-folded or plain), bias: host f32[cout] or NULL. */
+int32_t scpose_conv_create(const float* weight, const float* bias, int32_t cout, int32_t cin,
+                           int32_t ksize, int32_t stride, int32_t dtype, scpose_conv_t* out);
+int32_t scpose_conv_destroy(scpose_conv_t c);
+/* in/out/residual: blocked 16-bit device tensors; out_nchw_f32 != 0 writes float32 NCHW
+ * (cout channels) instead.  y = [relu]( conv(x) + bias [+ residual] ). */
+int32_t scpose_conv_forward(scpose_conv_t c, const void* in, int32_t n, int32_t h, int32_t w,
+                            const void* residual, int32_t relu, int32_t out_nchw_f32, void* out,
+                            void* stream);
+/* out = relu(sum_t upsample_nearest(term_t, 2^shift_t)); all blocked, out is c x h x w. */
+int32_t scpose_fuse_sum(const void* const* terms, const int32_t* shifts, int32_t nterms,
+                        int32_t n, int32_t c, int32_t h, int32_t w, int32_t dtype, void* out,
+                        void* stream);
+/* layout converters: float32 NCHW <-> blocked 16-bit (c multiple of 8). */
+int32_t scpose_nchw_f32_to_blocked(const float* src, int32_t n, int32_t c, int32_t h, int32_t w,
+                                   int32_t dtype, void* dst, void* stream);
+int32_t scpose_blocked_to_nchw_f32(const void* src, int32_t n, int32_t c, int32_t h, int32_t w,
+                                   int32_t dtype, float* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCPOSE_H */

@@ -1,0 +1,275 @@
+"""fp32 CPU restatement of the reference pose_hrnet forward (TEST ORACLE, not product).
+
+Follows /root/reference/landmark_regression/lib/models/pose_hrnet.py:
+  * stem + layer1 ................. :425-432, Bottleneck :78-98, _make_layer :374-391
+  * transition layers ............. :333-372, use in forward :434-455
+  * HighResolutionModule .......... branches :139-185, fuse layers :187-242, forward :247-265
+  * stages ........................ _make_stage :393-423 (last stage-4 module fuses to branch 0 only)
+  * final 1x1 (or 3x3) conv + bias  :323-329, :458
+
+The network is evaluated functionally from a plain ``state_dict`` whose keys and
+shapes are those of the reference module (``state_dict_spec``), so checkpoints
+interchange.  No nn.Module tree of the reference is reproduced here.
+
+``emulate`` selects the arithmetic model:
+  None   -- the reference's own arithmetic: fp32 conv, eval BatchNorm, ReLU, adds.
+  'bf16' / 'f16' -- the storage model of the HIP path: BatchNorm folded into the
+           conv weight/bias, folded weights rounded to the 16-bit type, every
+           tensor that the HIP path writes to HBM rounded to it, fp32 accumulation.
+           Used to separate "logic differs" from "precision differs" in the tests.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+EXPANSION = {"BASIC": 1, "BOTTLENECK": 4}
+
+
+# ----------------------------------------------------------------------------- cfg
+def extra_of(cfg):
+    return cfg["MODEL"]["EXTRA"]
+
+
+def w32_cfg(num_joints=11, image=256):
+    return _wN_cfg(32, num_joints, image)
+
+
+def w48_cfg(num_joints=11, image=384):
+    return _wN_cfg(48, num_joints, image)
+
+
+def _wN_cfg(c, num_joints, image, modules=(1, 4, 3)):
+    def stage(nb, nm):
+        return {"NUM_MODULES": nm, "NUM_BRANCHES": nb, "BLOCK": "BASIC",
+                "NUM_BLOCKS": [4] * nb, "NUM_CHANNELS": [c * (2 ** i) for i in range(nb)],
+                "FUSE_METHOD": "SUM"}
+    return {"MODEL": {"NAME": "pose_hrnet", "NUM_JOINTS": num_joints, "INIT_WEIGHTS": False,
+                      "PRETRAINED": "", "IMAGE_SIZE": [image, image],
+                      "HEATMAP_SIZE": [image // 4, image // 4],
+                      "EXTRA": {"PRETRAINED_LAYERS": ["*"], "FINAL_CONV_KERNEL": 1,
+                                "STAGE2": stage(2, modules[0]), "STAGE3": stage(3, modules[1]),
+                                "STAGE4": stage(4, modules[2])}}}
+
+
+def tiny_cfg(num_joints=11, image=64, c=16, modules=(1, 1, 1)):
+    """Small HRNet of the same topology (for fast CPU tests)."""
+    return _wN_cfg(c, num_joints, image, modules)
+
+
+# ----------------------------------------------------------------------------- key/shape census
+def _conv(sd, name, cout, cin, k, bias=False):
+    sd[name + ".weight"] = (cout, cin, k, k)
+    if bias:
+        sd[name + ".bias"] = (cout,)
+
+
+def _bn(sd, name, c):
+    sd[name + ".weight"] = (c,)
+    sd[name + ".bias"] = (c,)
+    sd[name + ".running_mean"] = (c,)
+    sd[name + ".running_var"] = (c,)
+    sd[name + ".num_batches_tracked"] = ()
+
+
+def _stage_channels(scfg):
+    e = EXPANSION[scfg["BLOCK"]]
+    return [c * e for c in scfg["NUM_CHANNELS"]]
+
+
+def state_dict_spec(cfg):
+    """name -> shape, in the reference module's registration order."""
+    ex = extra_of(cfg)
+    sd = OrderedDict()
+    _conv(sd, "conv1", 64, 3, 3); _bn(sd, "bn1", 64)
+    _conv(sd, "conv2", 64, 64, 3); _bn(sd, "bn2", 64)
+    inpl = 64
+    for b in range(4):                               # layer1: Bottleneck(planes 64) x4
+        p = "layer1.%d" % b
+        _conv(sd, p + ".conv1", 64, inpl, 1); _bn(sd, p + ".bn1", 64)
+        _conv(sd, p + ".conv2", 64, 64, 3); _bn(sd, p + ".bn2", 64)
+        _conv(sd, p + ".conv3", 256, 64, 1); _bn(sd, p + ".bn3", 256)
+        if b == 0:
+            _conv(sd, p + ".downsample.0", 256, inpl, 1); _bn(sd, p + ".downsample.1", 256)
+        inpl = 256
+    pre = [256]
+    for si, sname in enumerate(("STAGE2", "STAGE3", "STAGE4")):
+        scfg = ex[sname]
+        cur = _stage_channels(scfg)
+        tname = "transition%d" % (si + 1)
+        for i in range(len(cur)):
+            if i < len(pre):
+                if cur[i] != pre[i]:
+                    _conv(sd, "%s.%d.0" % (tname, i), cur[i], pre[i], 3); _bn(sd, "%s.%d.1" % (tname, i), cur[i])
+            else:
+                for j in range(i + 1 - len(pre)):
+                    cin = pre[-1]
+                    cout = cur[i] if j == i - len(pre) else cin
+                    _conv(sd, "%s.%d.%d.0" % (tname, i, j), cout, cin, 3); _bn(sd, "%s.%d.%d.1" % (tname, i, j), cout)
+        nb = scfg["NUM_BRANCHES"]
+        last_stage = sname == "STAGE4"
+        stname = "stage%d" % (si + 2)
+        for m in range(scfg["NUM_MODULES"]):
+            multi = not (last_stage and m == scfg["NUM_MODULES"] - 1)
+            mp = "%s.%d" % (stname, m)
+            if scfg["BLOCK"] != "BASIC":
+                raise NotImplementedError("stage blocks other than BASIC are not used by any shipped config")
+            for b in range(nb):
+                for k in range(scfg["NUM_BLOCKS"][b]):
+                    p = "%s.branches.%d.%d" % (mp, b, k)
+                    _conv(sd, p + ".conv1", cur[b], cur[b], 3); _bn(sd, p + ".bn1", cur[b])
+                    _conv(sd, p + ".conv2", cur[b], cur[b], 3); _bn(sd, p + ".bn2", cur[b])
+            for i in range(nb if multi else 1):
+                for j in range(nb):
+                    fp = "%s.fuse_layers.%d.%d" % (mp, i, j)
+                    if j > i:
+                        _conv(sd, fp + ".0", cur[i], cur[j], 1); _bn(sd, fp + ".1", cur[i])
+                    elif j < i:
+                        for k in range(i - j):
+                            cout = cur[i] if k == i - j - 1 else cur[j]
+                            _conv(sd, "%s.%d.0" % (fp, k), cout, cur[j], 3); _bn(sd, "%s.%d.1" % (fp, k), cout)
+        pre = cur
+    fk = ex["FINAL_CONV_KERNEL"]
+    _conv(sd, "final_layer", cfg["MODEL"]["NUM_JOINTS"], pre[0], fk, bias=True)
+    return sd
+
+
+def make_state_dict(cfg, seed=0):
+    """Seeded synthetic checkpoint (SURVEY.md 8d recipe): kaiming-uniform(a=sqrt 5) convs,
+    BN gamma~U[.75,1.25], beta,mean~N(0,.1^2), var~U[.75,1.25].  Deterministic for a torch build."""
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+    for name, shape in state_dict_spec(cfg).items():
+        leaf = name.rsplit(".", 1)[1]
+        if leaf == "num_batches_tracked":
+            sd[name] = torch.tensor(0, dtype=torch.long)
+        elif len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            bound = (1.0 / fan_in) ** 0.5                    # kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in))
+            sd[name] = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        elif name == "final_layer.bias":
+            sd[name] = (torch.rand(shape, generator=g) * 2 - 1) * 0.05
+        elif leaf in ("weight", "running_var"):
+            sd[name] = 0.75 + 0.5 * torch.rand(shape, generator=g)
+        else:                                                # bn bias / running_mean
+            sd[name] = 0.1 * torch.randn(shape, generator=g)
+    return sd
+
+
+# ----------------------------------------------------------------------------- arithmetic models
+class _Arith:
+    """conv(+bn)(+residual)(+relu) under one of the two arithmetic models."""
+
+    def __init__(self, sd, emulate=None):
+        self.sd = sd
+        self.emulate = emulate
+        self.dt = {None: None, "bf16": torch.bfloat16, "f16": torch.float16}[emulate]
+
+    def rnd(self, t):
+        return t if self.dt is None else t.to(self.dt).to(torch.float32)
+
+    def conv_bn(self, x, conv, bn, stride=1, relu=False, residual=None, bias=None, store=True, round_w=True):
+        sd = self.sd
+        w = sd[conv + ".weight"].float()
+        pad = (w.shape[-1] - 1) // 2
+        if self.dt is None:
+            y = F.conv2d(x, w, sd.get(conv + ".bias") if bias is None else bias, stride, pad)
+            if bn is not None:
+                y = F.batch_norm(y, sd[bn + ".running_mean"], sd[bn + ".running_var"],
+                                 sd[bn + ".weight"], sd[bn + ".bias"], False, 0.0, BN_EPS)
+            if residual is not None:
+                y = y + residual
+            return F.relu(y) if relu else y
+        # HIP storage model: fold, round weights, fp32 accumulate, epilogue in fp32, round on store
+        if bn is not None:
+            s = (sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + BN_EPS))
+            b = (sd[bn + ".bias"].double() - sd[bn + ".running_mean"].double() * s).float()
+            w = (w.double() * s.view(-1, 1, 1, 1)).float()
+        else:
+            b = sd[conv + ".bias"].float() if (conv + ".bias") in sd else None
+        y = F.conv2d(x, self.rnd(w) if round_w else w, b, stride, pad)
+        if residual is not None:
+            y = y + residual
+        if relu:
+            y = F.relu(y)
+        return self.rnd(y) if store else y
+
+
+def forward(sd, cfg, x, emulate=None, taps=None):
+    """x: (N,3,H,W) float32, ImageNet-normalised.  Returns (N,J,H/4,W/4) float32 heatmaps.
+    ``taps``: optional dict that receives named intermediate tensors."""
+    ex = extra_of(cfg)
+    A = _Arith(sd, emulate)
+
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = t
+        return t
+
+    x = x.float()
+    # the HIP stem (csrc/stem.hip) runs conv1 in f32 on the unrounded input and folded weights
+    x = tap("stem1", A.conv_bn(x, "conv1", "bn1", 2, relu=True, round_w=False))
+    x = tap("stem2", A.conv_bn(x, "conv2", "bn2", 2, relu=True))
+    for b in range(4):
+        p = "layer1.%d" % b
+        res = A.conv_bn(x, p + ".downsample.0", p + ".downsample.1") if b == 0 else x
+        y = A.conv_bn(x, p + ".conv1", p + ".bn1", relu=True)
+        y = A.conv_bn(y, p + ".conv2", p + ".bn2", relu=True)
+        x = A.conv_bn(y, p + ".conv3", p + ".bn3", relu=True, residual=res)
+    tap("layer1", x)
+
+    ylist = [x]
+    pre = [256]
+    for si, sname in enumerate(("STAGE2", "STAGE3", "STAGE4")):
+        scfg = ex[sname]
+        cur = _stage_channels(scfg)
+        tname = "transition%d" % (si + 1)
+        xs = []
+        for i in range(len(cur)):
+            if i < len(pre):
+                if cur[i] != pre[i]:
+                    src = ylist[-1]                            # reference :437,:445,:453 -- always the LAST branch
+                    xs.append(A.conv_bn(src, "%s.%d.0" % (tname, i), "%s.%d.1" % (tname, i), relu=True))
+                else:
+                    xs.append(ylist[i])
+            else:
+                t = ylist[-1]                                  # reference :445,:453 -- from the LAST branch
+                for j in range(i + 1 - len(pre)):
+                    t = A.conv_bn(t, "%s.%d.%d.0" % (tname, i, j), "%s.%d.%d.1" % (tname, i, j), 2, relu=True)
+                xs.append(t)
+        nb = scfg["NUM_BRANCHES"]
+        stname = "stage%d" % (si + 2)
+        for m in range(scfg["NUM_MODULES"]):
+            multi = not (sname == "STAGE4" and m == scfg["NUM_MODULES"] - 1)
+            mp = "%s.%d" % (stname, m)
+            for b in range(nb):
+                t = xs[b]
+                for k in range(scfg["NUM_BLOCKS"][b]):
+                    p = "%s.branches.%d.%d" % (mp, b, k)
+                    u = A.conv_bn(t, p + ".conv1", p + ".bn1", relu=True)
+                    t = A.conv_bn(u, p + ".conv2", p + ".bn2", relu=True, residual=t)
+                xs[b] = t
+            outs = []
+            for i in range(nb if multi else 1):
+                acc = None
+                for j in range(nb):
+                    fp = "%s.fuse_layers.%d.%d" % (mp, i, j)
+                    if j == i:
+                        term = xs[j]
+                    elif j > i:
+                        z = A.conv_bn(xs[j], fp + ".0", fp + ".1")
+                        term = F.interpolate(z, scale_factor=2 ** (j - i), mode="nearest")
+                    else:
+                        term = xs[j]
+                        for k in range(i - j):
+                            last = k == i - j - 1
+                            term = A.conv_bn(term, "%s.%d.0" % (fp, k), "%s.%d.1" % (fp, k), 2, relu=not last)
+                    acc = term if acc is None else acc + term
+                outs.append(A.rnd(F.relu(acc)))
+            xs = outs
+            tap("%s.out0" % mp, xs[0])
+        ylist = xs
+        pre = cur
+    out = A.conv_bn(ylist[0], "final_layer", None, store=False)
+    return tap("heatmaps", out)

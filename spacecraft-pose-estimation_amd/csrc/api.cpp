@@ -1,0 +1,85 @@
+// extern "C" surface (include/scpose.h) over the kernels: decode, PnP, single-layer entry points.
+// The HRNet entry points live next to the plan in hrnet.cpp.
+#include "common.h"
+#include <new>
+
+using namespace scpose;
+
+struct scpose_conv { PackedConv pc; };
+
+extern "C" int32_t scpose_abi_version(void) { return SCPOSE_ABI_VERSION; }
+extern "C" const char* scpose_last_error(void) { return last_error(); }
+
+extern "C" int32_t scpose_decode(const float* heatmaps, int32_t n, int32_t j, int32_t h, int32_t w,
+                                 const float* center, const float* scale, int32_t post_process,
+                                 float* preds_xyc, void* stream) {
+  SCP_REQUIRE(heatmaps && preds_xyc, "decode: null argument");
+  return decode_launch(heatmaps, n, j, h, w, center, scale, post_process, preds_xyc, nullptr,
+                       nullptr, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t scpose_max_preds(const float* heatmaps, int32_t n, int32_t j, int32_t h,
+                                    int32_t w, float* coords, float* maxvals, void* stream) {
+  SCP_REQUIRE(heatmaps && coords && maxvals, "max_preds: null argument");
+  return decode_launch(heatmaps, n, j, h, w, nullptr, nullptr, 0, nullptr, coords, maxvals,
+                       static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t scpose_pnp_epnp_ransac(const float* kp_xyc, const double* landmarks,
+                                          const double* K, const double* dist, int32_t n, int32_t j,
+                                          float conf_thr0, int32_t min_pts, float thr_decay,
+                                          int32_t thr_iters, int32_t max_iters, double reproj_err,
+                                          double confidence, double* rot, double* tvec,
+                                          double* rvec, int32_t* status, void* stream) {
+  SCP_REQUIRE(kp_xyc && landmarks && K && rot && tvec && status, "pnp: null argument");
+  return pnp_launch(kp_xyc, landmarks, K, dist, n, j, conf_thr0, min_pts, thr_decay, thr_iters,
+                    max_iters, reproj_err, confidence, rot, tvec, rvec, status,
+                    static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t scpose_conv_create(const float* weight, const float* bias, int32_t cout,
+                                      int32_t cin, int32_t ksize, int32_t stride, int32_t dtype,
+                                      scpose_conv_t* out) {
+  SCP_REQUIRE(weight && out, "conv_create: null argument");
+  scpose_conv* c = new (std::nothrow) scpose_conv();
+  if (!c) { set_error("conv_create: out of host memory"); return SCPOSE_E_NOMEM; }
+  const int32_t rc = conv_upload(weight, bias, cout, cin, ksize, stride, dtype, &c->pc);
+  if (rc != SCPOSE_OK) { conv_free(&c->pc); delete c; return rc; }
+  *out = c;
+  return SCPOSE_OK;
+}
+
+extern "C" int32_t scpose_conv_destroy(scpose_conv_t c) {
+  if (!c) return SCPOSE_OK;
+  conv_free(&c->pc);
+  delete c;
+  return SCPOSE_OK;
+}
+
+extern "C" int32_t scpose_conv_forward(scpose_conv_t c, const void* in, int32_t n, int32_t h,
+                                       int32_t w, const void* residual, int32_t relu,
+                                       int32_t out_nchw_f32, void* out, void* stream) {
+  SCP_REQUIRE(c && in && out, "conv_forward: null argument");
+  return conv_launch(c->pc, in, n, h, w, residual, relu, out_nchw_f32, out,
+                     static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t scpose_fuse_sum(const void* const* terms, const int32_t* shifts, int32_t nterms,
+                                   int32_t n, int32_t c, int32_t h, int32_t w, int32_t dtype,
+                                   void* out, void* stream) {
+  SCP_REQUIRE(terms && shifts && out, "fuse_sum: null argument");
+  return fuse_sum_launch(terms, shifts, nterms, n, c, h, w, dtype, out,
+                         static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t scpose_nchw_f32_to_blocked(const float* src, int32_t n, int32_t c, int32_t h,
+                                              int32_t w, int32_t dtype, void* dst, void* stream) {
+  SCP_REQUIRE(src && dst, "nchw_f32_to_blocked: null argument");
+  return nchw_to_blocked_launch(src, n, c, h, w, dtype, dst, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t scpose_blocked_to_nchw_f32(const void* src, int32_t n, int32_t c, int32_t h,
+                                              int32_t w, int32_t dtype, float* dst, void* stream) {
+  SCP_REQUIRE(src && dst, "blocked_to_nchw_f32: null argument");
+  return blocked_to_nchw_launch(src, n, c, h, w, dtype, dst, static_cast<hipStream_t>(stream));
+}

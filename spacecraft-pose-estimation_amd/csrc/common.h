@@ -1,0 +1,123 @@
+// Internal declarations shared by the gfx950 kernels and the host-side plan.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include <string.h>
+
+#include "../../include/scpose.h"
+
+namespace scpose {
+
+// ---- error plumbing (thread-local message, int status; nothing throws across the ABI) ----
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+#define SCP_CHECK_HIP(expr)                                                         \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) {                                                         \
+      ::scpose::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+                          __FILE__, __LINE__);                                      \
+      return SCPOSE_E_HIP;                                                          \
+    }                                                                               \
+  } while (0)
+
+#define SCP_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      ::scpose::set_error(__VA_ARGS__);   \
+      return SCPOSE_E_INVALID;            \
+    }                                     \
+  } while (0)
+
+// ---- 3x3 / 1x1 implicit-GEMM convolution ---------------------------------------------------
+// Device-side description of one convolution launch.  All tensors are "blocked":
+// [N][C/8][H][W][8] 16-bit elements.
+struct ConvLaunch {
+  const void* in;      // blocked input  N x Cin x H x W
+  const void* wpk;     // packed weights (see pack_conv_weights)
+  const float* bias;   // f32 [n_mblk*MT] (zero padded)
+  const void* res;     // optional blocked residual, shape of out
+  void* out;           // blocked output, or f32 NCHW when out_nchw_f32
+  int32_t N, H, W, Ho, Wo;
+  int32_t cin_planes;  // Cin/8
+  int32_t cout;        // real Cout (for store masks)
+  int32_t th, tw;      // output tile (th*tw <= 64*NREP)
+  int32_t tiles_x, tiles_y;
+  int32_t halo_w, halo_h;
+  int32_t plane_stride;  // LDS bytes per staged input plane
+  int32_t cp;            // planes per K-chunk (even)
+  int32_t nchunks;
+  int32_t ksteps_full;   // k-steps (32 deep) of a full chunk
+  int32_t n_mblk;        // Cout blocks of MT
+  int32_t relu;
+  int32_t out_nchw_f32;
+  int32_t total_blocks;
+};
+
+// Per-layer choice of kernel variant + tiling.
+struct ConvConfig {
+  int ks, stride;      // 1|3, 1|2
+  int mrep, nrep;      // 16x16 MFMA tiles per wave along Cout / pixels
+  int th, tw;          // output tile
+  int cp;              // input planes (8 channels each) per K chunk
+};
+
+struct PackedConv {
+  int cin, cout, ks, stride, dtype;
+  int mt;              // cout block (16*mrep)
+  int n_mblk;
+  int cp, nchunks, ksteps_full;
+  size_t wbytes;       // packed weight bytes
+  void* d_w = nullptr;     // device packed weights
+  float* d_bias = nullptr; // device bias (n_mblk*mt)
+  int mrep;
+};
+
+// Pick (mrep, cp) for a layer independent of the spatial size; tiles are chosen per launch.
+void choose_mrep_cp(int cin, int cout, int ks, int stride, int* mrep, int* cp);
+// Choose spatial tiling for an output map.
+void choose_tile(int ks, int stride, int Ho, int Wo, int* nrep, int* th, int* tw);
+
+// Host: fold-free packing of f32 OIHW weights into the kernel's LDS image order.
+// Returns bytes; fills `dst` (16-bit words) when non-null.
+size_t pack_conv_weights(const float* w, int cout, int cin, int ks, int mt, int cp, int dtype,
+                         uint16_t* dst, int* nchunks, int* ksteps_full);
+
+int32_t conv_upload(const float* w, const float* bias, int cout, int cin, int ks, int stride,
+                    int dtype, PackedConv* pc);
+void conv_free(PackedConv* pc);
+int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, const void* res,
+                    int relu, int out_nchw_f32, void* out, hipStream_t stream);
+size_t conv_lds_bytes(const PackedConv& pc, int nrep, int th, int tw);
+
+// ---- stem: 3 -> 64, 3x3 stride 2 from f32 NCHW or u8 NHWC ----------------------------------
+int32_t stem_launch(const void* in, int in_fmt, const float* w_folded /*dev [64][27]*/,
+                    const float* bias /*dev [64]*/, const float* mean_std /*dev [6] or null*/,
+                    int N, int H, int W, int dtype, void* out, hipStream_t stream);
+
+// ---- elementwise ---------------------------------------------------------------------------
+int32_t fuse_sum_launch(const void* const* terms, const int32_t* shifts, int nterms, int N, int C,
+                        int H, int W, int dtype, void* out, hipStream_t stream);
+int32_t nchw_to_blocked_launch(const float* src, int N, int C, int H, int W, int dtype, void* dst,
+                               hipStream_t stream);
+int32_t blocked_to_nchw_launch(const void* src, int N, int C, int H, int W, int dtype, float* dst,
+                               hipStream_t stream);
+
+// ---- decode / pnp --------------------------------------------------------------------------
+int32_t decode_launch(const float* hm, int N, int J, int H, int W, const float* center,
+                      const float* scale, int post_process, float* preds_xyc, float* coords,
+                      float* maxvals, hipStream_t stream);
+int32_t pnp_launch(const float* kp_xyc, const double* landmarks, const double* K,
+                   const double* dist, int N, int J, float conf_thr0, int min_pts, float thr_decay,
+                   int thr_iters, int max_iters, double reproj_err, double confidence, double* rot,
+                   double* tvec, double* rvec, int32_t* status, hipStream_t stream);
+
+// f32 -> 16-bit storage on the host (round to nearest even), matching the device casts.
+uint16_t host_f32_to_16(float f, int dtype);
+float host_16_to_f32(uint16_t v, int dtype);
+
+}  // namespace scpose

@@ -1,0 +1,117 @@
+// Heatmap decode: one wavefront per (frame, joint) map.
+//
+// Replaces get_max_preds (landmark_regression/lib/core/inference.py:18-46), the quarter-pixel
+// refinement and back-transform of get_final_preds (:49-79) with transform_preds /
+// get_affine_transform(inv=1) / affine_transform (lib/utils/transforms.py:49-110), and the
+// [x, y, maxval] row assembly of validate() (lib/core/function.py:392-393).
+//
+// HBM-bound: each map (H*W f32) is read exactly once with 16 B/lane loads; the 64 lanes keep a
+// running (value, first index) pair and combine with 6 xor-shuffles.  Tie / NaN rules are
+// numpy's: first occurrence wins, NaN counts as the maximum (first NaN wins).
+#include "common.h"
+
+namespace scpose {
+
+__device__ __forceinline__ bool better(float v1, int i1, float v2, int i2) {
+  const bool n1 = v1 != v1, n2 = v2 != v2;
+  if (n1 || n2) return (n1 && n2) ? (i1 < i2) : n1;
+  return v1 > v2 || (v1 == v2 && i1 < i2);
+}
+
+struct DecodeArgs {
+  const float* hm;
+  const float* center;
+  const float* scale;
+  float* preds_xyc;  // N*J*3 or null
+  float* coords;     // N*J*2 or null (get_max_preds coords, heatmap px, masked)
+  float* maxvals;    // N*J or null
+  int N, J, H, W;
+  int post_process;
+};
+
+__global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int map = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (map >= a.N * a.J) return;  // whole wave exits together
+  const int HW = a.H * a.W;
+  const float* m = a.hm + (size_t)map * HW;
+
+  float bv = -__builtin_inff();
+  int bi = 0x7fffffff;
+  if ((HW & 3) == 0) {
+    for (int i = lane * 4; i < HW; i += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(m + i);
+      if (better(v.x, i, bv, bi)) { bv = v.x; bi = i; }
+      if (better(v.y, i + 1, bv, bi)) { bv = v.y; bi = i + 1; }
+      if (better(v.z, i + 2, bv, bi)) { bv = v.z; bi = i + 2; }
+      if (better(v.w, i + 3, bv, bi)) { bv = v.w; bi = i + 3; }
+    }
+  } else {
+    for (int i = lane; i < HW; i += 64) {
+      const float v = m[i];
+      if (better(v, i, bv, bi)) { bv = v; bi = i; }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float ov = __shfl_xor(bv, off, 64);
+    const int oi = __shfl_xor(bi, off, 64);
+    if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  }
+  if (lane != 0) return;
+
+  // inference.py:37-45 -- idx as float32, x = idx % W, y = floor(idx / W), masked when !(max > 0)
+  float cx = (float)(bi % a.W), cy = (float)(bi / a.W);
+  if (!(bv > 0.0f)) { cx = 0.f; cy = 0.f; }
+  if (a.maxvals) a.maxvals[map] = bv;
+  if (a.coords) { a.coords[map * 2] = cx; a.coords[map * 2 + 1] = cy; }
+  if (!a.preds_xyc) return;
+
+  if (a.post_process) {  // inference.py:56-69 (strict inequalities, sign(0) = 0)
+    const int px = (int)floorf(cx + 0.5f), py = (int)floorf(cy + 0.5f);
+    if (1 < px && px < a.W - 1 && 1 < py && py < a.H - 1) {
+      const float dx = m[py * a.W + px + 1] - m[py * a.W + px - 1];
+      const float dy = m[(py + 1) * a.W + px] - m[(py - 1) * a.W + px];
+      const float sx = dx != dx ? dx : (dx > 0.f ? 1.f : (dx < 0.f ? -1.f : 0.f));
+      const float sy = dy != dy ? dy : (dy > 0.f ? 1.f : (dy < 0.f ? -1.f : 0.f));
+      cx += sx * 0.25f;
+      cy += sy * 0.25f;
+    }
+  }
+
+  // transforms.py:57-89 with rot = 0, inv = 1, output_size = (W, H).  The three float32 point
+  // pairs the reference hands to cv2.getAffineTransform are rebuilt with the same float32
+  // roundings; the affine map they define is then solved in closed form in float64:
+  //   dst: (W/2,H/2) (W/2,H/2-W/2) (0,H/2-W/2)  ->  src: (cx,cy) (cx,s1y) (s2x,s1y)
+  const int n = map / a.J;
+  const float ccx = a.center[n * 2], ccy = a.center[n * 2 + 1];
+  const float src_w = __fmul_rn(a.scale[n * 2], 200.0f);       // scale_tmp[0]
+  const float s1y = __fadd_rn(ccy, -0.5f * src_w);              // src[1,1]
+  const float d = __fsub_rn(ccy, s1y);                          // direct[1] of get_3rd_point
+  const float s2x = __fsub_rn(ccx, d);                          // src[2,0]
+  const double half_w = 0.5 * (double)a.W, half_h = 0.5 * (double)a.H;
+  const double a00 = ((double)ccx - (double)s2x) / half_w;
+  const double a11 = ((double)ccy - (double)s1y) / half_w;
+  const double xi = (double)ccx + a00 * ((double)cx - half_w);
+  const double yi = (double)ccy + a11 * ((double)cy - half_h);
+  float* o = a.preds_xyc + (size_t)map * 3;
+  o[0] = (float)xi;
+  o[1] = (float)yi;
+  o[2] = bv;
+}
+
+int32_t decode_launch(const float* hm, int N, int J, int H, int W, const float* center,
+                      const float* scale, int post_process, float* preds_xyc, float* coords,
+                      float* maxvals, hipStream_t stream) {
+  SCP_REQUIRE(N >= 0 && J > 0 && H > 0 && W > 0, "decode: bad shape N=%d J=%d H=%d W=%d", N, J, H, W);
+  SCP_REQUIRE((size_t)H * W < (1u << 24), "decode: H*W=%zu not exactly representable in float32 (reference :37)", (size_t)H * W);
+  SCP_REQUIRE(!preds_xyc || (center && scale), "decode: center/scale required for image-space output");
+  if (N == 0) return SCPOSE_OK;
+  DecodeArgs a{hm, center, scale, preds_xyc, coords, maxvals, N, J, H, W, post_process};
+  const int maps = N * J;
+  hipLaunchKernelGGL(decode_kernel, dim3((maps + 3) / 4), dim3(256), 0, stream, a);
+  SCP_CHECK_HIP(hipGetLastError());
+  return SCPOSE_OK;
+}
+
+}  // namespace scpose

@@ -1,0 +1,470 @@
+// Host-side plan of the pose_hrnet forward: builds the launch list from the model description,
+// folds BatchNorm into the convolutions, packs weights for the MFMA kernels, plans the
+// activation arena, and replays the launch list on a stream.
+//
+// Structure follows the reference landmark_regression/lib/models/pose_hrnet.py:
+//   stem :282-288/:426-431, layer1 (4 Bottlenecks) :289/:374-391/:78-98,
+//   transitions :333-372 (new branch always from the LAST previous branch, :445/:453),
+//   HighResolutionModule branches :139-185 + fuse :187-242/:247-265,
+//   stages :393-423 (last stage-4 module fuses to branch 0 only), final_layer :323-329/:458.
+// Checkpoint keys are the reference module's state_dict keys.
+#include <math.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <new>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace scpose {
+
+static const double kBnEps = 1e-5;
+
+struct HostTensor { const float* p; int64_t n; };
+
+struct Weights {
+  std::map<std::string, HostTensor> m;
+  bool allow_missing;
+  std::string missing;  // first missing key
+
+  const float* get(const std::string& k, int64_t numel) {
+    auto it = m.find(k);
+    if (it == m.end() || it->second.n != numel) {
+      if (missing.empty()) missing = k + (it == m.end() ? "" : " (wrong size)");
+      return nullptr;
+    }
+    return it->second.p;
+  }
+};
+
+// conv(+bn) -> folded f32 weight [cout][cin][k][k] and bias [cout]
+static bool fold(Weights& W, const std::string& conv, const std::string& bn, int cout, int cin,
+                 int ks, bool conv_bias, std::vector<float>* w, std::vector<float>* b) {
+  const int64_t per = (int64_t)cin * ks * ks;
+  w->assign((size_t)cout * per, 0.f);
+  b->assign(cout, 0.f);
+  const float* cw = W.get(conv + ".weight", cout * per);
+  const float* cb = conv_bias ? W.get(conv + ".bias", cout) : nullptr;
+  const float *g = nullptr, *be = nullptr, *mu = nullptr, *var = nullptr;
+  if (!bn.empty()) {
+    g = W.get(bn + ".weight", cout); be = W.get(bn + ".bias", cout);
+    mu = W.get(bn + ".running_mean", cout); var = W.get(bn + ".running_var", cout);
+  }
+  if (!W.missing.empty() && !W.allow_missing) return false;
+  for (int o = 0; o < cout; ++o) {
+    double s = 1.0, sh = 0.0;
+    if (!bn.empty()) {
+      const double gg = g ? g[o] : 1.0, bb = be ? be[o] : 0.0, mm = mu ? mu[o] : 0.0, vv = var ? var[o] : 1.0;
+      s = gg / sqrt(vv + kBnEps);
+      sh = bb - mm * s;
+    }
+    if (cw)
+      for (int64_t i = 0; i < per; ++i) (*w)[o * per + i] = (float)((double)cw[o * per + i] * s);
+    (*b)[o] = (float)((cb ? (double)cb[o] * s : 0.0) + sh);
+  }
+  return true;
+}
+
+enum OpKind { OP_STEM = 0, OP_CONV = 1, OP_FUSE = 2 };
+
+struct TensorDesc {
+  int C, ds;       // channels, log2 spatial downscale w.r.t. the network input
+  int last_use;    // index of the last op reading it
+  size_t off;      // byte offset in the workspace (planned per batch shape)
+};
+
+struct Op {
+  int kind;
+  int in, out, res;  // tensor ids (-1 none; in == -2: network input; out == -2: heatmaps)
+  int conv;          // index into convs
+  int relu, out_f32;
+  int nterms, term[4], shift[4];
+};
+
+}  // namespace scpose
+
+struct scpose_hrnet {
+  scpose_hrnet_desc desc;
+  int device = 0;
+  std::vector<scpose::PackedConv> convs;
+  float* d_stem_w = nullptr;   // [64][27] folded
+  float* d_stem_b = nullptr;   // [64]
+  float* d_mean_std = nullptr; // [6]
+  std::vector<scpose::TensorDesc> tensors;
+  std::vector<scpose::Op> ops;
+  // cached arena plan
+  int plan_n = -1, plan_h = -1, plan_w = -1;
+  size_t plan_bytes = 0;
+};
+
+namespace scpose {
+
+struct Builder {
+  scpose_hrnet* net;
+  Weights* W;
+  int32_t status = SCPOSE_OK;
+
+  int new_tensor(int C, int ds) {
+    net->tensors.push_back(TensorDesc{C, ds, -1, 0});
+    return (int)net->tensors.size() - 1;
+  }
+  // y = [relu](conv_bn(x) [+ res]);  returns output tensor id (or -2 for heatmaps)
+  int conv(int x, const std::string& cname, const std::string& bname, int cout, int ks, int stride,
+           bool relu, int res = -1, bool conv_bias = false, bool to_heatmaps = false) {
+    if (status != SCPOSE_OK) return -1;
+    const int cin = net->tensors[x].C;
+    std::vector<float> w, b;
+    if (!fold(*W, cname, bname, cout, cin, ks, conv_bias, &w, &b)) { status = SCPOSE_E_MISSING; return -1; }
+    PackedConv pc;
+    const int32_t st = conv_upload(w.data(), b.data(), cout, cin, ks, stride, net->desc.dtype, &pc);
+    if (st != SCPOSE_OK) { status = st; return -1; }
+    net->convs.push_back(pc);
+    const int ds = net->tensors[x].ds + (stride == 2 ? 1 : 0);
+    Op op{};
+    op.kind = OP_CONV; op.in = x; op.res = res; op.conv = (int)net->convs.size() - 1;
+    op.relu = relu; op.out_f32 = to_heatmaps;
+    op.out = to_heatmaps ? -2 : new_tensor(cout, ds);
+    net->ops.push_back(op);
+    return op.out;
+  }
+  int fuse(const std::vector<int>& terms, const std::vector<int>& shifts, int C, int ds) {
+    if (status != SCPOSE_OK) return -1;
+    Op op{};
+    op.kind = OP_FUSE; op.in = -1; op.res = -1; op.conv = -1; op.relu = 1;
+    op.nterms = (int)terms.size();
+    for (int k = 0; k < op.nterms; ++k) { op.term[k] = terms[k]; op.shift[k] = shifts[k]; }
+    op.out = new_tensor(C, ds);
+    net->ops.push_back(op);
+    return op.out;
+  }
+};
+
+static std::string fmt(const char* f, ...) {
+  char buf[256];
+  va_list ap; va_start(ap, f); vsnprintf(buf, sizeof(buf), f, ap); va_end(ap);
+  return buf;
+}
+
+int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
+  const scpose_hrnet_desc& d = net->desc;
+  Builder B{net, &W};
+
+  // ---- stem conv1 (f32 VALU kernel, own weight format) ----
+  {
+    std::vector<float> w, b;
+    if (!fold(W, "conv1", "bn1", 64, 3, 3, false, &w, &b)) return SCPOSE_E_MISSING;
+    SCP_CHECK_HIP(hipMalloc(&net->d_stem_w, w.size() * 4));
+    SCP_CHECK_HIP(hipMalloc(&net->d_stem_b, b.size() * 4));
+    SCP_CHECK_HIP(hipMalloc(&net->d_mean_std, 6 * 4));
+    SCP_CHECK_HIP(hipMemcpy(net->d_stem_w, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    SCP_CHECK_HIP(hipMemcpy(net->d_stem_b, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+    float ms[6] = {d.mean[0], d.mean[1], d.mean[2], d.std[0], d.std[1], d.std[2]};
+    SCP_CHECK_HIP(hipMemcpy(net->d_mean_std, ms, sizeof(ms), hipMemcpyHostToDevice));
+  }
+  Op stem{};
+  stem.kind = OP_STEM; stem.in = -2; stem.res = -1; stem.conv = -1; stem.relu = 1;
+  stem.out = B.new_tensor(64, 1);
+  net->ops.push_back(stem);
+  int x = stem.out;
+  x = B.conv(x, "conv2", "bn2", 64, 3, 2, true);
+
+  // ---- layer1: 4 Bottlenecks (64 -> 256) ----
+  for (int b = 0; b < 4; ++b) {
+    const std::string p = fmt("layer1.%d", b);
+    int res = x;
+    if (b == 0) res = B.conv(x, p + ".downsample.0", p + ".downsample.1", 256, 1, 1, false);
+    int y = B.conv(x, p + ".conv1", p + ".bn1", 64, 1, 1, true);
+    y = B.conv(y, p + ".conv2", p + ".bn2", 64, 3, 1, true);
+    x = B.conv(y, p + ".conv3", p + ".bn3", 256, 1, 1, true, res);
+  }
+
+  std::vector<int> ylist{x};
+  std::vector<int> pre{256};
+  for (int si = 0; si < 3; ++si) {
+    const int nb = d.num_branches[si];
+    std::vector<int> cur(d.num_channels[si], d.num_channels[si] + nb);
+    const std::string tname = fmt("transition%d", si + 1);
+    std::vector<int> xs;
+    for (int i = 0; i < nb; ++i) {
+      if (i < (int)pre.size()) {
+        if (cur[i] != pre[i])
+          xs.push_back(B.conv(ylist.back(), fmt("%s.%d.0", tname.c_str(), i), fmt("%s.%d.1", tname.c_str(), i), cur[i], 3, 1, true));
+        else
+          xs.push_back(ylist[i]);
+      } else {
+        int t = ylist.back();
+        for (int j = 0; j < i + 1 - (int)pre.size(); ++j) {
+          const int cout = (j == i - (int)pre.size()) ? cur[i] : pre.back();
+          t = B.conv(t, fmt("%s.%d.%d.0", tname.c_str(), i, j), fmt("%s.%d.%d.1", tname.c_str(), i, j), cout, 3, 2, true);
+        }
+        xs.push_back(t);
+      }
+    }
+    for (int m = 0; m < d.num_modules[si]; ++m) {
+      const bool multi = !(si == 2 && m == d.num_modules[si] - 1);
+      const std::string mp = fmt("stage%d.%d", si + 2, m);
+      for (int b = 0; b < nb; ++b) {
+        int t = xs[b];
+        for (int k = 0; k < d.num_blocks[si][b]; ++k) {
+          const std::string p = fmt("%s.branches.%d.%d", mp.c_str(), b, k);
+          const int u = B.conv(t, p + ".conv1", p + ".bn1", cur[b], 3, 1, true);
+          t = B.conv(u, p + ".conv2", p + ".bn2", cur[b], 3, 1, true, t);
+        }
+        xs[b] = t;
+      }
+      std::vector<int> outs;
+      for (int i = 0; i < (multi ? nb : 1); ++i) {
+        std::vector<int> terms, shifts;
+        for (int j = 0; j < nb; ++j) {
+          const std::string fp = fmt("%s.fuse_layers.%d.%d", mp.c_str(), i, j);
+          if (j == i) {
+            terms.push_back(xs[j]); shifts.push_back(0);
+          } else if (j > i) {
+            terms.push_back(B.conv(xs[j], fp + ".0", fp + ".1", cur[i], 1, 1, false));
+            shifts.push_back(j - i);
+          } else {
+            int t = xs[j];
+            for (int k = 0; k < i - j; ++k) {
+              const bool last = k == i - j - 1;
+              t = B.conv(t, fmt("%s.%d.0", fp.c_str(), k), fmt("%s.%d.1", fp.c_str(), k), last ? cur[i] : cur[j], 3, 2, !last);
+            }
+            terms.push_back(t); shifts.push_back(0);
+          }
+        }
+        if (B.status != SCPOSE_OK) break;
+        outs.push_back(B.fuse(terms, shifts, cur[i], net->tensors[xs[i]].ds));
+      }
+      xs = outs;
+      if (B.status != SCPOSE_OK) break;
+    }
+    if (B.status != SCPOSE_OK) break;
+    ylist = xs;
+    pre = cur;
+  }
+  if (B.status == SCPOSE_OK)
+    B.conv(ylist[0], "final_layer", "", d.num_joints, d.final_conv_kernel, 1, false, -1, true, true);
+  if (B.status == SCPOSE_E_MISSING || (!W.missing.empty() && !W.allow_missing)) {
+    set_error("checkpoint tensor missing: %s", W.missing.c_str());
+    return SCPOSE_E_MISSING;
+  }
+  if (B.status != SCPOSE_OK) return B.status;
+
+  // liveness
+  for (size_t i = 0; i < net->ops.size(); ++i) {
+    const Op& op = net->ops[i];
+    auto use = [&](int t) { if (t >= 0) net->tensors[t].last_use = (int)i; };
+    use(op.in); use(op.res);
+    for (int k = 0; k < op.nterms; ++k) use(op.term[k]);
+  }
+  return SCPOSE_OK;
+}
+
+static size_t tensor_bytes(const TensorDesc& t, int n, int h, int w) {
+  const size_t b = (size_t)n * t.C * (h >> t.ds) * (w >> t.ds) * 2;
+  return (b + 255) & ~(size_t)255;
+}
+
+// Greedy first-fit arena: an output is placed when its producer runs, freed after its last reader.
+size_t hrnet_plan(scpose_hrnet* net, int n, int h, int w) {
+  if (net->plan_n == n && net->plan_h == h && net->plan_w == w) return net->plan_bytes;
+  struct Blk { size_t off, size; };
+  std::vector<Blk> freel;
+  size_t top = 0;
+  auto alloc = [&](size_t sz) {
+    int best = -1;
+    for (size_t i = 0; i < freel.size(); ++i)
+      if (freel[i].size >= sz && (best < 0 || freel[i].size < freel[best].size)) best = (int)i;
+    if (best >= 0) {
+      const size_t off = freel[best].off;
+      if (freel[best].size == sz) freel.erase(freel.begin() + best);
+      else { freel[best].off += sz; freel[best].size -= sz; }
+      return off;
+    }
+    // grow: extend a trailing free block if there is one
+    for (size_t i = 0; i < freel.size(); ++i)
+      if (freel[i].off + freel[i].size == top) {
+        const size_t off = freel[i].off;
+        top = off + sz;
+        freel.erase(freel.begin() + i);
+        return off;
+      }
+    const size_t off = top;
+    top += sz;
+    return off;
+  };
+  auto release = [&](size_t off, size_t sz) {
+    freel.push_back(Blk{off, sz});
+    bool merged = true;
+    while (merged) {
+      merged = false;
+      for (size_t i = 0; i < freel.size() && !merged; ++i)
+        for (size_t j = 0; j < freel.size() && !merged; ++j)
+          if (i != j && freel[i].off + freel[i].size == freel[j].off) {
+            freel[i].size += freel[j].size;
+            freel.erase(freel.begin() + j);
+            merged = true;
+          }
+    }
+  };
+  for (size_t i = 0; i < net->ops.size(); ++i) {
+    const Op& op = net->ops[i];
+    if (op.out >= 0) net->tensors[op.out].off = alloc(tensor_bytes(net->tensors[op.out], n, h, w));
+    auto done = [&](int t) {
+      if (t >= 0 && net->tensors[t].last_use == (int)i) {
+        release(net->tensors[t].off, tensor_bytes(net->tensors[t], n, h, w));
+        net->tensors[t].last_use = -100 - (int)i;  // guard against double release (same tensor twice)
+      }
+    };
+    done(op.in); done(op.res);
+    for (int k = 0; k < op.nterms; ++k) done(op.term[k]);
+    // an output nobody reads (cannot happen in a well-formed net) is simply never reused
+  }
+  // restore last_use for the next plan
+  for (auto& t : net->tensors)
+    if (t.last_use <= -100) t.last_use = -(t.last_use + 100);
+  net->plan_n = n; net->plan_h = h; net->plan_w = w; net->plan_bytes = top;
+  return top;
+}
+
+int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int h, int w,
+                      float* heatmaps, void* ws, size_t ws_bytes, hipStream_t st) {
+  SCP_REQUIRE(n > 0, "hrnet_forward: batch %d", n);
+  SCP_REQUIRE(h % 32 == 0 && w % 32 == 0 && h > 0 && w > 0, "hrnet_forward: H=%d W=%d must be multiples of 32", h, w);
+  const size_t need = hrnet_plan(net, n, h, w);
+  if (ws_bytes < need || !ws) {
+    set_error("hrnet_forward: workspace %zu bytes < required %zu", ws_bytes, need);
+    return SCPOSE_E_WORKSPACE;
+  }
+  char* base = static_cast<char*>(ws);
+  auto ptr = [&](int t) -> void* { return t >= 0 ? base + net->tensors[t].off : nullptr; };
+  for (const Op& op : net->ops) {
+    int32_t rc = SCPOSE_OK;
+    if (op.kind == OP_STEM) {
+      rc = stem_launch(in, in_fmt, net->d_stem_w, net->d_stem_b, net->d_mean_std, n, h, w,
+                       net->desc.dtype, ptr(op.out), st);
+    } else if (op.kind == OP_CONV) {
+      const TensorDesc& ti = net->tensors[op.in];
+      void* out = op.out == -2 ? static_cast<void*>(heatmaps) : ptr(op.out);
+      rc = conv_launch(net->convs[op.conv], ptr(op.in), n, h >> ti.ds, w >> ti.ds, ptr(op.res),
+                       op.relu, op.out_f32, out, st);
+    } else {
+      const TensorDesc& to = net->tensors[op.out];
+      const void* terms[4];
+      for (int k = 0; k < op.nterms; ++k) terms[k] = ptr(op.term[k]);
+      rc = fuse_sum_launch(terms, op.shift, op.nterms, n, to.C, h >> to.ds, w >> to.ds,
+                           net->desc.dtype, ptr(op.out), st);
+    }
+    if (rc != SCPOSE_OK) return rc;
+  }
+  return SCPOSE_OK;
+}
+
+void hrnet_stats(scpose_hrnet* net, int h, int w, int* launches, double* flops, double* bytes) {
+  double f = 0, by = 0;
+  for (const Op& op : net->ops) {
+    if (op.kind == OP_STEM) {
+      f += 2.0 * 27 * 64 * (h / 2) * (w / 2);
+      by += 0;  // network input/first output counted below with the tensors
+      by += (double)64 * (h / 2) * (w / 2) * 2;
+    } else if (op.kind == OP_CONV) {
+      const PackedConv& pc = net->convs[op.conv];
+      const TensorDesc& ti = net->tensors[op.in];
+      const double hi = h >> ti.ds, wi = w >> ti.ds;
+      const double ho = pc.stride == 2 ? hi / 2 : hi, wo = pc.stride == 2 ? wi / 2 : wi;
+      f += 2.0 * pc.cin * pc.cout * pc.ks * pc.ks * ho * wo;
+      by += pc.cin * hi * wi * 2 + pc.cout * ho * wo * (op.out_f32 ? 4 : 2) + (op.res >= 0 ? pc.cout * ho * wo * 2 : 0);
+    } else {
+      const TensorDesc& to = net->tensors[op.out];
+      const double ho = h >> to.ds, wo = w >> to.ds;
+      by += to.C * ho * wo * 2;
+      for (int k = 0; k < op.nterms; ++k) by += to.C * (ho / (1 << op.shift[k])) * (wo / (1 << op.shift[k])) * 2;
+    }
+  }
+  if (launches) *launches = (int)net->ops.size();
+  if (flops) *flops = f;
+  if (bytes) *bytes = by;
+}
+
+void hrnet_free(scpose_hrnet* net) {
+  for (auto& c : net->convs) conv_free(&c);
+  if (net->d_stem_w) (void)hipFree(net->d_stem_w);
+  if (net->d_stem_b) (void)hipFree(net->d_stem_b);
+  if (net->d_mean_std) (void)hipFree(net->d_mean_std);
+}
+
+}  // namespace scpose
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+using namespace scpose;
+
+extern "C" int32_t scpose_hrnet_create(const scpose_hrnet_desc* desc, const char* const* names,
+                                       const float* const* ptrs, const int64_t* numels,
+                                       int32_t count, int32_t allow_missing, scpose_hrnet_t* out) {
+  SCP_REQUIRE(desc && out, "hrnet_create: null argument");
+  SCP_REQUIRE(desc->num_stages == 3, "hrnet_create: num_stages=%d (pose_hrnet has STAGE2..STAGE4)", desc->num_stages);
+  SCP_REQUIRE(desc->num_joints > 0, "hrnet_create: num_joints=%d", desc->num_joints);
+  SCP_REQUIRE(desc->final_conv_kernel == 1 || desc->final_conv_kernel == 3, "hrnet_create: FINAL_CONV_KERNEL=%d", desc->final_conv_kernel);
+  SCP_REQUIRE(desc->dtype == SCPOSE_DT_BF16 || desc->dtype == SCPOSE_DT_F16, "hrnet_create: dtype=%d", desc->dtype);
+  for (int s = 0; s < 3; ++s) {
+    SCP_REQUIRE(desc->num_branches[s] == s + 2, "hrnet_create: STAGE%d NUM_BRANCHES=%d (expected %d)", s + 2, desc->num_branches[s], s + 2);
+    SCP_REQUIRE(desc->num_modules[s] >= 1, "hrnet_create: STAGE%d NUM_MODULES=%d", s + 2, desc->num_modules[s]);
+    for (int b = 0; b < desc->num_branches[s]; ++b) {
+      SCP_REQUIRE(desc->num_channels[s][b] > 0 && desc->num_channels[s][b] % 16 == 0,
+                  "hrnet_create: STAGE%d NUM_CHANNELS[%d]=%d must be a positive multiple of 16", s + 2, b, desc->num_channels[s][b]);
+      SCP_REQUIRE(desc->num_blocks[s][b] >= 1, "hrnet_create: STAGE%d NUM_BLOCKS[%d]=%d", s + 2, b, desc->num_blocks[s][b]);
+      if (s > 0 && b < desc->num_branches[s - 1])
+        SCP_REQUIRE(desc->num_channels[s][b] == desc->num_channels[s - 1][b],
+                    "hrnet_create: STAGE%d branch %d changes channel count (%d -> %d); the reference forward (:445) cannot run that either",
+                    s + 2, b, desc->num_channels[s - 1][b], desc->num_channels[s][b]);
+    }
+  }
+  Weights W;
+  W.allow_missing = allow_missing != 0;
+  for (int i = 0; i < count; ++i)
+    if (names[i] && ptrs[i]) W.m[names[i]] = HostTensor{ptrs[i], numels[i]};
+  scpose_hrnet* net = new (std::nothrow) scpose_hrnet();
+  if (!net) { set_error("hrnet_create: out of host memory"); return SCPOSE_E_NOMEM; }
+  net->desc = *desc;
+  (void)hipGetDevice(&net->device);
+  const int32_t rc = hrnet_build(net, W);
+  if (rc != SCPOSE_OK) { hrnet_free(net); delete net; return rc; }
+  *out = net;
+  return SCPOSE_OK;
+}
+
+extern "C" int32_t scpose_hrnet_destroy(scpose_hrnet_t h) {
+  if (!h) return SCPOSE_OK;
+  hrnet_free(h);
+  delete h;
+  return SCPOSE_OK;
+}
+
+extern "C" int32_t scpose_hrnet_workspace_bytes(scpose_hrnet_t h, int32_t n, int32_t height,
+                                                int32_t width, size_t* bytes) {
+  SCP_REQUIRE(h && bytes, "hrnet_workspace_bytes: null argument");
+  SCP_REQUIRE(n > 0 && height > 0 && width > 0 && height % 32 == 0 && width % 32 == 0,
+              "hrnet_workspace_bytes: n=%d H=%d W=%d (H, W multiples of 32)", n, height, width);
+  *bytes = hrnet_plan(h, n, height, width);
+  return SCPOSE_OK;
+}
+
+extern "C" int32_t scpose_hrnet_stats(scpose_hrnet_t h, int32_t height, int32_t width,
+                                      int32_t* launches, double* flops_per_frame,
+                                      double* act_bytes_per_frame) {
+  SCP_REQUIRE(h, "hrnet_stats: null handle");
+  hrnet_stats(h, height, width, launches, flops_per_frame, act_bytes_per_frame);
+  return SCPOSE_OK;
+}
+
+extern "C" int32_t scpose_hrnet_forward(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n,
+                                        int32_t height, int32_t width, float* heatmaps,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+  SCP_REQUIRE(h && in && heatmaps, "hrnet_forward: null argument");
+  return hrnet_forward(h, in, in_fmt, n, height, width, heatmaps, workspace, workspace_bytes,
+                       static_cast<hipStream_t>(stream));
+}

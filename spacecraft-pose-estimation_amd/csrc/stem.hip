@@ -1,0 +1,102 @@
+// Stem conv1: 3 -> 64 channels, 3x3, stride 2, pad 1, folded BN + ReLU, f32 arithmetic.
+//
+// Replaces conv1/bn1/relu of the reference forward
+// (landmark_regression/lib/models/pose_hrnet.py:282-284, :426-428) and, for the uint8 input
+// format, the ToTensor()+Normalize(mean,std) of landmark_regression/tools/test.py:106-114
+// (x/255 - mean)/std fused into the load.
+//
+// K = 27 is too thin for MFMA; the layer is 0.13 % of the network's FLOPs and is bound by
+// its 64-channel output write, so it runs on the f32 VALU: one thread per output pixel, all
+// 64 output channels, weights through the scalar cache (wave-uniform addresses -> s_load).
+// Output is the blocked [N][8][H/2][W/2][8] 16-bit tensor the MFMA convolutions consume.
+#include "common.h"
+
+namespace scpose {
+
+template <typename T> __device__ __forceinline__ uint16_t stem_bits(float f) {
+  T t = (T)f;
+  return __builtin_bit_cast(uint16_t, t);
+}
+
+template <typename T, int FMT>
+__global__ __launch_bounds__(256) void stem_conv1_kernel(const void* __restrict__ in,
+                                                         const float* __restrict__ w,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ mean_std,
+                                                         int N, int H, int W, void* __restrict__ out) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const size_t total = (size_t)N * Ho * Wo;
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int ox = (int)(gid % Wo);
+  const int oy = (int)((gid / Wo) % Ho);
+  const int n = (int)(gid / ((size_t)Wo * Ho));
+
+  float x[27];  // [c][ky][kx], matching OIHW weight order
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = 2 * oy + ky - 1;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = 2 * ox + kx - 1;
+      const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float v = 0.f;
+        if (ok) {
+          if constexpr (FMT == SCPOSE_IN_F32_NCHW) {
+            v = static_cast<const float*>(in)[(((size_t)n * 3 + c) * H + iy) * W + ix];
+          } else {
+            const float u = (float)static_cast<const uint8_t*>(in)[(((size_t)n * H + iy) * W + ix) * 3 + c];
+            // ToTensor: u/255 ; Normalize: (t - mean)/std   (same op order as torchvision)
+            v = (u / 255.0f - mean_std[c]) / mean_std[3 + c];
+          }
+        }
+        x[c * 9 + ky * 3 + kx] = v;
+      }
+    }
+  }
+
+  const size_t plane = (size_t)Ho * Wo;
+  char* obase = static_cast<char*>(out) + (((size_t)n * 8) * plane + (size_t)oy * Wo + ox) * 16;
+#pragma unroll 1
+  for (int cg = 0; cg < 8; ++cg) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float* wr = w + (cg * 8 + j) * 27;
+      float a = bias[cg * 8 + j];
+#pragma unroll
+      for (int k = 0; k < 27; ++k) a = fmaf(x[k], wr[k], a);
+      acc[j] = fmaxf(a, 0.f);
+    }
+    uint4 o;
+    o.x = (uint32_t)stem_bits<T>(acc[0]) | ((uint32_t)stem_bits<T>(acc[1]) << 16);
+    o.y = (uint32_t)stem_bits<T>(acc[2]) | ((uint32_t)stem_bits<T>(acc[3]) << 16);
+    o.z = (uint32_t)stem_bits<T>(acc[4]) | ((uint32_t)stem_bits<T>(acc[5]) << 16);
+    o.w = (uint32_t)stem_bits<T>(acc[6]) | ((uint32_t)stem_bits<T>(acc[7]) << 16);
+    *reinterpret_cast<uint4*>(obase + (size_t)cg * plane * 16) = o;
+  }
+}
+
+int32_t stem_launch(const void* in, int in_fmt, const float* w_folded, const float* bias,
+                    const float* mean_std, int N, int H, int W, int dtype, void* out,
+                    hipStream_t stream) {
+  SCP_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H=%d W=%d must be even", H, W);
+  SCP_REQUIRE(in_fmt == SCPOSE_IN_F32_NCHW || in_fmt == SCPOSE_IN_U8_NHWC, "stem: input format %d", in_fmt);
+  SCP_REQUIRE(in_fmt == SCPOSE_IN_F32_NCHW || mean_std, "stem: u8 input needs mean/std");
+  const size_t total = (size_t)N * (H / 2) * (W / 2);
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  const bool bf = dtype == SCPOSE_DT_BF16;
+  if (in_fmt == SCPOSE_IN_F32_NCHW) {
+    if (bf) hipLaunchKernelGGL((stem_conv1_kernel<__bf16, SCPOSE_IN_F32_NCHW>), grid, block, 0, stream, in, w_folded, bias, mean_std, N, H, W, out);
+    else hipLaunchKernelGGL((stem_conv1_kernel<_Float16, SCPOSE_IN_F32_NCHW>), grid, block, 0, stream, in, w_folded, bias, mean_std, N, H, W, out);
+  } else {
+    if (bf) hipLaunchKernelGGL((stem_conv1_kernel<__bf16, SCPOSE_IN_U8_NHWC>), grid, block, 0, stream, in, w_folded, bias, mean_std, N, H, W, out);
+    else hipLaunchKernelGGL((stem_conv1_kernel<_Float16, SCPOSE_IN_U8_NHWC>), grid, block, 0, stream, in, w_folded, bias, mean_std, N, H, W, out);
+  }
+  SCP_CHECK_HIP(hipGetLastError());
+  return SCPOSE_OK;
+}
+
+}  // namespace scpose

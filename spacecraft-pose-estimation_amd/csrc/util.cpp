@@ -1,0 +1,20 @@
+// Error plumbing of the C ABI: thread-local message, no exceptions across the boundary.
+#include "common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+namespace scpose {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+const char* last_error() { return g_err; }
+
+}  // namespace scpose

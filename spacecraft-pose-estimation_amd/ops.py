@@ -1,0 +1,255 @@
+"""Thin torch-facing wrappers over the C ABI (device memory, streams: plumbing only).
+
+Every function here launches HIP kernels from libscpose_hip.so on the current torch
+stream; tensors must live on a ROCm device.  Nothing falls back to eager PyTorch.
+"""
+import ctypes
+from ctypes import c_int32, c_int64, c_void_p, c_char_p, c_size_t, c_double
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+_TORCH_DT = {nat.DT_BF16: torch.bfloat16, nat.DT_F16: torch.float16}
+_DT_OF = {"bf16": nat.DT_BF16, "f16": nat.DT_F16, "fp16": nat.DT_F16, "bfloat16": nat.DT_BF16,
+          "float16": nat.DT_F16}
+
+
+def dtype_code(dtype):
+    if isinstance(dtype, int):
+        return dtype
+    return _DT_OF[str(dtype).replace("torch.", "")]
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise nat.NativeError("scpose ops need device tensors (got %s); there is no CPU path" % t.device)
+
+
+# ------------------------------------------------------------------ layout
+def to_blocked(x, dtype="bf16"):
+    """float32 NCHW (C % 8 == 0) -> blocked [N][C/8][H][W][8] 16-bit tensor."""
+    _need_cuda(x)
+    dt = dtype_code(dtype)
+    x = x.contiguous().float()
+    n, c, h, w = x.shape
+    out = torch.empty((n, c // 8, h, w, 8), dtype=_TORCH_DT[dt], device=x.device)
+    nat.check(nat.lib().scpose_nchw_f32_to_blocked(_ptr(x), n, c, h, w, dt, _ptr(out), _stream()), "nchw_f32_to_blocked")
+    return out
+
+
+def from_blocked(xb):
+    """blocked 16-bit tensor -> float32 NCHW."""
+    _need_cuda(xb)
+    n, cg, h, w, _ = xb.shape
+    dt = nat.DT_BF16 if xb.dtype == torch.bfloat16 else nat.DT_F16
+    out = torch.empty((n, cg * 8, h, w), dtype=torch.float32, device=xb.device)
+    nat.check(nat.lib().scpose_blocked_to_nchw_f32(_ptr(xb), n, cg * 8, h, w, dt, _ptr(out), _stream()), "blocked_to_nchw_f32")
+    return out
+
+
+# ------------------------------------------------------------------ single conv layer
+class Conv:
+    """One (BN-folded) convolution on the MFMA kernel: y = [relu](conv(x) + b [+ res])."""
+
+    def __init__(self, weight, bias=None, stride=1, dtype="bf16"):
+        w = weight.detach().float().cpu().contiguous()
+        self.cout, self.cin, self.ks, _ = w.shape
+        self.stride = stride
+        self.dt = dtype_code(dtype)
+        b = bias.detach().float().cpu().contiguous() if bias is not None else None
+        h = c_void_p()
+        nat.check(nat.lib().scpose_conv_create(c_void_p(w.data_ptr()), c_void_p(b.data_ptr()) if b is not None else c_void_p(0),
+                                               self.cout, self.cin, self.ks, stride, self.dt, ctypes.byref(h)), "conv_create")
+        self._h = h
+
+    def __call__(self, xb, residual=None, relu=False, out_nchw_f32=False):
+        _need_cuda(xb, residual)
+        n, cg, h, w, _ = xb.shape
+        assert cg * 8 == self.cin, (cg * 8, self.cin)
+        ho, wo = (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
+        if out_nchw_f32:
+            out = torch.empty((n, self.cout, ho, wo), dtype=torch.float32, device=xb.device)
+        else:
+            out = torch.empty((n, self.cout // 8, ho, wo, 8), dtype=xb.dtype, device=xb.device)
+        nat.check(nat.lib().scpose_conv_forward(self._h, _ptr(xb), n, h, w, _ptr(residual), int(relu), int(out_nchw_f32),
+                                                _ptr(out), _stream()), "conv_forward")
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                nat.lib().scpose_conv_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def fuse_sum(terms, shifts, out_hw):
+    """relu(sum_t nearest_upsample(term_t, 2**shift_t)); terms blocked, out at (H, W)."""
+    _need_cuda(*terms)
+    h, w = out_hw
+    n, cg = terms[0].shape[0], terms[0].shape[1]
+    dt = nat.DT_BF16 if terms[0].dtype == torch.bfloat16 else nat.DT_F16
+    out = torch.empty((n, cg, h, w, 8), dtype=terms[0].dtype, device=terms[0].device)
+    tp = (c_void_p * len(terms))(*[t.data_ptr() for t in terms])
+    sh = (c_int32 * len(terms))(*shifts)
+    nat.check(nat.lib().scpose_fuse_sum(tp, sh, len(terms), n, cg * 8, h, w, dt, _ptr(out), _stream()), "fuse_sum")
+    return out
+
+
+# ------------------------------------------------------------------ decode
+def decode(heatmaps, center, scale, post_process=True):
+    """heatmaps (N,J,H,W) f32 device; center/scale (N,2) f32 device -> (N,J,3) [x_img,y_img,maxval]."""
+    _need_cuda(heatmaps, center, scale)
+    hm = heatmaps.contiguous().float()
+    n, j, h, w = hm.shape
+    c = center.contiguous().float()
+    s = scale.contiguous().float()
+    out = torch.empty((n, j, 3), dtype=torch.float32, device=hm.device)
+    nat.check(nat.lib().scpose_decode(_ptr(hm), n, j, h, w, _ptr(c), _ptr(s), int(bool(post_process)), _ptr(out), _stream()), "decode")
+    return out
+
+
+def max_preds(heatmaps):
+    _need_cuda(heatmaps)
+    hm = heatmaps.contiguous().float()
+    n, j, h, w = hm.shape
+    coords = torch.empty((n, j, 2), dtype=torch.float32, device=hm.device)
+    maxvals = torch.empty((n, j, 1), dtype=torch.float32, device=hm.device)
+    nat.check(nat.lib().scpose_max_preds(_ptr(hm), n, j, h, w, _ptr(coords), _ptr(maxvals), _stream()), "max_preds")
+    return coords, maxvals
+
+
+# ------------------------------------------------------------------ PnP
+def pnp_epnp_ransac(kp_xyc, landmarks, K, dist, conf_thr0=0.95, min_pts=15, thr_decay=0.8, thr_iters=100,
+                    max_iters=10000, reproj_err=15.0, confidence=0.99, want_rvec=False):
+    """kp_xyc (N,J,3) f32 device; landmarks (J,3), K (3,3), dist (5,) f64 device.
+    Returns rot (N,3,3) f64, tvec (N,3) f64, status (N,) i32 [, rvec (N,3)]."""
+    _need_cuda(kp_xyc, landmarks, K, dist)
+    kp = kp_xyc.contiguous().float()
+    n, j, _ = kp.shape
+    dev = kp.device
+    lm = landmarks.contiguous().double()
+    Kd = K.contiguous().double()
+    dd = dist.contiguous().double() if dist is not None else torch.zeros(5, dtype=torch.float64, device=dev)
+    rot = torch.empty((n, 3, 3), dtype=torch.float64, device=dev)
+    tv = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    rv = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    st = torch.empty((n,), dtype=torch.int32, device=dev)
+    nat.check(nat.lib().scpose_pnp_epnp_ransac(_ptr(kp), _ptr(lm), _ptr(Kd), _ptr(dd), n, j, conf_thr0, min_pts, thr_decay,
+                                               thr_iters, max_iters, reproj_err, confidence, _ptr(rot), _ptr(tv), _ptr(rv),
+                                               _ptr(st), _stream()), "pnp_epnp_ransac")
+    return (rot, tv, st, rv) if want_rvec else (rot, tv, st)
+
+
+# ------------------------------------------------------------------ HRNet engine
+def desc_from_cfg(cfg, dtype="bf16", mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """cfg: yacs-like node or plain dict with MODEL.NUM_JOINTS and MODEL.EXTRA.STAGE{2,3,4}."""
+    model = cfg["MODEL"]
+    extra = model["EXTRA"]
+    d = nat.HrnetDesc()
+    d.num_joints = int(model["NUM_JOINTS"])
+    d.final_conv_kernel = int(extra["FINAL_CONV_KERNEL"])
+    d.num_stages = 3
+    for si, name in enumerate(("STAGE2", "STAGE3", "STAGE4")):
+        s = extra[name]
+        if str(s["BLOCK"]) != "BASIC":
+            raise nat.NativeError("%s.BLOCK=%s: only BASIC stage blocks are supported (all shipped configs)" % (name, s["BLOCK"]))
+        d.num_modules[si] = int(s["NUM_MODULES"])
+        d.num_branches[si] = int(s["NUM_BRANCHES"])
+        for b in range(int(s["NUM_BRANCHES"])):
+            d.num_blocks[si][b] = int(s["NUM_BLOCKS"][b])
+            d.num_channels[si][b] = int(s["NUM_CHANNELS"][b])
+    d.dtype = dtype_code(dtype)
+    for i in range(3):
+        d.mean[i] = mean[i]
+        d.std[i] = std[i]
+    return d
+
+
+class HrnetEngine:
+    """Owns a native scpose_hrnet handle built from a state_dict (host f32 copies are
+    only needed during create) and a torch-allocated workspace arena."""
+
+    def __init__(self, cfg, state_dict, dtype="bf16", allow_missing=False, device=None):
+        if not torch.cuda.is_available():
+            raise nat.NativeError("no ROCm device visible: the HRNet engine only runs on the GPU")
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.desc = desc_from_cfg(cfg, dtype)
+        self.num_joints = self.desc.num_joints
+        names, ptrs, numels, keep = [], [], [], []
+        for k, v in state_dict.items():
+            if not torch.is_floating_point(v):
+                continue
+            t = v.detach().to("cpu", torch.float32).contiguous()
+            keep.append(t)
+            names.append(k.encode())
+            ptrs.append(t.data_ptr())
+            numels.append(t.numel())
+        n = len(names)
+        c_names = (c_char_p * n)(*names)
+        c_ptrs = (c_void_p * n)(*ptrs)
+        c_numels = (c_int64 * n)(*numels)
+        h = c_void_p()
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().scpose_hrnet_create(ctypes.byref(self.desc), c_names, c_ptrs, c_numels, n,
+                                                    int(allow_missing), ctypes.byref(h)), "hrnet_create")
+        self._h = h
+        self._ws = None
+
+    def workspace_bytes(self, n, h, w):
+        b = c_size_t()
+        nat.check(nat.lib().scpose_hrnet_workspace_bytes(self._h, n, h, w, ctypes.byref(b)), "hrnet_workspace_bytes")
+        return b.value
+
+    def stats(self, h, w):
+        l = c_int32(); f = c_double(); by = c_double()
+        nat.check(nat.lib().scpose_hrnet_stats(self._h, h, w, ctypes.byref(l), ctypes.byref(f), ctypes.byref(by)), "hrnet_stats")
+        return {"launches": l.value, "flops_per_frame": f.value, "act_bytes_per_frame": by.value}
+
+    def forward(self, x, out=None):
+        """x: float32 (N,3,H,W) normalised, or uint8 (N,H,W,3) raw RGB.  Returns f32 (N,J,H/4,W/4)."""
+        _need_cuda(x)
+        x = x.contiguous()
+        if x.dtype == torch.uint8:
+            n, h, w, c = x.shape
+            fmt = nat.IN_U8_NHWC
+        else:
+            x = x.float()
+            n, c, h, w = x.shape
+            fmt = nat.IN_F32_NCHW
+        if c != 3:
+            raise nat.NativeError("HRNet input must have 3 channels, got %d" % c)
+        need = self.workspace_bytes(n, h, w)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        if out is None:
+            out = torch.empty((n, self.num_joints, h // 4, w // 4), dtype=torch.float32, device=x.device)
+        nat.check(nat.lib().scpose_hrnet_forward(self._h, _ptr(x), fmt, n, h, w, _ptr(out), _ptr(self._ws),
+                                                 self._ws.numel(), _stream()), "hrnet_forward")
+        return out
+
+    __call__ = forward
+
+    def close(self):
+        if getattr(self, "_h", None):
+            nat.lib().scpose_hrnet_destroy(self._h)
+            self._h = None
+        self._ws = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

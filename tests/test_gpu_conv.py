@@ -1,0 +1,116 @@
+"""Parity of the MFMA implicit-GEMM convolution (csrc/conv_igemm.hip) through the C ABI
+against torch's CPU float32 conv2d on identical 16-bit-rounded operands.
+
+Tolerance: the kernel accumulates in fp32 and rounds once to bf16 (8 significand bits), so
+agreement is required to 2 bf16 ulps of the result scale: |d| <= 1e-2*|ref| + 1e-2*rms(ref).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+#        cin cout k s  H   W  N  res   relu
+CASES = [
+    (48, 48, 3, 1, 96, 96, 2, True, True),      # W48 branch 0 (mrep 3, nrep 4, single 6-plane chunk)
+    (96, 96, 3, 1, 48, 48, 2, True, True),      # branch 1 (mrep 6)
+    (192, 192, 3, 1, 24, 24, 2, True, True),    # branch 2 (2 Cout blocks, 24-wide tile, nrep 3)
+    (384, 384, 3, 1, 12, 12, 3, True, True),    # branch 3 (4 Cout blocks, whole-image tile)
+    (32, 32, 3, 1, 64, 64, 1, True, True),      # W32 branches
+    (64, 64, 3, 1, 32, 32, 2, False, True),
+    (128, 128, 3, 1, 16, 16, 2, True, False),
+    (256, 256, 3, 1, 8, 8, 3, True, True),
+    (64, 64, 3, 2, 192, 192, 1, False, True),   # stem conv2
+    (64, 256, 1, 1, 96, 96, 1, False, False),   # layer1 1x1s
+    (256, 64, 1, 1, 96, 96, 1, False, True),
+    (64, 64, 1, 1, 32, 32, 2, False, True),
+    (256, 48, 3, 1, 96, 96, 1, False, True),    # transition1
+    (256, 96, 3, 2, 96, 96, 1, False, True),
+    (48, 96, 3, 2, 96, 96, 2, False, False),    # fuse down paths
+    (48, 48, 3, 2, 96, 96, 1, False, True),
+    (96, 192, 3, 2, 48, 48, 2, False, False),
+    (192, 384, 3, 2, 24, 24, 2, False, True),
+    (96, 48, 1, 1, 48, 48, 2, False, False),    # fuse up paths (1x1)
+    (384, 48, 1, 1, 12, 12, 2, False, False),
+    (192, 96, 1, 1, 24, 24, 2, False, False),
+    (48, 48, 3, 1, 20, 20, 2, True, True),      # ragged: tile overhangs the map
+    (32, 64, 3, 2, 40, 40, 1, False, True),
+    (16, 16, 3, 1, 6, 6, 2, True, True),        # tiny maps
+    (16, 32, 3, 2, 2, 2, 3, False, False),
+    (128, 16, 1, 1, 2, 2, 1, False, False),
+    (80, 80, 3, 1, 16, 16, 1, True, True),      # Cout not on a 48/64/96 grid (padded block)
+]
+
+
+def _rnd(t, dt):
+    return t.to(dt).to(torch.float32)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "c%d-%d_k%d_s%d_%dx%d_n%d" % c[:7])
+def test_conv_matches_cpu(gpu_ops, case, dtype):
+    cin, cout, k, s, H, W, N, use_res, relu = case
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    g = torch.Generator().manual_seed(1000 * cin + cout + k + s + H)
+    x = _rnd(torch.randn(N, cin, H, W, generator=g), tdt)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    res = _rnd(torch.randn(N, cout, Ho, Wo, generator=g), tdt) if use_res else None
+
+    ref = F.conv2d(x, _rnd(w, tdt), b, s, (k - 1) // 2)
+    if res is not None:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+
+    conv = gpu_ops.Conv(w, b, stride=s, dtype=dtype)
+    xb = gpu_ops.to_blocked(x.cuda(), dtype)
+    rb = gpu_ops.to_blocked(res.cuda(), dtype) if res is not None else None
+    got = gpu_ops.from_blocked(conv(xb, residual=rb, relu=relu)).cpu()
+    assert got.shape == ref.shape
+    tol = 1e-2 * ref.abs() + 1e-2 * ref.pow(2).mean().sqrt()
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), "max |d| %.4g (tol %.4g) at %d/%d elements" % (
+        (got - ref).abs().max(), tol.min(), int(bad.sum()), bad.numel())
+
+
+def test_conv_f32_nchw_output_with_joint_padding(gpu_ops):
+    """final_layer: Cout = 11 joints (padded to 16 in the MFMA tile), float32 NCHW output, bias."""
+    g = torch.Generator().manual_seed(5)
+    x = _rnd(torch.randn(2, 48, 96, 96, generator=g), torch.bfloat16)
+    w = torch.randn(11, 48, 1, 1, generator=g) / 48 ** 0.5
+    b = torch.randn(11, generator=g)
+    ref = F.conv2d(x, _rnd(w, torch.bfloat16), b)
+    conv = gpu_ops.Conv(w, b, dtype="bf16")
+    got = conv(gpu_ops.to_blocked(x.cuda()), out_nchw_f32=True).cpu()
+    assert got.shape == (2, 11, 96, 96) and got.dtype == torch.float32
+    assert (got - ref).abs().max() < 2e-4 * max(1.0, ref.abs().max().item())   # fp32 out: only summation order differs
+
+
+def test_layout_roundtrip_is_exact(gpu_ops):
+    x = _rnd(torch.randn(3, 40, 7, 9), torch.bfloat16)
+    back = gpu_ops.from_blocked(gpu_ops.to_blocked(x.cuda())).cpu()
+    assert torch.equal(back, x)
+
+
+def test_fuse_sum_matches_reference_order(gpu_ops):
+    """relu(x0 + up2(z1) + up4(z2) + up8(z3)) -- HighResolutionModule.forward :256-263."""
+    g = torch.Generator().manual_seed(7)
+    bf = torch.bfloat16
+    x0 = _rnd(torch.randn(2, 48, 32, 32, generator=g), bf)
+    zs = [_rnd(torch.randn(2, 48, 32 >> s, 32 >> s, generator=g), bf) for s in (1, 2, 3)]
+    ref = x0.clone()
+    for s, z in zip((1, 2, 3), zs):
+        ref = ref + F.interpolate(z, scale_factor=2 ** s, mode="nearest")
+    ref = _rnd(F.relu(ref), bf)
+    terms = [gpu_ops.to_blocked(t.cuda()) for t in [x0] + zs]
+    got = gpu_ops.from_blocked(gpu_ops.fuse_sum(terms, [0, 1, 2, 3], (32, 32))).cpu()
+    assert torch.equal(got, ref)          # same fp32 sum order, one rounding: bit-exact
+
+
+def test_bad_arguments_report_errors(gpu_ops):
+    with pytest.raises(gpu_ops.nat.NativeError, match="multiple of 16"):
+        gpu_ops.Conv(torch.zeros(8, 12, 3, 3))
+    with pytest.raises(gpu_ops.nat.NativeError, match="kernel size"):
+        gpu_ops.Conv(torch.zeros(16, 16, 5, 5))

@@ -1,0 +1,96 @@
+"""Parity of the wavefront argmax decode kernel (csrc/decode.hip, C ABI scpose_decode /
+scpose_max_preds) against the NumPy oracle of get_max_preds / get_final_preds.
+Index work is bit-exact; image-space coordinates agree to 1 float32 ulp-of-result
+(|d| <= 2e-4 px at ~2000 px) because the oracle solves the 3-point affine numerically."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import decode_ref as D
+
+pytestmark = pytest.mark.gpu
+
+
+def _boxes(n, rng, size=1920.0):
+    c = (rng.random((n, 2)) * size).astype(np.float32)
+    s = (rng.random((n, 2)) * 3 + 0.3).astype(np.float32)
+    return c, s
+
+
+def _run(gpu_ops, hm, c, s, pp):
+    out = gpu_ops.decode(torch.from_numpy(hm).cuda(), torch.from_numpy(c).cuda(), torch.from_numpy(s).cuda(), pp)
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("shape", [(4, 11, 64, 64), (3, 11, 96, 96), (2, 24, 128, 128), (5, 11, 16, 24), (2, 3, 5, 7)])
+@pytest.mark.parametrize("pp", [True, False])
+def test_decode_random_maps(gpu_ops, shape, pp):
+    rng = np.random.default_rng(sum(shape))
+    hm = rng.standard_normal(shape).astype(np.float32)
+    c, s = _boxes(shape[0], rng)
+    ref = D.decode_xyc(pp, hm.copy(), c, s)
+    got = _run(gpu_ops, hm, c, s, pp)
+    assert np.array_equal(got[:, :, 2], ref[:, :, 2])                # maxval: exact
+    assert np.abs(got[:, :, :2] - ref[:, :, :2]).max() <= 2e-4
+
+
+def test_decode_gaussian_targets_and_max_preds(gpu_ops):
+    rng = np.random.default_rng(11)
+    hm, cx, cy = D.gaussian_heatmaps(6, 11, 96, 96, rng, sigma=2.0)
+    coords, maxvals = gpu_ops.max_preds(torch.from_numpy(hm).cuda())
+    rc, rm = D.get_max_preds(hm)
+    assert np.array_equal(coords.cpu().numpy(), rc) and np.array_equal(maxvals.cpu().numpy(), rm)
+    assert np.array_equal(rc[:, :, 0], cx.astype(np.float32)) and np.array_equal(rc[:, :, 1], cy.astype(np.float32))
+    c, s = _boxes(6, rng)
+    assert np.abs(_run(gpu_ops, hm, c, s, True) - D.decode_xyc(True, hm.copy(), c, s)).max() <= 2e-4
+
+
+def test_decode_edge_cases(gpu_ops):
+    """ties (first index wins), non-positive maps (coords masked to 0), peaks on the border
+    (no quarter-pixel shift: strict 1 < px < W-1), flat neighbourhoods (sign(0) = 0), NaN."""
+    n, j, h, w = 2, 8, 32, 32
+    hm = np.full((n, j, h, w), -1.0, dtype=np.float32)
+    hm[0, 0, 5, 7] = hm[0, 0, 20, 3] = hm[0, 0, 5, 8] = 2.0           # ties -> (7,5)
+    hm[0, 1] = 0.0                                                     # max == 0 -> masked
+    hm[0, 2, 0, 0] = 3.0                                               # corner
+    hm[0, 3, 1, 10] = 3.0                                              # py == 1: no refine
+    hm[0, 4, 10, 30] = 3.0                                             # px == W-2: refine allowed? (1 < 30 < 31)
+    hm[0, 4, 10, 31] = 2.5
+    hm[0, 5, 10, 31] = 3.0                                             # px == W-1: no refine
+    hm[0, 6, 12, 12] = 1.0; hm[0, 6, 12, 13] = 0.5; hm[0, 6, 12, 11] = 0.5   # symmetric: sign 0 in x
+    hm[0, 6, 13, 12] = 0.75                                            # +y
+    hm[0, 7, 3, 3] = np.nan; hm[0, 7, 9, 9] = 5.0                      # NaN counts as max (first NaN)
+    hm[1] = np.random.default_rng(0).standard_normal((j, h, w)).astype(np.float32)
+    c, s = _boxes(n, np.random.default_rng(1))
+    for pp in (True, False):
+        ref = D.decode_xyc(pp, hm.copy(), c, s)
+        got = _run(gpu_ops, hm, c, s, pp)
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        ok = ~np.isnan(ref)
+        assert np.abs(got[ok] - ref[ok]).max() <= 2e-4
+    coords, _ = gpu_ops.max_preds(torch.from_numpy(hm).cuda())
+    rc, _ = D.get_max_preds(hm)
+    assert np.array_equal(coords.cpu().numpy(), rc)
+    assert tuple(rc[0, 0]) == (7.0, 5.0) and tuple(rc[0, 1]) == (0.0, 0.0)
+
+
+def test_decode_full_size_properties(gpu_ops):
+    """BASELINE config B size (256 x 11 x 96 x 96): size-independent properties -- the decoded
+    maxval equals the map's max, and decoding a map shifted by one pixel shifts the
+    keypoint by exactly the affine step k = scale_x*200/W."""
+    g = torch.Generator().manual_seed(3)
+    hm = torch.randn(256, 11, 96, 96, generator=g)
+    c = torch.full((256, 2), 500.0); s = torch.full((256, 2), 1.92)
+    out = gpu_ops.decode(hm.cuda(), c.cuda(), s.cuda(), False).cpu()
+    assert torch.equal(out[:, :, 2], hm.amax(dim=(2, 3)))
+    rolled = torch.roll(hm, shifts=1, dims=3)
+    out2 = gpu_ops.decode(rolled.cuda(), c.cuda(), s.cuda(), False).cpu()
+    idx = hm.flatten(2).argmax(2) % 96
+    keep = idx < 95                                                    # peaks that do not wrap around
+    step = 1.92 * 200 / 96
+    assert torch.allclose((out2[:, :, 0] - out[:, :, 0])[keep], torch.tensor(step), atol=1e-3)
+
+
+def test_decode_empty_batch(gpu_ops):
+    out = gpu_ops.decode(torch.zeros(0, 11, 8, 8).cuda(), torch.zeros(0, 2).cuda(), torch.zeros(0, 2).cuda(), True)
+    assert out.shape == (0, 11, 3)
