@@ -13,6 +13,7 @@ extern "C" const char* scpose_last_error(void) { return last_error(); }
 extern "C" int32_t scpose_decode(const float* heatmaps, int32_t n, int32_t j, int32_t h, int32_t w,
                                  const float* center, const float* scale, int32_t post_process,
                                  float* preds_xyc, void* stream) {
+  if (n == 0) return SCPOSE_OK;  /* empty batch: nothing to do, pointers may be null */
   SCP_REQUIRE(heatmaps && preds_xyc, "decode: null argument");
   return decode_launch(heatmaps, n, j, h, w, center, scale, post_process, preds_xyc, nullptr,
                        nullptr, static_cast<hipStream_t>(stream));
@@ -20,6 +21,7 @@ extern "C" int32_t scpose_decode(const float* heatmaps, int32_t n, int32_t j, in
 
 extern "C" int32_t scpose_max_preds(const float* heatmaps, int32_t n, int32_t j, int32_t h,
                                     int32_t w, float* coords, float* maxvals, void* stream) {
+  if (n == 0) return SCPOSE_OK;
   SCP_REQUIRE(heatmaps && coords && maxvals, "max_preds: null argument");
   return decode_launch(heatmaps, n, j, h, w, nullptr, nullptr, 0, nullptr, coords, maxvals,
                        static_cast<hipStream_t>(stream));
@@ -31,6 +33,7 @@ extern "C" int32_t scpose_pnp_epnp_ransac(const float* kp_xyc, const double* lan
                                           int32_t thr_iters, int32_t max_iters, double reproj_err,
                                           double confidence, double* rot, double* tvec,
                                           double* rvec, int32_t* status, void* stream) {
+  if (n == 0) return SCPOSE_OK;
   SCP_REQUIRE(kp_xyc && landmarks && K && rot && tvec && status, "pnp: null argument");
   return pnp_launch(kp_xyc, landmarks, K, dist, n, j, conf_thr0, min_pts, thr_decay, thr_iters,
                     max_iters, reproj_err, confidence, rot, tvec, rvec, status,
