@@ -131,8 +131,8 @@ int32_t scpose_max_preds(const float* heatmaps, int32_t n, int32_t j, int32_t h,
  *              (-1: fewer than 4 usable points [the reference raises], -2: RANSAC found no model)
  * ---------------------------------------------------------------------------------------- */
 int32_t scpose_pnp_epnp_ransac(const float* kp_xyc, const double* landmarks, const double* K,
-                               const double* dist, int32_t n, int32_t j, float conf_thr0,
-                               int32_t min_pts, float thr_decay, int32_t thr_iters,
+                               const double* dist, int32_t n, int32_t j, double conf_thr0,
+                               int32_t min_pts, double thr_decay, int32_t thr_iters,
                                int32_t max_iters, double reproj_err, double confidence,
                                double* rot, double* tvec, double* rvec, int32_t* status,
                                void* stream);

@@ -47,8 +47,8 @@ SYMBOLS = {
                                 c_void_p, c_void_p]),
     "scpose_max_preds": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                    c_void_p]),
-    "scpose_pnp_epnp_ransac": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float,
-                                         c_int32, c_float, c_int32, c_int32, c_double, c_double, c_void_p,
+    "scpose_pnp_epnp_ransac": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_double,
+                                         c_int32, c_double, c_int32, c_int32, c_double, c_double, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p]),
     "scpose_conv_create": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                      POINTER(c_void_p)]),

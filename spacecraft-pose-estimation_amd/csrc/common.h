@@ -112,7 +112,7 @@ int32_t decode_launch(const float* hm, int N, int J, int H, int W, const float* 
                       const float* scale, int post_process, float* preds_xyc, float* coords,
                       float* maxvals, hipStream_t stream);
 int32_t pnp_launch(const float* kp_xyc, const double* landmarks, const double* K,
-                   const double* dist, int N, int J, float conf_thr0, int min_pts, float thr_decay,
+                   const double* dist, int N, int J, double conf_thr0, int min_pts, double thr_decay,
                    int thr_iters, int max_iters, double reproj_err, double confidence, double* rot,
                    double* tvec, double* rvec, int32_t* status, hipStream_t stream);
 

@@ -1,7 +1,813 @@
+// Batched EPnP + RANSAC: one wavefront per frame, fp64.
+//
+// Replaces the per-frame serial CPU loop of pose_estimation/export_predicted_poses_real.py
+// :177-203: confidence filter (:186-197), cv2.solvePnPRansac(obj, img, K, dist,
+// flags=SOLVEPNP_EPNP, iterationsCount, reprojectionError) (:199-201) and cv2.Rodrigues (:203).
+// cv2 is opencv-python 3.4.11.41 (environment.yml:37); its algorithm (solvepnp.cpp
+// solvePnPRansac/PnPRansacCallback, ptsetreg.cpp RANSACPointSetRegistrator::run, epnp.cpp,
+// calibration.cpp Rodrigues/projectPoints, undistort.cpp undistortPoints, lapack.cpp
+// JacobiSVDImpl_) is implemented here directly for the GPU.
+//
+// Mapping to the wavefront:
+//   * lane j < J  : per-landmark work (confidence filter, undistortion, compaction by ballot);
+//   * lane k      : RANSAC hypothesis k of the current batch of <= 64 iterations.  The minimal
+//     5-point subsets are drawn from ONE cv::RNG stream in iteration order (all lanes step the
+//     generator together), every lane solves its own 5-point EPnP and counts inliers, then the
+//     batch is scanned in iteration order with OpenCV's acceptance rule and adaptive iteration
+//     count -- exactly the sequential loop's result, with the iterations' latency overlapped;
+//   * the 12x12 M^T M of each lane lives in LDS ([entry][lane], conflict-free 8-byte access);
+//   * the final EPnP over the inliers is wave-uniform.
+// Latency-bound by design (a few hundred microseconds per wave, all frames in parallel); it is
+// <1 % of the HRNet forward at the benchmark sizes.
+#include <float.h>
+
 #include "common.h"
+
+#pragma clang fp contract(off)   // separate mul/add like the scalar CPU path it is checked against
+
 namespace scpose {
-int32_t pnp_launch(const float*, const double*, const double*, const double*, int, int, float, int, float, int, int, double, double, double*, double*, double*, int32_t*, hipStream_t) {
-  set_error("pnp: not built yet");
-  return SCPOSE_E_INVALID;
+
+static constexpr int kMaxJ = 64;
+
+struct PnpArgs {
+  const float* kp;          // N x J x 3
+  const double* landmarks;  // J x 3
+  const double* K;          // 3x3
+  const double* dist;       // 5 or null
+  double* rot;              // N x 9
+  double* tvec;             // N x 3
+  double* rvec;             // N x 3 or null
+  int32_t* status;          // N
+  int N, J;
+  double conf_thr0, thr_decay;
+  int min_pts, thr_iters, max_iters;
+  double reproj_err, confidence;
+};
+
+struct Cam { double fx, fy, cx, cy, k[5]; };
+
+// ---- cv::RNG ---------------------------------------------------------------------------------
+struct CvRng {
+  unsigned long long state;
+  __device__ unsigned next() {
+    state = (unsigned long long)(unsigned)state * 4164903690ULL + (unsigned)(state >> 32);
+    return (unsigned)state;
+  }
+  __device__ int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
+};
+
+// ---- one-sided Jacobi SVD on small private matrices (JacobiSVDImpl_<double>) -----------------
+// At: N rows of length M (columns of the M x N input).  Out: rows of At = left singular
+// vectors, W descending, Vt rows = right singular vectors.
+template <int M, int N>
+__device__ void jacobi_small(double* At, double* W, double* Vt) {
+  const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
+  for (int i = 0; i < N; i++) {
+    double sd = 0;
+    for (int k = 0; k < M; k++) sd += At[i * M + k] * At[i * M + k];
+    W[i] = sd;
+    for (int k = 0; k < N; k++) Vt[i * N + k] = 0;
+    Vt[i * N + i] = 1;
+  }
+  const int max_iter = M > 30 ? M : 30;
+  for (int iter = 0; iter < max_iter; iter++) {
+    bool changed = false;
+    for (int i = 0; i < N - 1; i++)
+      for (int j = i + 1; j < N; j++) {
+        double* Ai = At + i * M; double* Aj = At + j * M;
+        double a = W[i], p = 0, b = W[j], c, s;
+        for (int k = 0; k < M; k++) p += Ai[k] * Aj[k];
+        if (fabs(p) <= eps * sqrt(a * b)) continue;
+        p *= 2;
+        const double beta = a - b, gamma = hypot(p, beta);
+        if (beta < 0) {
+          const double delta = (gamma - beta) * 0.5;
+          s = sqrt(delta / gamma);
+          c = p / (gamma * s * 2);
+        } else {
+          c = sqrt((gamma + beta) / (gamma * 2));
+          s = p / (gamma * c * 2);
+        }
+        a = b = 0;
+        for (int k = 0; k < M; k++) {
+          const double t0 = c * Ai[k] + s * Aj[k], t1 = -s * Ai[k] + c * Aj[k];
+          Ai[k] = t0; Aj[k] = t1;
+          a += t0 * t0; b += t1 * t1;
+        }
+        W[i] = a; W[j] = b;
+        changed = true;
+        double* Vi = Vt + i * N; double* Vj = Vt + j * N;
+        for (int k = 0; k < N; k++) {
+          const double t0 = c * Vi[k] + s * Vj[k], t1 = -s * Vi[k] + c * Vj[k];
+          Vi[k] = t0; Vj[k] = t1;
+        }
+      }
+    if (!changed) break;
+  }
+  for (int i = 0; i < N; i++) {
+    double sd = 0;
+    for (int k = 0; k < M; k++) sd += At[i * M + k] * At[i * M + k];
+    W[i] = sqrt(sd);
+  }
+  for (int i = 0; i < N - 1; i++) {
+    int j = i;
+    for (int k = i + 1; k < N; k++)
+      if (W[j] < W[k]) j = k;
+    if (i != j) {
+      double t = W[i]; W[i] = W[j]; W[j] = t;
+      for (int k = 0; k < M; k++) { t = At[i * M + k]; At[i * M + k] = At[j * M + k]; At[j * M + k] = t; }
+      for (int k = 0; k < N; k++) { t = Vt[i * N + k]; Vt[i * N + k] = Vt[j * N + k]; Vt[j * N + k] = t; }
+    }
+  }
+  CvRng rng{0x12345678ULL};
+  for (int i = 0; i < N; i++) {
+    double sd = W[i];
+    for (int ii = 0; ii < 100 && sd <= minval; ii++) {  // exactly-zero singular value
+      const double val0 = 1. / M;
+      for (int k = 0; k < M; k++) At[i * M + k] = (rng.next() & 256) != 0 ? val0 : -val0;
+      for (int it = 0; it < 2; it++)
+        for (int j = 0; j < i; j++) {
+          double asum = 0;
+          sd = 0;
+          for (int k = 0; k < M; k++) sd += At[i * M + k] * At[j * M + k];
+          for (int k = 0; k < M; k++) {
+            const double t = At[i * M + k] - sd * At[j * M + k];
+            At[i * M + k] = t;
+            asum += fabs(t);
+          }
+          asum = asum > eps * 100 ? 1 / asum : 0;
+          for (int k = 0; k < M; k++) At[i * M + k] *= asum;
+        }
+      sd = 0;
+      for (int k = 0; k < M; k++) sd += At[i * M + k] * At[i * M + k];
+      sd = sqrt(sd);
+    }
+    const double s = sd > minval ? 1 / sd : 0.;
+    for (int k = 0; k < M; k++) At[i * M + k] *= s;
+  }
 }
+
+// x = pinv(A) b  (cvSolve / cvInvert with CV_SVD: SVBkSb with threshold 2*eps*sum(w))
+template <int M, int N, int NB>
+__device__ void svd_solve(const double* A, const double* b, double* x) {
+  double At[N * M], W[N], Vt[N * N];
+  for (int i = 0; i < N; i++)
+    for (int k = 0; k < M; k++) At[i * M + k] = A[k * N + i];
+  jacobi_small<M, N>(At, W, Vt);
+  double thr = 0;
+  for (int i = 0; i < N; i++) thr += W[i];
+  thr *= DBL_EPSILON * 2;
+  for (int j = 0; j < N * NB; j++) x[j] = 0;
+  for (int i = 0; i < N; i++) {
+    double wi = W[i];
+    if (fabs(wi) <= thr) continue;
+    wi = 1 / wi;
+    for (int j = 0; j < NB; j++) {
+      double s = 0;
+      for (int k = 0; k < M; k++) s += At[i * M + k] * b[k * NB + j];
+      s *= wi;
+      for (int k = 0; k < N; k++) x[k * NB + j] += s * Vt[i * N + k];
+    }
+  }
 }
+
+// 12x12 one-sided Jacobi on the lane's LDS matrix; only U^T (rows) and the ordering are needed
+// (the V accumulation of JacobiSVDImpl_ does not influence U or W).
+#define UT(r, c) ut[((r) * 12 + (c)) * 64]
+__device__ void jacobi12(double* ut /* = base + lane */) {
+  const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
+  double W[12];
+  for (int i = 0; i < 12; i++) {
+    double sd = 0;
+    for (int k = 0; k < 12; k++) sd += UT(i, k) * UT(i, k);
+    W[i] = sd;
+  }
+  for (int iter = 0; iter < 30; iter++) {
+    bool changed = false;
+    for (int i = 0; i < 11; i++)
+      for (int j = i + 1; j < 12; j++) {
+        double ai[12], aj[12];
+        double a = W[i], p = 0, b = W[j], c, s;
+#pragma unroll
+        for (int k = 0; k < 12; k++) { ai[k] = UT(i, k); aj[k] = UT(j, k); }
+#pragma unroll
+        for (int k = 0; k < 12; k++) p += ai[k] * aj[k];
+        if (fabs(p) <= eps * sqrt(a * b)) continue;
+        p *= 2;
+        const double beta = a - b, gamma = hypot(p, beta);
+        if (beta < 0) {
+          const double delta = (gamma - beta) * 0.5;
+          s = sqrt(delta / gamma);
+          c = p / (gamma * s * 2);
+        } else {
+          c = sqrt((gamma + beta) / (gamma * 2));
+          s = p / (gamma * c * 2);
+        }
+        a = b = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+          const double t0 = c * ai[k] + s * aj[k], t1 = -s * ai[k] + c * aj[k];
+          UT(i, k) = t0; UT(j, k) = t1;
+          a += t0 * t0; b += t1 * t1;
+        }
+        W[i] = a; W[j] = b;
+        changed = true;
+      }
+    if (!changed) break;
+  }
+  for (int i = 0; i < 12; i++) {
+    double sd = 0;
+    for (int k = 0; k < 12; k++) sd += UT(i, k) * UT(i, k);
+    W[i] = sqrt(sd);
+  }
+  for (int i = 0; i < 11; i++) {
+    int j = i;
+    for (int k = i + 1; k < 12; k++)
+      if (W[j] < W[k]) j = k;
+    if (i != j) {
+      double t = W[i]; W[i] = W[j]; W[j] = t;
+      for (int k = 0; k < 12; k++) { t = UT(i, k); UT(i, k) = UT(j, k); UT(j, k) = t; }
+    }
+  }
+  CvRng rng{0x12345678ULL};
+  for (int i = 0; i < 12; i++) {
+    double sd = W[i];
+    for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+      const double val0 = 1. / 12;
+      for (int k = 0; k < 12; k++) UT(i, k) = (rng.next() & 256) != 0 ? val0 : -val0;
+      for (int it = 0; it < 2; it++)
+        for (int j = 0; j < i; j++) {
+          double asum = 0;
+          sd = 0;
+          for (int k = 0; k < 12; k++) sd += UT(i, k) * UT(j, k);
+          for (int k = 0; k < 12; k++) {
+            const double t = UT(i, k) - sd * UT(j, k);
+            UT(i, k) = t;
+            asum += fabs(t);
+          }
+          asum = asum > eps * 100 ? 1 / asum : 0;
+          for (int k = 0; k < 12; k++) UT(i, k) *= asum;
+        }
+      sd = 0;
+      for (int k = 0; k < 12; k++) sd += UT(i, k) * UT(i, k);
+      sd = sqrt(sd);
+    }
+    const double s = sd > minval ? 1 / sd : 0.;
+    for (int k = 0; k < 12; k++) UT(i, k) *= s;
+  }
+}
+
+// ---- calib3d pieces --------------------------------------------------------------------------
+__device__ void rodrigues_vec2mat(const double r[3], double R[9]) {
+  const double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  if (theta < DBL_EPSILON) {
+    for (int k = 0; k < 9; k++) R[k] = 0;
+    R[0] = R[4] = R[8] = 1;
+    return;
+  }
+  const double c = cos(theta), s = sin(theta), c1 = 1. - c, it = 1. / theta;
+  const double rx = r[0] * it, ry = r[1] * it, rz = r[2] * it;
+  const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+  const double rxm[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+  for (int k = 0; k < 9; k++) R[k] = c1 * rrt[k] + s * rxm[k];
+  R[0] += c; R[4] += c; R[8] += c;
+}
+
+__device__ void rodrigues_mat2vec(const double Rin[9], double r[3]) {
+  double At[9], W[3], Vt[9], R[9];
+  for (int i = 0; i < 3; i++)
+    for (int k = 0; k < 3; k++) At[i * 3 + k] = Rin[k * 3 + i];
+  jacobi_small<3, 3>(At, W, Vt);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double a = 0;
+      for (int k = 0; k < 3; k++) a += At[k * 3 + i] * Vt[k * 3 + j];
+      R[i * 3 + j] = a;
+    }
+  double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+  const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+  double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+  c = c > 1. ? 1. : c < -1. ? -1. : c;
+  double theta = acos(c);
+  if (s < 1e-5) {
+    if (c > 0) { r[0] = r[1] = r[2] = 0; return; }
+    double t = (R[0] + 1) * 0.5; rx = sqrt(t > 0. ? t : 0.);
+    t = (R[4] + 1) * 0.5; ry = sqrt(t > 0. ? t : 0.) * (R[1] < 0 ? -1. : 1.);
+    t = (R[8] + 1) * 0.5; rz = sqrt(t > 0. ? t : 0.) * (R[2] < 0 ? -1. : 1.);
+    if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+    theta /= sqrt(rx * rx + ry * ry + rz * rz);
+    r[0] = rx * theta; r[1] = ry * theta; r[2] = rz * theta;
+  } else {
+    double vth = 1 / (2 * s);
+    vth *= theta;
+    r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
+  }
+}
+
+__device__ void project_point(const Cam& cam, const double R[9], const double t[3], const double* X,
+                              double* u, double* v) {
+  double x = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0];
+  double y = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1];
+  double z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2];
+  z = z ? 1. / z : 1;
+  x *= z; y *= z;
+  const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+  const double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+  const double cdist = 1 + cam.k[0] * r2 + cam.k[1] * r4 + cam.k[4] * r6;
+  const double xd = x * cdist + cam.k[2] * a1 + cam.k[3] * a2;
+  const double yd = y * cdist + cam.k[2] * a3 + cam.k[3] * a1;
+  *u = xd * cam.fx + cam.cx;
+  *v = yd * cam.fy + cam.cy;
+}
+
+__device__ void undistort_point(const Cam& cam, double u, double v, double* xo, double* yo) {
+  const double x0 = (u - cam.cx) * (1. / cam.fx), y0 = (v - cam.cy) * (1. / cam.fy);
+  double x = x0, y = y0;
+  for (int j = 0; j < 5; j++) {
+    const double r2 = x * x + y * y;
+    const double icdist = 1. / (1 + ((cam.k[4] * r2 + cam.k[1]) * r2 + cam.k[0]) * r2);
+    if (icdist < 0) { x = x0; y = y0; break; }
+    const double dx = 2 * cam.k[2] * x * y + cam.k[3] * (r2 + 2 * x * x);
+    const double dy = cam.k[2] * (r2 + 2 * y * y) + 2 * cam.k[3] * x * y;
+    x = (x0 - dx) * icdist;
+    y = (y0 - dy) * icdist;
+  }
+  *xo = x; *yo = y;
+}
+
+// ---- point set of one EPnP call: 5 packed indices (draw order) or an inlier bit mask ----------
+struct PtSet {
+  unsigned long long mask;
+  unsigned packed;
+  int n;
+  bool hyp;
+};
+struct PtIter {
+  unsigned long long m; unsigned packed; bool hyp;
+  __device__ explicit PtIter(const PtSet& s) : m(s.mask), packed(s.packed), hyp(s.hyp) {}
+  __device__ int next() {
+    if (hyp) { const int i = packed & 63; packed >>= 6; return i; }
+    const int i = __builtin_ctzll(m); m &= m - 1; return i;
+  }
+};
+
+__device__ __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ double dist2(const double* a, const double* b) {
+  return (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]);
+}
+
+struct EpnpCtx {
+  const double* obj;  // LDS: compacted object points (float32-rounded) [n][3]
+  const double* us;   // LDS: undistorted*f+c image points [n][2]
+  double uc, vc, fu, fv;
+  double cws[4][3];
+  double cc_inv[9];
+};
+
+__device__ __forceinline__ void alphas_of(const EpnpCtx& e, const double* pi, double a[4]) {
+  for (int j = 0; j < 3; j++)
+    a[1 + j] = e.cc_inv[3 * j] * (pi[0] - e.cws[0][0]) + e.cc_inv[3 * j + 1] * (pi[1] - e.cws[0][1]) +
+               e.cc_inv[3 * j + 2] * (pi[2] - e.cws[0][2]);
+  a[0] = 1.0f - a[1] - a[2] - a[3];
+}
+
+// qr_solve of epnp.cpp for the 6x4 Gauss-Newton system (row-scan quirk of `eta` kept)
+__device__ void qr_solve_6x4(double* pA, double* pb, double* pX) {
+  constexpr int nr = 6, nc = 4;
+  double A1[4], A2[4];
+  double* ppAkk = pA;
+  for (int k = 0; k < nc; k++) {
+    double* ppAik1 = ppAkk; double eta = fabs(*ppAik1);
+    for (int i = k + 1; i < nr; i++) {
+      const double elt = fabs(*ppAik1);
+      if (eta < elt) eta = elt;
+      ppAik1 += nc;
+    }
+    if (eta == 0) { A1[k] = A2[k] = 0.0; return; }
+    double* ppAik2 = ppAkk; double sum2 = 0.0; const double inv_eta = 1. / eta;
+    for (int i = k; i < nr; i++) { *ppAik2 *= inv_eta; sum2 += *ppAik2 * *ppAik2; ppAik2 += nc; }
+    double sigma = sqrt(sum2);
+    if (*ppAkk < 0) sigma = -sigma;
+    *ppAkk += sigma;
+    A1[k] = sigma * *ppAkk;
+    A2[k] = -eta * sigma;
+    for (int j = k + 1; j < nc; j++) {
+      double* ppAik = ppAkk; double sum = 0;
+      for (int i = k; i < nr; i++) { sum += *ppAik * ppAik[j - k]; ppAik += nc; }
+      const double tau = sum / A1[k];
+      ppAik = ppAkk;
+      for (int i = k; i < nr; i++) { ppAik[j - k] -= tau * *ppAik; ppAik += nc; }
+    }
+    ppAkk += nc + 1;
+  }
+  double* ppAjj = pA;
+  for (int j = 0; j < nc; j++) {
+    double* ppAij = ppAjj; double tau = 0;
+    for (int i = j; i < nr; i++) { tau += *ppAij * pb[i]; ppAij += nc; }
+    tau /= A1[j];
+    ppAij = ppAjj;
+    for (int i = j; i < nr; i++) { pb[i] -= tau * *ppAij; ppAij += nc; }
+    ppAjj += nc + 1;
+  }
+  pX[nc - 1] = pb[nc - 1] / A2[nc - 1];
+  for (int i = nc - 2; i >= 0; i--) {
+    double* ppAij = pA + i * nc + (i + 1); double sum = 0;
+    for (int j = i + 1; j < nc; j++) { sum += *ppAij * pX[j]; ppAij++; }
+    pX[i] = (pb[i] - sum) / A2[i];
+  }
+}
+
+__device__ void gauss_newton(const double* L, const double* rho, double betas[4]) {
+  for (int k = 0; k < 5; k++) {
+    double a[24], b[6], x[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 6; i++) {
+      const double* rl = L + i * 10;
+      double* ra = a + i * 4;
+      ra[0] = 2 * rl[0] * betas[0] + rl[1] * betas[1] + rl[3] * betas[2] + rl[6] * betas[3];
+      ra[1] = rl[1] * betas[0] + 2 * rl[2] * betas[1] + rl[4] * betas[2] + rl[7] * betas[3];
+      ra[2] = rl[3] * betas[0] + rl[4] * betas[1] + 2 * rl[5] * betas[2] + rl[8] * betas[3];
+      ra[3] = rl[6] * betas[0] + rl[7] * betas[1] + rl[8] * betas[2] + 2 * rl[9] * betas[3];
+      b[i] = rho[i] - (rl[0] * betas[0] * betas[0] + rl[1] * betas[0] * betas[1] + rl[2] * betas[1] * betas[1] +
+                       rl[3] * betas[0] * betas[2] + rl[4] * betas[1] * betas[2] + rl[5] * betas[2] * betas[2] +
+                       rl[6] * betas[0] * betas[3] + rl[7] * betas[1] * betas[3] + rl[8] * betas[2] * betas[3] +
+                       rl[9] * betas[3] * betas[3]);
+    }
+    qr_solve_6x4(a, b, x);
+    for (int i = 0; i < 4; i++) betas[i] += x[i];
+  }
+}
+
+// compute_ccs + compute_pcs + solve_for_sign + estimate_R_and_t + reprojection_error
+__device__ double compute_R_and_t(const EpnpCtx& e, const PtSet& ps, const double* ut, const double* betas,
+                                  double R[9], double t[3]) {
+  double ccs[4][3];
+  for (int i = 0; i < 4; i++) ccs[i][0] = ccs[i][1] = ccs[i][2] = 0.0;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++)
+      for (int k = 0; k < 3; k++) ccs[j][k] += betas[i] * UT(11 - i, 3 * j + k);
+  auto pc_of = [&](const double* a, double pc[3]) {
+    for (int j = 0; j < 3; j++) pc[j] = a[0] * ccs[0][j] + a[1] * ccs[1][j] + a[2] * ccs[2][j] + a[3] * ccs[3][j];
+  };
+  {  // solve_for_sign: depth of the first point
+    PtIter it(ps);
+    double a[4], pc[3];
+    alphas_of(e, e.obj + 3 * it.next(), a);
+    pc_of(a, pc);
+    if (pc[2] < 0.0)
+      for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 3; j++) ccs[i][j] = -ccs[i][j];
+  }
+  double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+  {
+    PtIter it(ps);
+    for (int i = 0; i < ps.n; i++) {
+      const double* pw = e.obj + 3 * it.next();
+      double a[4], pc[3];
+      alphas_of(e, pw, a); pc_of(a, pc);
+      for (int j = 0; j < 3; j++) { pc0[j] += pc[j]; pw0[j] += pw[j]; }
+    }
+  }
+  for (int j = 0; j < 3; j++) { pc0[j] /= ps.n; pw0[j] /= ps.n; }
+  double abt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  {
+    PtIter it(ps);
+    for (int i = 0; i < ps.n; i++) {
+      const double* pw = e.obj + 3 * it.next();
+      double a[4], pc[3];
+      alphas_of(e, pw, a); pc_of(a, pc);
+      for (int j = 0; j < 3; j++) {
+        abt[3 * j] += (pc[j] - pc0[j]) * (pw[0] - pw0[0]);
+        abt[3 * j + 1] += (pc[j] - pc0[j]) * (pw[1] - pw0[1]);
+        abt[3 * j + 2] += (pc[j] - pc0[j]) * (pw[2] - pw0[2]);
+      }
+    }
+  }
+  double At[9], W[3], Vt[9];
+  for (int i = 0; i < 3; i++)
+    for (int k = 0; k < 3; k++) At[i * 3 + k] = abt[k * 3 + i];
+  jacobi_small<3, 3>(At, W, Vt);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double s = 0;
+      for (int k = 0; k < 3; k++) s += At[k * 3 + i] * Vt[k * 3 + j];
+      R[i * 3 + j] = s;
+    }
+  const double det = R[0] * R[4] * R[8] + R[1] * R[5] * R[6] + R[2] * R[3] * R[7] - R[2] * R[4] * R[6] -
+                     R[1] * R[3] * R[8] - R[0] * R[5] * R[7];
+  if (det < 0) { R[6] = -R[6]; R[7] = -R[7]; R[8] = -R[8]; }
+  t[0] = pc0[0] - dot3(R, pw0);
+  t[1] = pc0[1] - dot3(R + 3, pw0);
+  t[2] = pc0[2] - dot3(R + 6, pw0);
+  double sum2 = 0.0;
+  {
+    PtIter it(ps);
+    for (int i = 0; i < ps.n; i++) {
+      const int idx = it.next();
+      const double* pw = e.obj + 3 * idx;
+      const double Xc = dot3(R, pw) + t[0], Yc = dot3(R + 3, pw) + t[1];
+      const double inv_Zc = 1.0 / (dot3(R + 6, pw) + t[2]);
+      const double ue = e.uc + e.fu * Xc * inv_Zc, ve = e.vc + e.fv * Yc * inv_Zc;
+      const double u = e.us[2 * idx], v = e.us[2 * idx + 1];
+      sum2 += sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
+    }
+  }
+  return sum2 / ps.n;
+}
+
+// epnp::compute_pose followed by Rodrigues(R) (solvePnP, SOLVEPNP_EPNP branch)
+__device__ void solve_epnp(EpnpCtx& e, const PtSet& ps, double* ut, double rvec[3], double tvec[3]) {
+  const int n = ps.n;
+  // choose_control_points
+  e.cws[0][0] = e.cws[0][1] = e.cws[0][2] = 0;
+  { PtIter it(ps); for (int i = 0; i < n; i++) { const double* p = e.obj + 3 * it.next(); for (int j = 0; j < 3; j++) e.cws[0][j] += p[j]; } }
+  for (int j = 0; j < 3; j++) e.cws[0][j] /= n;
+  {
+    double At[9], dc[3], vt[9];
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) {
+        double s = 0;
+        PtIter it(ps);
+        for (int i = 0; i < n; i++) { const double* p = e.obj + 3 * it.next(); s += (p[a] - e.cws[0][a]) * (p[b] - e.cws[0][b]); }
+        At[b * 3 + a] = s;   // At = transpose (the matrix is symmetric)
+      }
+    jacobi_small<3, 3>(At, dc, vt);
+    for (int i = 1; i < 4; i++) {
+      const double k = sqrt(dc[i - 1] / n);
+      for (int j = 0; j < 3; j++) e.cws[i][j] = e.cws[0][j] + k * At[3 * (i - 1) + j];
+    }
+  }
+  {  // compute_barycentric_coordinates: cvInvert(CC, CC_inv, CV_SVD)
+    double cc[9];
+    const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int i = 0; i < 3; i++)
+      for (int j = 1; j < 4; j++) cc[3 * i + j - 1] = e.cws[j][i] - e.cws[0][i];
+    svd_solve<3, 3, 3>(cc, eye, e.cc_inv);
+  }
+  // M^T M accumulated row pair by row pair (same summation order as cvMulTransposed over M)
+  for (int a = 0; a < 12; a++)
+    for (int b = 0; b < 12; b++) UT(a, b) = 0;
+  {
+    PtIter it(ps);
+    for (int i = 0; i < n; i++) {
+      const int idx = it.next();
+      double al[4];
+      alphas_of(e, e.obj + 3 * idx, al);
+      const double u = e.us[2 * idx], v = e.us[2 * idx + 1];
+      double m1[12], m2[12];
+      for (int a = 0; a < 4; a++) {
+        m1[3 * a] = al[a] * e.fu; m1[3 * a + 1] = 0.0; m1[3 * a + 2] = al[a] * (e.uc - u);
+        m2[3 * a] = 0.0; m2[3 * a + 1] = al[a] * e.fv; m2[3 * a + 2] = al[a] * (e.vc - v);
+      }
+      for (int a = 0; a < 12; a++)
+        for (int b = a; b < 12; b++) {
+          double s = UT(a, b);
+          s += m1[a] * m1[b];
+          s += m2[a] * m2[b];
+          UT(a, b) = s;
+        }
+    }
+    for (int a = 0; a < 12; a++)
+      for (int b = 0; b < a; b++) UT(a, b) = UT(b, a);
+  }
+  jacobi12(ut);
+
+  double L[60], rho[6];
+  {  // compute_L_6x10
+    double dv[4][6][3];
+    for (int i = 0; i < 4; i++) {
+      int a = 0, b = 1;
+      for (int j = 0; j < 6; j++) {
+        dv[i][j][0] = UT(11 - i, 3 * a) - UT(11 - i, 3 * b);
+        dv[i][j][1] = UT(11 - i, 3 * a + 1) - UT(11 - i, 3 * b + 1);
+        dv[i][j][2] = UT(11 - i, 3 * a + 2) - UT(11 - i, 3 * b + 2);
+        b++;
+        if (b > 3) { a++; b = a + 1; }
+      }
+    }
+    for (int i = 0; i < 6; i++) {
+      double* row = L + 10 * i;
+      row[0] = dot3(dv[0][i], dv[0][i]);
+      row[1] = 2.0f * dot3(dv[0][i], dv[1][i]);
+      row[2] = dot3(dv[1][i], dv[1][i]);
+      row[3] = 2.0f * dot3(dv[0][i], dv[2][i]);
+      row[4] = 2.0f * dot3(dv[1][i], dv[2][i]);
+      row[5] = dot3(dv[2][i], dv[2][i]);
+      row[6] = 2.0f * dot3(dv[0][i], dv[3][i]);
+      row[7] = 2.0f * dot3(dv[1][i], dv[3][i]);
+      row[8] = 2.0f * dot3(dv[2][i], dv[3][i]);
+      row[9] = dot3(dv[3][i], dv[3][i]);
+    }
+  }
+  rho[0] = dist2(e.cws[0], e.cws[1]); rho[1] = dist2(e.cws[0], e.cws[2]); rho[2] = dist2(e.cws[0], e.cws[3]);
+  rho[3] = dist2(e.cws[1], e.cws[2]); rho[4] = dist2(e.cws[1], e.cws[3]); rho[5] = dist2(e.cws[2], e.cws[3]);
+
+  double betas[4], bestR[9], bestt[3], best_err = 0;
+  for (int N = 1; N <= 3; N++) {
+    if (N == 1) {  // find_betas_approx_1: columns {0,1,3,6}
+      double l[24], b4[4];
+      for (int i = 0; i < 6; i++) { l[4 * i] = L[10 * i]; l[4 * i + 1] = L[10 * i + 1]; l[4 * i + 2] = L[10 * i + 3]; l[4 * i + 3] = L[10 * i + 6]; }
+      svd_solve<6, 4, 1>(l, rho, b4);
+      if (b4[0] < 0) { betas[0] = sqrt(-b4[0]); betas[1] = -b4[1] / betas[0]; betas[2] = -b4[2] / betas[0]; betas[3] = -b4[3] / betas[0]; }
+      else { betas[0] = sqrt(b4[0]); betas[1] = b4[1] / betas[0]; betas[2] = b4[2] / betas[0]; betas[3] = b4[3] / betas[0]; }
+    } else if (N == 2) {  // columns {0,1,2}
+      double l[18], b3[3];
+      for (int i = 0; i < 6; i++) { l[3 * i] = L[10 * i]; l[3 * i + 1] = L[10 * i + 1]; l[3 * i + 2] = L[10 * i + 2]; }
+      svd_solve<6, 3, 1>(l, rho, b3);
+      if (b3[0] < 0) { betas[0] = sqrt(-b3[0]); betas[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0; }
+      else { betas[0] = sqrt(b3[0]); betas[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0; }
+      if (b3[1] < 0) betas[0] = -betas[0];
+      betas[2] = 0.0; betas[3] = 0.0;
+    } else {  // columns {0,1,2,3,4}
+      double l[30], b5[5];
+      for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 5; j++) l[5 * i + j] = L[10 * i + j];
+      svd_solve<6, 5, 1>(l, rho, b5);
+      if (b5[0] < 0) { betas[0] = sqrt(-b5[0]); betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0; }
+      else { betas[0] = sqrt(b5[0]); betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0; }
+      if (b5[1] < 0) betas[0] = -betas[0];
+      betas[2] = b5[3] / betas[0];
+      betas[3] = 0.0;
+    }
+    gauss_newton(L, rho, betas);
+    double R[9], t[3];
+    const double err = compute_R_and_t(e, ps, ut, betas, R, t);
+    if (N == 1 || err < best_err) {   // rep_errors[2] < [1], then [3] < [N]: strict '<' keeps the earlier one
+      best_err = err;
+      for (int k = 0; k < 9; k++) bestR[k] = R[k];
+      for (int k = 0; k < 3; k++) bestt[k] = t[k];
+    }
+  }
+  for (int k = 0; k < 3; k++) tvec[k] = bestt[k];
+  rodrigues_mat2vec(bestR, rvec);
+}
+#undef UT
+
+__device__ int ransac_update_num_iters(double p, double ep, int model_points, int max_iters) {
+  p = p > 0. ? p : 0.; p = p < 1. ? p : 1.;
+  ep = ep > 0. ? ep : 0.; ep = ep < 1. ? ep : 1.;
+  double num = (1. - p) > DBL_MIN ? (1. - p) : DBL_MIN;
+  double denom = 1. - pow(1. - ep, (double)model_points);
+  if (denom < DBL_MIN) return 0;
+  num = log(num);
+  denom = log(denom);
+  return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+}
+
+__global__ __launch_bounds__(64) void pnp_kernel(const PnpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* s_ut = smem;                       // 144 x 64
+  double* s_obj = s_ut + 144 * 64;           // kMaxJ x 3
+  double* s_u32 = s_obj + kMaxJ * 3;         // kMaxJ x 2  (undistorted, float32-rounded, * f + c)
+  double* s_u64 = s_u32 + kMaxJ * 2;         // kMaxJ x 2
+  double* s_img = s_u64 + kMaxJ * 2;         // kMaxJ x 2  raw float32 image points
+
+  const int lane = threadIdx.x;
+  const int frame = blockIdx.x;
+  const int J = a.J;
+  Cam cam;
+  cam.fx = a.K[0]; cam.fy = a.K[4]; cam.cx = a.K[2]; cam.cy = a.K[5];
+  for (int i = 0; i < 5; i++) cam.k[i] = a.dist ? a.dist[i] : 0.0;
+
+  // ---- confidence filter (export_predicted_poses_real.py:186-197) ----
+  const float* kp = a.kp + (size_t)frame * J * 3;
+  const float conf = lane < J ? kp[lane * 3 + 2] : -__builtin_inff();
+  double thr64 = a.conf_thr0;
+  unsigned long long sel;
+  for (int it = 0;;) {
+    const float thr = (float)thr64;
+    sel = __ballot(lane < J && conf > thr);
+    if (__popcll(sel) >= a.min_pts) break;
+    thr64 *= a.thr_decay;
+    if (++it >= a.thr_iters) { sel = __ballot(lane < J && conf > (float)thr64); break; }
+  }
+  const int n = __popcll(sel);
+  if ((sel >> lane) & 1ULL) {   // compact in landmark order; float32 roundings of solvePnPRansac's convertTo
+    const int pos = __popcll(sel & ((1ULL << lane) - 1ULL));
+    for (int k = 0; k < 3; k++) s_obj[pos * 3 + k] = (double)(float)a.landmarks[lane * 3 + k];
+    const double u = (double)kp[lane * 3], v = (double)kp[lane * 3 + 1];
+    double x, y;
+    undistort_point(cam, u, v, &x, &y);
+    s_u64[pos * 2] = x * cam.fx + cam.cx; s_u64[pos * 2 + 1] = y * cam.fy + cam.cy;
+    s_u32[pos * 2] = (double)(float)x * cam.fx + cam.cx; s_u32[pos * 2 + 1] = (double)(float)y * cam.fy + cam.cy;
+    s_img[pos * 2] = u; s_img[pos * 2 + 1] = v;
+  }
+  __syncthreads();
+
+  double rvec[3] = {0, 0, 0}, tvec[3] = {0, 0, 0};
+  int status;
+  EpnpCtx e;
+  e.obj = s_obj; e.uc = cam.cx; e.vc = cam.cy; e.fu = cam.fx; e.fv = cam.fy;
+  double* ut = s_ut + lane;
+  const int model_points = 5;
+
+  if (n < 4) {
+    status = -1;
+  } else if (n == 4) {
+    status = -3;   // OpenCV switches to its P3P kernel for exactly 4 points: not on this path
+  } else if (n == model_points) {
+    PtSet ps{(1ULL << n) - 1ULL, 0u, n, false};
+    e.us = s_u32;
+    solve_epnp(e, ps, ut, rvec, tvec);
+    status = n;
+  } else {
+    int niters = a.max_iters > 1 ? a.max_iters : 1;
+    int max_good = 0;
+    unsigned long long best_mask = 0;
+    double best_r[3] = {0, 0, 0}, best_t[3] = {0, 0, 0};
+    CvRng rng{~0ULL};
+    const float t2 = (float)(a.reproj_err * a.reproj_err);
+    for (int iter0 = 0; iter0 < niters;) {
+      const int nb = min(64, niters - iter0);
+      unsigned my_packed = 0;
+      for (int k = 0; k < nb; k++) {   // getSubset: duplicate-free draws, one shared RNG stream
+        unsigned packed = 0;
+        int idx[5];
+        for (int i = 0; i < model_points; i++) {
+          int idx_i;
+          for (;;) {
+            idx_i = idx[i] = rng.uniform(0, n);
+            int j = 0;
+            for (; j < i; j++) if (idx_i == idx[j]) break;
+            if (j == i) break;
+          }
+          packed |= (unsigned)idx_i << (6 * i);
+        }
+        if (k == lane) my_packed = packed;
+      }
+      double r[3] = {0, 0, 0}, t[3] = {0, 0, 0};
+      unsigned long long mask = 0;
+      int good = 0;
+      if (lane < nb) {
+        PtSet ps{0ULL, my_packed, model_points, true};
+        e.us = s_u32;
+        solve_epnp(e, ps, ut, r, t);
+        double R[9];
+        rodrigues_vec2mat(r, R);
+        for (int i = 0; i < n; i++) {   // PnPRansacCallback::computeError + findInliers
+          double u, v;
+          project_point(cam, R, t, s_obj + 3 * i, &u, &v);
+          const float pu = (float)u, pv = (float)v;
+          const float dx = (float)s_img[2 * i] - pu, dy = (float)s_img[2 * i + 1] - pv;
+          const float err = (float)((double)dx * dx + (double)dy * dy);
+          if (err <= t2) { mask |= 1ULL << i; good++; }
+        }
+      }
+      // scan the batch in iteration order with OpenCV's acceptance rule
+      int best_lane = -1;
+      for (int k = 0; k < nb && iter0 + k < niters; k++) {
+        const int g = __shfl(good, k, 64);
+        if (g > max(max_good, model_points - 1)) {
+          max_good = g;
+          best_lane = k;
+          niters = ransac_update_num_iters(a.confidence, (double)(n - g) / n, model_points, niters);
+        }
+      }
+      if (best_lane >= 0) {
+        best_mask = __shfl(mask, best_lane, 64);
+        for (int k = 0; k < 3; k++) { best_r[k] = __shfl(r[k], best_lane, 64); best_t[k] = __shfl(t[k], best_lane, 64); }
+      }
+      iter0 += nb;
+    }
+    if (max_good <= 0) {
+      status = -2;
+    } else {
+      PtSet ps{best_mask, 0u, (int)__popcll(best_mask), false};
+      e.us = s_u64;
+      solve_epnp(e, ps, ut, rvec, tvec);   // wave-uniform
+      status = ps.n;
+    }
+  }
+
+  if (lane == 0) {
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (status > 0) rodrigues_vec2mat(rvec, R);
+    else { rvec[0] = rvec[1] = rvec[2] = 0; tvec[0] = tvec[1] = tvec[2] = 0; }
+    for (int k = 0; k < 9; k++) a.rot[(size_t)frame * 9 + k] = R[k];
+    for (int k = 0; k < 3; k++) a.tvec[(size_t)frame * 3 + k] = tvec[k];
+    if (a.rvec) for (int k = 0; k < 3; k++) a.rvec[(size_t)frame * 3 + k] = rvec[k];
+    a.status[frame] = status;
+  }
+}
+
+int32_t pnp_launch(const float* kp_xyc, const double* landmarks, const double* K, const double* dist,
+                   int N, int J, double conf_thr0, int min_pts, double thr_decay, int thr_iters,
+                   int max_iters, double reproj_err, double confidence, double* rot, double* tvec,
+                   double* rvec, int32_t* status, hipStream_t stream) {
+  SCP_REQUIRE(J >= 1 && J <= kMaxJ, "pnp: J=%d landmarks (1..%d)", J, kMaxJ);
+  SCP_REQUIRE(confidence > 0 && confidence < 1, "pnp: confidence %g must be in (0,1)", confidence);
+  SCP_REQUIRE(N >= 0, "pnp: N=%d", N);
+  if (N == 0) return SCPOSE_OK;
+  PnpArgs a{kp_xyc, landmarks, K, dist, rot, tvec, rvec, status, N, J, conf_thr0, thr_decay, min_pts, thr_iters,
+            max_iters, reproj_err, confidence};
+  const size_t lds = (size_t)(144 * 64 + kMaxJ * 9) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SCP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pnp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(pnp_kernel, dim3(N), dim3(64), lds, stream, a);
+  SCP_CHECK_HIP(hipGetLastError());
+  return SCPOSE_OK;
+}
+
+}  // namespace scpose

@@ -1,0 +1,103 @@
+"""Parity of the one-wavefront-per-frame EPnP+RANSAC kernel (csrc/pnp.hip, C ABI
+scpose_pnp_epnp_ransac) against the scalar C oracle (oracle/pnp_ref.c).
+
+Tolerance (BASELINE.json north_star): rotation <= 1e-4 rad (geodesic angle of R_ref^T R),
+translation <= 1e-4 relative (|dt|/|t|); inlier counts (status) must be identical.
+The oracle itself is "parity unpinned" w.r.t. cv2 (see oracle/pnp_ref.c); both are also
+checked against the generating ground-truth pose."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pnp_ref as P
+
+pytestmark = pytest.mark.gpu
+
+ROT_TOL, T_TOL = 1e-4, 1e-4
+
+
+def _gpu(gpu_ops, kp, landmarks=P.LANDMARKS, **kw):
+    rot, tv, st, rv = gpu_ops.pnp_epnp_ransac(torch.from_numpy(kp).cuda(), torch.from_numpy(landmarks).cuda(),
+                                              torch.from_numpy(P.CAMERA_K).cuda(), torch.from_numpy(P.CAMERA_DIST).cuda(),
+                                              want_rvec=True, **kw)
+    return rot.cpu().numpy(), tv.cpu().numpy(), st.cpu().numpy(), rv.cpu().numpy()
+
+
+def _check(gpu, ref):
+    rot, tv, st, rv = gpu
+    assert np.array_equal(st, ref["status"]), "inlier counts differ: %s vs %s" % (st[:16], ref["status"][:16])
+    ok = st > 0
+    ang = P.rot_angle(rot[ok], ref["R"][ok])
+    terr = np.linalg.norm(tv[ok] - ref["t"][ok], axis=1) / np.linalg.norm(ref["t"][ok], axis=1)
+    assert ang.max() <= ROT_TOL, "rotation differs by %.3g rad" % ang.max()
+    assert terr.max() <= T_TOL, "translation differs by %.3g (relative)" % terr.max()
+    # orthonormal output
+    eye = np.einsum("nij,nkj->nik", rot[ok], rot[ok])
+    assert np.abs(eye - np.eye(3)).max() < 1e-12
+    return ang.max(), terr.max()
+
+
+@pytest.mark.parametrize("noise,outliers", [(0.0, 0.0), (1.0, 0.0), (1.0, 0.1), (1.0, 0.3), (3.0, 0.3)])
+def test_pnp_matches_oracle(gpu_ops, noise, outliers):
+    rng = np.random.default_rng(int(noise * 10 + outliers * 100))
+    kp, Rs, ts = P.synth_keypoints(128, rng, noise, outliers)
+    ref = P.solve_batch(kp)
+    gpu = _gpu(gpu_ops, kp)
+    a, t = _check(gpu, ref)
+    print("noise %.1f outliers %.1f: max rot diff %.2e rad, max t diff %.2e, mean RANSAC iters %.1f" % (
+        noise, outliers, a, t, ref["iters"].mean()))
+    if noise == 0.0:   # known answer: exact projections recover the generating pose
+        assert P.rot_angle(gpu[0], Rs).max() < 5e-6
+        assert (np.linalg.norm(gpu[1] - ts, axis=1) / np.linalg.norm(ts, axis=1)).max() < 5e-6
+
+
+def test_pnp_confidence_filter_and_failures(gpu_ops):
+    rng = np.random.default_rng(5)
+    kp, _, _ = P.synth_keypoints(8, rng, 0.5, 0.0)
+    kp[0, :, 2] = 0.0                     # nothing passes (conf > ~2e-10 false): <4 points -> -1
+    kp[1, 3:, 2] = 0.0                    # 3 points -> -1
+    kp[2, 4:, 2] = -1.0                   # exactly 4 points -> -3 (OpenCV would switch to P3P)
+    kp[3, 5:, 2] = 0.0                    # exactly 5 points: direct EPnP, no RANSAC
+    kp[4, 6:, 2] = 1e-12                  # below the final threshold 0.95*0.8^100 = 1.9e-10 -> 6 points
+    kp[5, :, 2] = 1e-9                    # just above it: all 11
+    kp[6, 0, 2] = np.float32(0.95 * 0.8 ** 100)   # boundary: strict '>' on float32
+    ref = P.solve_batch(kp)
+    gpu = _gpu(gpu_ops, kp)
+    assert list(ref["status"][:4]) == [-1, -1, -3, 5]
+    _check(gpu, ref)
+    assert np.array_equal(gpu[0][0], np.eye(3)) and np.all(gpu[1][0] == 0)
+
+
+def test_pnp_threshold_loop_with_24_landmarks(gpu_ops):
+    """J = 24 (Hubble default, evaluate_pipeline.py:44): the loop stops at the first threshold
+    that admits >= 15 points, so low-confidence landmarks are really dropped."""
+    rng = np.random.default_rng(9)
+    lm = rng.uniform(-1, 1, (24, 3))
+    kp, Rs, ts = P.synth_keypoints(32, rng, 0.5, 0.0, landmarks=lm)
+    kp[:, :, 2] = rng.uniform(0.2, 1.0, (32, 24)).astype(np.float32)
+    bad = kp[:, :, 2] < 0.5
+    kp[bad, 0] += 300.0                   # low-confidence points are gross outliers
+    ref = P.solve_batch(kp, landmarks=lm)
+    gpu = _gpu(gpu_ops, kp, landmarks=lm)
+    _check(gpu, ref)
+
+
+def test_pnp_full_batch_properties(gpu_ops):
+    """BASELINE config B batch (256 frames): every clean frame keeps all 11 inliers and the
+    reprojection of the recovered pose stays within the RANSAC gate."""
+    rng = np.random.default_rng(21)
+    kp, Rs, ts = P.synth_keypoints(256, rng, 1.0, 0.0)
+    rot, tv, st, _ = _gpu(gpu_ops, kp)
+    assert (st == 11).all()
+    for i in range(0, 256, 17):
+        uv = P.project_numpy(rot[i], tv[i], P.LANDMARKS)
+        assert np.abs(uv - kp[i, :, :2]).max() < 15.0
+
+
+def test_pnp_empty_batch_and_bad_args(gpu_ops):
+    rot, tv, st = gpu_ops.pnp_epnp_ransac(torch.zeros(0, 11, 3).cuda(), torch.from_numpy(P.LANDMARKS).cuda(),
+                                          torch.from_numpy(P.CAMERA_K).cuda(), torch.from_numpy(P.CAMERA_DIST).cuda())
+    assert rot.shape == (0, 3, 3) and st.shape == (0,)
+    with pytest.raises(gpu_ops.nat.NativeError, match="landmarks"):
+        gpu_ops.pnp_epnp_ransac(torch.zeros(1, 65, 3).cuda(), torch.zeros(65, 3, dtype=torch.float64).cuda(),
+                                torch.from_numpy(P.CAMERA_K).cuda(), None)
