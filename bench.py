@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""End-to-end poses/s of the HIP HRNet -> decode -> EPnP/RANSAC path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): HRNet-W48,
+384x384 synthetic RGB crops, 11 landmarks, 256 frames per GPU per step, bf16 MFMA; weak scaling:
+every rank processes its own contiguous shard of the frame list and the per-rank (R, t,
+status) blocks are all-gathered over RCCL (13 float64 per frame) -- SURVEY.md section 8(e).
+
+A step, timed with inputs resident in HBM: uint8 crops -> pose_hrnet forward -> heatmap decode
+-> batched EPnP+RANSAC -> all-gather -> (R, t, status) on the host of rank 0.
+The random-init network's heatmaps carry no pose, so -- as SURVEY.md section 8(d) prescribes --
+the PnP stage consumes seeded synthetic keypoints (landmarks projected through random poses,
+1 px noise, 10 % outliers) of the same shape; the decode stage still runs on the network's
+heatmaps inside the timed region.  Nothing is skipped or cached between steps.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel class, from HIP events recorded around every launch of the
+                timed steps (scpose_hrnet_forward_profiled): algorithmic bytes|flops / time.
+  cpu_baseline  the CPU oracle (oracle/, a port of the reference path) timed on this host's
+                cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0    # dense bf16/f16 MFMA
+BATCH_PER_GPU = 256
+IMAGE = 384
+JOINTS = 11
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="frames per GPU per step")
+    ap.add_argument("--model", default="w48", choices=["w48", "w32"])
+    ap.add_argument("--image", type=int, default=None)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--chained", action="store_true",
+                    help="feed the PnP stage with the decoded (random-weight) keypoints instead of synthetic ones")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, sd, image, nframes, kp_sample):
+    """Reference path restated on the CPU (oracle/): fp32 torch forward on all host cores,
+    NumPy decode with the reference's Python loops, serial C EPnP+RANSAC per frame.
+    This leg is the ONLY place bench.py touches oracle/ -- as the reported baseline, never as
+    part of the measured GPU path."""
+    from oracle import hrnet_ref as R, decode_ref as D, pnp_ref as P
+    cores = torch.get_num_threads()
+    g = torch.Generator().manual_seed(123)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    bs = 8
+    t_net = t_dec = t_pnp = 0.0
+    done = 0
+    P.lib()
+    while done < nframes:
+        n = min(bs, nframes - done)
+        u8 = torch.randint(0, 256, (n, image, image, 3), generator=g, dtype=torch.uint8)
+        t0 = time.perf_counter()
+        x = (u8.permute(0, 3, 1, 2).float() / 255.0 - mean) / std
+        with torch.no_grad():
+            hm = R.forward(sd, cfg, x).numpy()
+        t1 = time.perf_counter()
+        c = np.full((n, 2), image / 2.0, dtype=np.float32)
+        s = np.full((n, 2), image / 200.0 * 1.5, dtype=np.float32)
+        D.decode_xyc(True, hm, c, s)
+        t2 = time.perf_counter()
+        P.solve_batch(kp_sample[done:done + n])
+        t3 = time.perf_counter()
+        t_net += t1 - t0; t_dec += t2 - t1; t_pnp += t3 - t2
+        done += n
+    total = t_net + t_dec + t_pnp
+    return {"value": round(nframes / total, 3), "unit": "poses/s", "cores": cores, "kind": "port",
+            "sample": "%d frames of the same workload (HRNet-%s %dx%d fp32 torch-CPU forward in batches of %d, NumPy decode, "
+                      "serial C EPnP+RANSAC), %.1f s" % (nframes, "W48" if cfg["MODEL"]["EXTRA"]["STAGE2"]["NUM_CHANNELS"][0] == 48 else "W32",
+                                                         image, image, bs, total),
+            "stage_s_per_frame": {"hrnet": t_net / nframes, "decode": t_dec / nframes, "pnp": t_pnp / nframes}}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world), file=sys.stderr)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import scpose  # noqa: F401  (alias of the hyphenated package)
+    from importlib import import_module
+    ops = import_module("spacecraft-pose-estimation_amd.ops")
+    syn = import_module("spacecraft-pose-estimation_amd.synthetic")   # product-side data generation (no oracle/)
+
+    image = args.image or (IMAGE if args.model == "w48" else 256)
+    cfg = syn.hrnet_cfg(48 if args.model == "w48" else 32, JOINTS, image)
+    sd = syn.random_checkpoint(cfg, seed=0)
+    eng = ops.HrnetEngine(cfg, sd, dtype=args.dtype, device=dev)
+    B = args.batch
+    hh = image // 4
+
+    # ---- synthetic inputs, resident in HBM before the timed region (shard = rank's slice) ----
+    g = torch.Generator().manual_seed(1000 + rank)
+    frames = torch.randint(0, 256, (B, image, image, 3), generator=g, dtype=torch.uint8).to(dev)
+    center = torch.full((B, 2), image / 2.0, dtype=torch.float32, device=dev)
+    scale = torch.full((B, 2), image / 200.0 * 1.5, dtype=torch.float32, device=dev)
+    kp_np, _, _ = syn.keypoints(B, np.random.default_rng(2000 + rank), noise_px=1.0, outlier_frac=0.1)
+    kp_syn = torch.from_numpy(kp_np).to(dev)
+    lm = torch.from_numpy(syn.TANGO_LANDMARKS).to(dev)
+    Kc = torch.from_numpy(syn.SPEEDPLUS_K).to(dev)
+    dc = torch.from_numpy(syn.SPEEDPLUS_DIST).to(dev)
+    heat = torch.empty((B, JOINTS, hh, hh), dtype=torch.float32, device=dev)
+    block = torch.empty((B, 13), dtype=torch.float64, device=dev)
+    gathered = torch.empty((world * B, 13), dtype=torch.float64, device=dev) if world > 1 else None
+
+    prof_ms = {}
+
+    def step(profile):
+        eng.forward(frames, out=heat, profile=profile)
+        kp = ops.decode(heat, center, scale, True)
+        rot, tv, st = ops.pnp_epnp_ransac(kp if args.chained else kp_syn, lm, Kc, dc)
+        block[:, 0:9] = rot.view(B, 9)
+        block[:, 9:12] = tv
+        block[:, 12] = st.double()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, block)
+            out = gathered
+        else:
+            out = block
+        host = out.cpu() if rank == 0 else None     # (R, t, status) of every frame on rank 0's host
+        if profile:
+            for rec in eng.profile_read():
+                key = (rec["kind"], rec["a"], rec["cin"], rec["cout"])
+                e = prof_ms.setdefault(key, [0.0, 0, 0.0, 0.0])
+                e[0] += rec["ms"]; e[1] += 1; e[2] += rec["flops_per_frame"] * B; e[3] += rec["bytes_per_frame"] * B
+        return host
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    host = None
+    for _ in range(args.steps):
+        host = step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        ok = int((host[:, 12] > 0).sum().item())
+        total_frames = world * B * args.steps
+        # ---- roofline of the dominant kernel class (largest summed time over the timed steps) ----
+        key, (ms, calls, flops, byts) = max(prof_ms.items(), key=lambda kv: kv[1][0])
+        kind, a, cin, cout = key
+        kname = {0: "stem_conv1_kernel (3->64 3x3 s2, f32 VALU)", 2: "fuse_sum_kernel (%d terms, C=%d)" % (a, cin)}.get(
+            kind, "conv_igemm_kernel %dx%d s%d %d->%d" % (a // 10, a // 10, a % 10, cin, cout))
+        ai = flops / byts if byts else float("inf")
+        hbm_bound = ai < MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+        sec = ms / 1e3
+        if hbm_bound:
+            roof = {"bound": "hbm", "achieved": round(byts / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        else:
+            roof = {"bound": "mfma", "achieved": round(flops / sec / 1e12, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+        roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+        roof["traffic"] = None   # HBM bytes from PMC counters: collected by separate rocprofv3 --pmc passes (profiles/)
+        roof.update({"kernel": kname, "launches": calls, "avg_launch_us": round(ms / calls * 1e3, 2),
+                     "share_of_forward": round(ms / sum(v[0] for v in prof_ms.values()), 4),
+                     "flop_per_byte": round(ai, 1),
+                     "also_tflops": round(flops / sec / 1e12, 2), "also_gbs": round(byts / sec / 1e9, 1)})
+        fwd_ms = sum(v[0] for v in prof_ms.values()) / args.steps
+        cpu = None
+        if world == 1 and args.cpu_frames > 0:
+            cpu = cpu_baseline(cfg, sd, image, args.cpu_frames, kp_np)
+        st = eng.stats(image, image)
+        line = {
+            "metric": "poses/sec end-to-end (HRNet+PnP) at batch 256; keypoint/pose err vs ref",
+            "value": round(total_frames / elapsed, 2), "unit": "poses/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "HRNet-%s %dx%d %d joints, batch %d per GPU + batched EPnP-RANSAC HIP kernel%s" % (
+                           args.model.upper(), image, image, JOINTS, B, " (PnP chained to decoded keypoints)" if args.chained else ""),
+                       "frames_per_step": world * B, "parallelism": "frame-sharded x%d, all-gather of (R,t,status)" % world,
+                       "pnp_input": "decoded" if args.chained else "synthetic projected landmarks, 1 px noise, 10% outliers",
+                       "launches_per_forward": st["launches"], "gflop_per_frame": round(st["flops_per_frame"] / 1e9, 3),
+                       "act_mbytes_per_frame": round(st["act_bytes_per_frame"] / 1e6, 2)},
+            "hrnet_forward_ms": round(fwd_ms, 3),
+            "hrnet_tflops": round(st["flops_per_frame"] * B / (fwd_ms / 1e3) / 1e12, 2),
+            "poses_ok": ok, "poses_total": world * B,
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -100,6 +100,17 @@ int32_t scpose_hrnet_forward(scpose_hrnet_t h, const void* in, int32_t in_fmt, i
                              int32_t height, int32_t width, float* heatmaps, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+/* Measurement hooks (bench.py): the same forward with a HIP event recorded on `stream` before
+ * every launch and after the last one, then per-launch milliseconds, algorithmic FLOPs and
+ * bytes per frame and a kernel signature {kind(0 stem,1 conv,2 fuse), 10*ksize+stride | nterms,
+ * Cin, Cout}.  profile_read blocks on the last event.  Call with ms == NULL to get *count. */
+int32_t scpose_hrnet_forward_profiled(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n,
+                                      int32_t height, int32_t width, float* heatmaps,
+                                      void* workspace, size_t workspace_bytes, void* stream);
+int32_t scpose_hrnet_profile_read(scpose_hrnet_t h, int32_t height, int32_t width, int32_t cap,
+                                  float* ms, double* flops_per_frame, double* bytes_per_frame,
+                                  int32_t* sig, int32_t* count);
+
 /* ------------------------------------------------------------------------------------------
  * Heatmap decode.  Replaces get_max_preds + get_final_preds + transform_preds
  * (landmark_regression/lib/core/inference.py:18-79, lib/utils/transforms.py:49-110) and the

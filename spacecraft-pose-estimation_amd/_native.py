@@ -43,6 +43,10 @@ SYMBOLS = {
                                      POINTER(c_double)]),
     "scpose_hrnet_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                        c_void_p, c_size_t, c_void_p]),
+    "scpose_hrnet_forward_profiled": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                                c_void_p, c_size_t, c_void_p]),
+    "scpose_hrnet_profile_read": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, POINTER(c_int32)]),
     "scpose_decode": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
                                 c_void_p, c_void_p]),
     "scpose_max_preds": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,

@@ -98,6 +98,9 @@ struct scpose_hrnet {
   // cached arena plan
   int plan_n = -1, plan_h = -1, plan_w = -1;
   size_t plan_bytes = 0;
+  // per-op HIP events of the last profiled forward (ops.size()+1, created on first use)
+  std::vector<hipEvent_t> events;
+  bool events_valid = false;
 };
 
 namespace scpose {
@@ -330,7 +333,7 @@ size_t hrnet_plan(scpose_hrnet* net, int n, int h, int w) {
 }
 
 int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int h, int w,
-                      float* heatmaps, void* ws, size_t ws_bytes, hipStream_t st) {
+                      float* heatmaps, void* ws, size_t ws_bytes, hipStream_t st, bool profile) {
   SCP_REQUIRE(n > 0, "hrnet_forward: batch %d", n);
   SCP_REQUIRE(h % 32 == 0 && w % 32 == 0 && h > 0 && w > 0, "hrnet_forward: H=%d W=%d must be multiples of 32", h, w);
   const size_t need = hrnet_plan(net, n, h, w);
@@ -340,7 +343,15 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
   }
   char* base = static_cast<char*>(ws);
   auto ptr = [&](int t) -> void* { return t >= 0 ? base + net->tensors[t].off : nullptr; };
+  if (profile && net->events.empty()) {
+    net->events.resize(net->ops.size() + 1);
+    for (auto& e : net->events) SCP_CHECK_HIP(hipEventCreate(&e));
+  }
+  net->events_valid = false;
+  size_t opi = 0;
   for (const Op& op : net->ops) {
+    if (profile) SCP_CHECK_HIP(hipEventRecord(net->events[opi], st));
+    ++opi;
     int32_t rc = SCPOSE_OK;
     if (op.kind == OP_STEM) {
       rc = stem_launch(in, in_fmt, net->d_stem_w, net->d_stem_b, net->d_mean_std, n, h, w,
@@ -359,29 +370,45 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
     }
     if (rc != SCPOSE_OK) return rc;
   }
+  if (profile) {
+    SCP_CHECK_HIP(hipEventRecord(net->events[opi], st));
+    net->events_valid = true;
+  }
   return SCPOSE_OK;
+}
+
+// per-op algorithmic work (per frame) and a signature identifying the kernel variant
+static void op_work(const scpose_hrnet* net, const Op& op, int h, int w, double* f, double* by, int32_t sig[4]) {
+  *f = 0; *by = 0;
+  sig[0] = op.kind; sig[1] = sig[2] = sig[3] = 0;
+  if (op.kind == OP_STEM) {
+    *f = 2.0 * 27 * 64 * (h / 2) * (w / 2);
+    *by = (double)64 * (h / 2) * (w / 2) * 2 + 3.0 * h * w;   // u8 in (f32 in: 4x) + 16-bit out
+    sig[1] = 32; sig[2] = 3; sig[3] = 64;
+  } else if (op.kind == OP_CONV) {
+    const PackedConv& pc = net->convs[op.conv];
+    const TensorDesc& ti = net->tensors[op.in];
+    const double hi = h >> ti.ds, wi = w >> ti.ds;
+    const double ho = pc.stride == 2 ? hi / 2 : hi, wo = pc.stride == 2 ? wi / 2 : wi;
+    *f = 2.0 * pc.cin * pc.cout * pc.ks * pc.ks * ho * wo;
+    *by = pc.cin * hi * wi * 2 + pc.cout * ho * wo * (op.out_f32 ? 4 : 2) + (op.res >= 0 ? pc.cout * ho * wo * 2 : 0);
+    sig[1] = pc.ks * 10 + pc.stride; sig[2] = pc.cin; sig[3] = pc.cout;
+  } else {
+    const TensorDesc& to = net->tensors[op.out];
+    const double ho = h >> to.ds, wo = w >> to.ds;
+    *by = to.C * ho * wo * 2;
+    for (int k = 0; k < op.nterms; ++k) *by += to.C * (ho / (1 << op.shift[k])) * (wo / (1 << op.shift[k])) * 2;
+    sig[1] = op.nterms; sig[2] = to.C; sig[3] = to.C;
+  }
 }
 
 void hrnet_stats(scpose_hrnet* net, int h, int w, int* launches, double* flops, double* bytes) {
   double f = 0, by = 0;
   for (const Op& op : net->ops) {
-    if (op.kind == OP_STEM) {
-      f += 2.0 * 27 * 64 * (h / 2) * (w / 2);
-      by += 0;  // network input/first output counted below with the tensors
-      by += (double)64 * (h / 2) * (w / 2) * 2;
-    } else if (op.kind == OP_CONV) {
-      const PackedConv& pc = net->convs[op.conv];
-      const TensorDesc& ti = net->tensors[op.in];
-      const double hi = h >> ti.ds, wi = w >> ti.ds;
-      const double ho = pc.stride == 2 ? hi / 2 : hi, wo = pc.stride == 2 ? wi / 2 : wi;
-      f += 2.0 * pc.cin * pc.cout * pc.ks * pc.ks * ho * wo;
-      by += pc.cin * hi * wi * 2 + pc.cout * ho * wo * (op.out_f32 ? 4 : 2) + (op.res >= 0 ? pc.cout * ho * wo * 2 : 0);
-    } else {
-      const TensorDesc& to = net->tensors[op.out];
-      const double ho = h >> to.ds, wo = w >> to.ds;
-      by += to.C * ho * wo * 2;
-      for (int k = 0; k < op.nterms; ++k) by += to.C * (ho / (1 << op.shift[k])) * (wo / (1 << op.shift[k])) * 2;
-    }
+    double of, ob; int32_t sig[4];
+    op_work(net, op, h, w, &of, &ob, sig);
+    if (op.kind == OP_STEM) ob -= 3.0 * h * w;   // network input is not an inter-layer activation
+    f += of; by += ob;
   }
   if (launches) *launches = (int)net->ops.size();
   if (flops) *flops = f;
@@ -393,6 +420,8 @@ void hrnet_free(scpose_hrnet* net) {
   if (net->d_stem_w) (void)hipFree(net->d_stem_w);
   if (net->d_stem_b) (void)hipFree(net->d_stem_b);
   if (net->d_mean_std) (void)hipFree(net->d_mean_std);
+  for (auto& e : net->events) (void)hipEventDestroy(e);
+  net->events.clear();
 }
 
 }  // namespace scpose
@@ -466,5 +495,35 @@ extern "C" int32_t scpose_hrnet_forward(scpose_hrnet_t h, const void* in, int32_
                                         void* workspace, size_t workspace_bytes, void* stream) {
   SCP_REQUIRE(h && in && heatmaps, "hrnet_forward: null argument");
   return hrnet_forward(h, in, in_fmt, n, height, width, heatmaps, workspace, workspace_bytes,
-                       static_cast<hipStream_t>(stream));
+                       static_cast<hipStream_t>(stream), false);
+}
+
+extern "C" int32_t scpose_hrnet_forward_profiled(scpose_hrnet_t h, const void* in, int32_t in_fmt,
+                                                 int32_t n, int32_t height, int32_t width,
+                                                 float* heatmaps, void* workspace,
+                                                 size_t workspace_bytes, void* stream) {
+  SCP_REQUIRE(h && in && heatmaps, "hrnet_forward_profiled: null argument");
+  return hrnet_forward(h, in, in_fmt, n, height, width, heatmaps, workspace, workspace_bytes,
+                       static_cast<hipStream_t>(stream), true);
+}
+
+extern "C" int32_t scpose_hrnet_profile_read(scpose_hrnet_t h, int32_t height, int32_t width,
+                                             int32_t cap, float* ms, double* flops_per_frame,
+                                             double* bytes_per_frame, int32_t* sig, int32_t* count) {
+  SCP_REQUIRE(h && count, "hrnet_profile_read: null argument");
+  const int nops = (int)h->ops.size();
+  *count = nops;
+  if (!ms) return SCPOSE_OK;   // size query
+  SCP_REQUIRE(h->events_valid, "hrnet_profile_read: no profiled forward has been recorded");
+  SCP_REQUIRE(cap >= nops, "hrnet_profile_read: capacity %d < %d ops", cap, nops);
+  SCP_CHECK_HIP(hipEventSynchronize(h->events[nops]));
+  for (int i = 0; i < nops; ++i) {
+    SCP_CHECK_HIP(hipEventElapsedTime(&ms[i], h->events[i], h->events[i + 1]));
+    double f, b; int32_t sg[4];
+    op_work(h, h->ops[i], height, width, &f, &b, sg);
+    if (flops_per_frame) flops_per_frame[i] = f;
+    if (bytes_per_frame) bytes_per_frame[i] = b;
+    if (sig) for (int k = 0; k < 4; ++k) sig[i * 4 + k] = sg[k];
+  }
+  return SCPOSE_OK;
 }

@@ -1,0 +1,150 @@
+"""Host-side mirror of the reference pose_hrnet module API, executing on the HIP engine.
+
+Interface kept from landmark_regression/lib/models/pose_hrnet.py:
+  get_pose_net(cfg, is_train, **kwargs) -> nn.Module              (:495-501)
+  module(x: float32 N x 3 x H x W, normalised) -> float32 N x J x H/4 x W/4   (:425-460)
+  .state_dict() / .load_state_dict(sd, strict=False) with the reference's key names and shapes
+  (conv weights OIHW, BatchNorm weight/bias/running_mean/running_var/num_batches_tracked).
+
+The module tree below only HOLDS parameters (so checkpoints interchange and .cuda()/.eval()
+behave); it contains no torch compute.  forward() hands the tensors to libscpose_hip.so
+(csrc/hrnet.cpp), which folds BatchNorm, packs bf16/f16 MFMA weights and runs the hand-written
+kernels.  There is no eager fallback: without the HIP library or a GPU, forward() raises.
+Inference only (is_train=True is rejected: training is out of scope).
+"""
+import logging
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+logger = logging.getLogger(__name__)
+BN_MOMENTUM = 0.1
+
+
+def _conv(cin, cout, k, stride=1, bias=False):
+    return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=(k - 1) // 2, bias=bias)
+
+
+def _cbn(cin, cout, k, stride=1, relu=False, momentum=BN_MOMENTUM):
+    layers = [_conv(cin, cout, k, stride), nn.BatchNorm2d(cout, momentum=momentum)]
+    if relu:
+        layers.append(nn.ReLU(True))
+    return nn.Sequential(*layers)
+
+
+class _Params(nn.Module):
+    """A bag of named sub-modules that is never called."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container: compute runs in the HIP engine")
+
+
+def _basic_block(c):
+    m = _Params()
+    m.conv1 = _conv(c, c, 3); m.bn1 = nn.BatchNorm2d(c, momentum=BN_MOMENTUM)
+    m.conv2 = _conv(c, c, 3); m.bn2 = nn.BatchNorm2d(c, momentum=BN_MOMENTUM)
+    return m
+
+
+def _bottleneck(cin, planes, downsample):
+    m = _Params()
+    m.conv1 = _conv(cin, planes, 1); m.bn1 = nn.BatchNorm2d(planes, momentum=BN_MOMENTUM)
+    m.conv2 = _conv(planes, planes, 3); m.bn2 = nn.BatchNorm2d(planes, momentum=BN_MOMENTUM)
+    m.conv3 = _conv(planes, planes * 4, 1); m.bn3 = nn.BatchNorm2d(planes * 4, momentum=BN_MOMENTUM)
+    if downsample:
+        m.downsample = nn.Sequential(_conv(cin, planes * 4, 1), nn.BatchNorm2d(planes * 4, momentum=BN_MOMENTUM))
+    return m
+
+
+def _hr_module(channels, num_blocks, multi_scale_output):
+    nb = len(channels)
+    m = _Params()
+    m.branches = nn.ModuleList([nn.Sequential(*[_basic_block(channels[b]) for _ in range(num_blocks[b])]) for b in range(nb)])
+    rows = []
+    for i in range(nb if multi_scale_output else 1):
+        row = []
+        for j in range(nb):
+            if j > i:      # 1x1 + BN (+ nearest upsample, parameter-free; index 2 kept for key parity)
+                row.append(nn.Sequential(_conv(channels[j], channels[i], 1), nn.BatchNorm2d(channels[i]),
+                                         nn.Upsample(scale_factor=2 ** (j - i), mode="nearest")))
+            elif j == i:
+                row.append(None)
+            else:          # (i-j) stride-2 3x3 convs, ReLU on all but the last (fuse-layer BNs use default momentum)
+                chain = []
+                for k in range(i - j):
+                    last = k == i - j - 1
+                    chain.append(_cbn(channels[j], channels[i] if last else channels[j], 3, 2, relu=not last, momentum=0.1))
+                row.append(nn.Sequential(*chain))
+        rows.append(nn.ModuleList(row))
+    m.fuse_layers = nn.ModuleList(rows)
+    return m
+
+
+class PoseHighResolutionNet(nn.Module):
+    def __init__(self, cfg, **kwargs):
+        super().__init__()
+        extra = cfg["MODEL"]["EXTRA"]
+        self._cfg_model = {"NUM_JOINTS": int(cfg["MODEL"]["NUM_JOINTS"]),
+                           "EXTRA": {k: (dict(extra[k]) if k.startswith("STAGE") else extra[k]) for k in extra}}
+        self.dtype_name = kwargs.get("dtype", "bf16")
+        self.conv1 = _conv(3, 64, 3, 2); self.bn1 = nn.BatchNorm2d(64, momentum=BN_MOMENTUM)
+        self.conv2 = _conv(64, 64, 3, 2); self.bn2 = nn.BatchNorm2d(64, momentum=BN_MOMENTUM)
+        self.layer1 = nn.Sequential(*[_bottleneck(64 if b == 0 else 256, 64, b == 0) for b in range(4)])
+        pre = [256]
+        for si, name in enumerate(("STAGE2", "STAGE3", "STAGE4")):
+            scfg = extra[name]
+            if str(scfg["BLOCK"]) != "BASIC":
+                raise ValueError("%s.BLOCK=%s: stage blocks other than BASIC are not supported" % (name, scfg["BLOCK"]))
+            cur = [int(c) for c in scfg["NUM_CHANNELS"]]
+            trans = []
+            for i in range(len(cur)):
+                if i < len(pre):
+                    trans.append(_cbn(pre[i], cur[i], 3, 1, relu=True) if cur[i] != pre[i] else None)
+                else:
+                    chain = []
+                    for j in range(i + 1 - len(pre)):
+                        cout = cur[i] if j == i - len(pre) else pre[-1]
+                        chain.append(_cbn(pre[-1], cout, 3, 2, relu=True))
+                    trans.append(nn.Sequential(*chain))
+            setattr(self, "transition%d" % (si + 1), nn.ModuleList(trans))
+            nm = int(scfg["NUM_MODULES"])
+            mods = [_hr_module(cur, [int(b) for b in scfg["NUM_BLOCKS"]], not (name == "STAGE4" and m == nm - 1)) for m in range(nm)]
+            setattr(self, "stage%d" % (si + 2), nn.Sequential(*mods))
+            pre = cur
+        fk = int(extra["FINAL_CONV_KERNEL"])
+        self.final_layer = _conv(pre[0], int(cfg["MODEL"]["NUM_JOINTS"]), fk, 1, bias=True)
+        self.pretrained_layers = extra["PRETRAINED_LAYERS"] if "PRETRAINED_LAYERS" in extra else ["*"]
+        self._engine = None
+        self._engine_version = None
+
+    # ---- engine lifetime: rebuilt whenever parameters may have changed ----
+    def _param_version(self):
+        return tuple((p.data_ptr(), p._version) for p in self.state_dict().values())
+
+    def _get_engine(self, device):
+        ver = self._param_version()
+        if self._engine is None or self._engine_version != ver or self._engine.device != device:
+            if self._engine is not None:
+                self._engine.close()
+            cfg = {"MODEL": self._cfg_model}
+            self._engine = ops.HrnetEngine(cfg, self.state_dict(), dtype=self.dtype_name, device=device)
+            self._engine_version = ver
+        return self._engine
+
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError("the MI355X pose_hrnet is inference-only: call .eval() (training is out of scope)")
+        if not x.is_cuda:
+            raise ops.nat.NativeError("pose_hrnet.forward needs a ROCm device tensor: there is no CPU fallback")
+        return self._get_engine(x.device)(x)
+
+    def init_weights(self, pretrained=""):
+        raise RuntimeError("init_weights: training-time initialisation is out of scope; load a checkpoint instead")
+
+
+def get_pose_net(cfg, is_train, **kwargs):
+    if is_train:
+        raise ValueError("get_pose_net(is_train=True): the MI355X build covers the inference path only")
+    return PoseHighResolutionNet(cfg, **kwargs)

@@ -218,8 +218,9 @@ class HrnetEngine:
         nat.check(nat.lib().scpose_hrnet_stats(self._h, h, w, ctypes.byref(l), ctypes.byref(f), ctypes.byref(by)), "hrnet_stats")
         return {"launches": l.value, "flops_per_frame": f.value, "act_bytes_per_frame": by.value}
 
-    def forward(self, x, out=None):
-        """x: float32 (N,3,H,W) normalised, or uint8 (N,H,W,3) raw RGB.  Returns f32 (N,J,H/4,W/4)."""
+    def forward(self, x, out=None, profile=False):
+        """x: float32 (N,3,H,W) normalised, or uint8 (N,H,W,3) raw RGB.  Returns f32 (N,J,H/4,W/4).
+        profile=True records a HIP event around every launch (read with profile_read())."""
         _need_cuda(x)
         x = x.contiguous()
         if x.dtype == torch.uint8:
@@ -236,9 +237,24 @@ class HrnetEngine:
             self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
         if out is None:
             out = torch.empty((n, self.num_joints, h // 4, w // 4), dtype=torch.float32, device=x.device)
-        nat.check(nat.lib().scpose_hrnet_forward(self._h, _ptr(x), fmt, n, h, w, _ptr(out), _ptr(self._ws),
-                                                 self._ws.numel(), _stream()), "hrnet_forward")
+        fn = nat.lib().scpose_hrnet_forward_profiled if profile else nat.lib().scpose_hrnet_forward
+        nat.check(fn(self._h, _ptr(x), fmt, n, h, w, _ptr(out), _ptr(self._ws), self._ws.numel(), _stream()), "hrnet_forward")
+        self._last_hw = (h, w)
         return out
+
+    def profile_read(self):
+        """Per-launch records of the last profiled forward: list of dicts
+        {ms, flops_per_frame, bytes_per_frame, kind, a, cin, cout}."""
+        cnt = c_int32()
+        nat.check(nat.lib().scpose_hrnet_profile_read(self._h, 0, 0, 0, None, None, None, None, ctypes.byref(cnt)), "profile_read")
+        k = cnt.value
+        ms = np.zeros(k, dtype=np.float32); fl = np.zeros(k); by = np.zeros(k); sig = np.zeros((k, 4), dtype=np.int32)
+        h, w = self._last_hw
+        nat.check(nat.lib().scpose_hrnet_profile_read(self._h, h, w, k, c_void_p(ms.ctypes.data), c_void_p(fl.ctypes.data),
+                                                      c_void_p(by.ctypes.data), c_void_p(sig.ctypes.data), ctypes.byref(cnt)),
+                  "profile_read")
+        return [{"ms": float(ms[i]), "flops_per_frame": float(fl[i]), "bytes_per_frame": float(by[i]),
+                 "kind": int(sig[i, 0]), "a": int(sig[i, 1]), "cin": int(sig[i, 2]), "cout": int(sig[i, 3])} for i in range(k)]
 
     __call__ = forward
 

@@ -1,0 +1,112 @@
+"""Seeded synthetic workloads for the benchmark and smoke run: model
+configs, a random-init checkpoint of the pose_hrnet architecture, and PnP keypoints made by
+projecting the 11 Tango landmarks through random poses.  Product-side data generation: no
+file under oracle/ is imported here.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+# Reference fixtures (data): object_detection/speed_plus_utils/landmarks.csv:2-12 and
+# calibration.json:1-24 of mohsij/spacecraft-pose-estimation.
+TANGO_LANDMARKS = np.array([
+    [0.36940446496009827, -0.3845726549625397, 0.16007566452026367],
+    [0.36786314845085144, 0.3836139440536499, 0.16053038835525513],
+    [-0.36881211400032043, 0.38277047872543335, 0.16048267483711243],
+    [-0.36801040172576904, -0.3831963539123535, 0.16058564186096191],
+    [0.36815810203552246, -0.26237574219703674, -0.16152474284172058],
+    [0.36859363317489624, 0.30254653096199036, -0.15993139147758484],
+    [-0.36717548966407776, 0.30379965901374817, -0.1599225401878357],
+    [-0.3663908839225769, -0.2586885094642639, -0.1586388796567917],
+    [0.30565211176872253, -0.5800656676292419, 0.08969831466674805],
+    [0.5425941348075867, 0.48880907893180847, 0.09245043992996216],
+    [-0.5449637770652771, 0.48740869760513306, 0.09220433235168457]], dtype=np.float64)
+SPEEDPLUS_K = np.array([[2988.5795163815555, 0, 960], [0, 2988.3401159176124, 600], [0, 0, 1]], dtype=np.float64)
+SPEEDPLUS_DIST = np.array([-0.22383016606510672, 0.51409797089106379, -0.00066499611998340662,
+                           -0.00021404771667484594, -0.13124227429077406], dtype=np.float64)
+
+
+def hrnet_cfg(width=48, num_joints=11, image=384, modules=(1, 4, 3)):
+    """Plain-dict cfg in the shape of the reference YAMLs (experiments/events/events-config.yaml
+    MODEL subtree): NUM_CHANNELS (w, 2w, 4w, 8w), 4 BASIC blocks per branch, NUM_MODULES 1/4/3."""
+    def stage(nb, nm):
+        return {"NUM_MODULES": nm, "NUM_BRANCHES": nb, "BLOCK": "BASIC", "NUM_BLOCKS": [4] * nb,
+                "NUM_CHANNELS": [width * (2 ** i) for i in range(nb)], "FUSE_METHOD": "SUM"}
+    return {"MODEL": {"NAME": "pose_hrnet", "NUM_JOINTS": num_joints, "INIT_WEIGHTS": False, "PRETRAINED": "",
+                      "IMAGE_SIZE": [image, image], "HEATMAP_SIZE": [image // 4, image // 4],
+                      "EXTRA": {"PRETRAINED_LAYERS": ["*"], "FINAL_CONV_KERNEL": 1, "STAGE2": stage(2, modules[0]),
+                                "STAGE3": stage(3, modules[1]), "STAGE4": stage(4, modules[2])}}}
+
+
+def random_checkpoint(cfg, seed=0):
+    """Random-init state_dict of the architecture: Conv2d default init (kaiming-uniform, a=sqrt 5 ==
+    U(+-1/sqrt(fan_in))), BN gamma,var ~ U[.75,1.25], beta,mean ~ N(0,.1^2) so activations stay O(1)
+    through ~300 layers.  Keys/shapes come from the module tree (== the reference's state_dict)."""
+    from .models.pose_hrnet import PoseHighResolutionNet
+    with torch.device("meta"):
+        spec = PoseHighResolutionNet(cfg).state_dict()
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+    for name, meta in spec.items():
+        shape = tuple(meta.shape)
+        leaf = name.rsplit(".", 1)[1]
+        if leaf == "num_batches_tracked":
+            sd[name] = torch.tensor(0, dtype=torch.long)
+        elif len(shape) == 4:
+            bound = (1.0 / (shape[1] * shape[2] * shape[3])) ** 0.5
+            sd[name] = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        elif name == "final_layer.bias":
+            sd[name] = (torch.rand(shape, generator=g) * 2 - 1) * 0.05
+        elif leaf in ("weight", "running_var"):
+            sd[name] = 0.75 + 0.5 * torch.rand(shape, generator=g)
+        else:
+            sd[name] = 0.1 * torch.randn(shape, generator=g)
+    return sd
+
+
+def project(R, t, X, K=SPEEDPLUS_K, dist=SPEEDPLUS_DIST):
+    """Pinhole + (k1,k2,p1,p2,k3) projection, the model of the reference's project()
+    (pose_estimation/export_predicted_poses_real.py:104-121)."""
+    pc = X @ R.T + t
+    x0, y0 = pc[:, 0] / pc[:, 2], pc[:, 1] / pc[:, 2]
+    r2 = x0 * x0 + y0 * y0
+    cd = 1 + dist[0] * r2 + dist[1] * r2 * r2 + dist[4] * r2 * r2 * r2
+    x1 = x0 * cd + dist[2] * 2 * x0 * y0 + dist[3] * (r2 + 2 * x0 * x0)
+    y1 = y0 * cd + dist[2] * (r2 + 2 * y0 * y0) + dist[3] * 2 * x0 * y0
+    return np.stack([K[0, 0] * x1 + K[0, 2], K[1, 1] * y1 + K[1, 2]], 1)
+
+
+def random_rotation(rng):
+    axis = rng.standard_normal(3)
+    axis /= np.linalg.norm(axis)
+    ang = rng.uniform(-np.pi, np.pi)
+    kx = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(ang) * kx + (1 - np.cos(ang)) * kx @ kx
+
+
+def keypoints(n, rng, noise_px=1.0, outlier_frac=0.0, landmarks=TANGO_LANDMARKS, K=SPEEDPLUS_K, dist=SPEEDPLUS_DIST,
+              width=1920, height=1200):
+    """(n, J, 3) float32 [u, v, conf=1] + ground-truth (R, t): |t| in [3,10] m, target in frame,
+    N(0, noise) px jitter, a fraction of landmarks replaced by uniform image points."""
+    j = len(landmarks)
+    kp = np.zeros((n, j, 3), dtype=np.float32)
+    rs = np.zeros((n, 3, 3)); ts = np.zeros((n, 3))
+    for i in range(n):
+        while True:
+            r = random_rotation(rng)
+            z = rng.uniform(3.0, 10.0)
+            t = np.array([rng.uniform(-0.25, 0.25) * z, rng.uniform(-0.15, 0.15) * z, z])
+            uv = project(r, t, landmarks, K, dist)
+            if (uv[:, 0] > 0).all() and (uv[:, 0] < width).all() and (uv[:, 1] > 0).all() and (uv[:, 1] < height).all():
+                break
+        uv = uv + rng.standard_normal(uv.shape) * noise_px
+        nout = int(round(outlier_frac * j))
+        if nout:
+            idx = rng.choice(j, nout, replace=False)
+            uv[idx, 0] = rng.uniform(0, width, nout)
+            uv[idx, 1] = rng.uniform(0, height, nout)
+        kp[i, :, :2] = uv
+        kp[i, :, 2] = 1.0
+        rs[i], ts[i] = r, t
+    return kp, rs, ts
