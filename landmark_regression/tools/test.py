@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Drop-in for the reference's landmark_regression/tools/test.py (:35-130), on the MI355X HIP path.
+
+    cd landmark_regression
+    python tools/test.py --cfg experiments/events/events-config.yaml KEY VAL ...
+
+Same arguments (--cfg, --modelDir, --logDir, --dataDir, --prevModelDir, trailing yacs KEY VAL
+overrides), same inputs (<DATASET.ROOT>/<TEST_SET>.json COCO dict, images under DATA_DIR,
+TEST.MODEL_FILE state_dict) and same output
+(<OUTPUT_DIR>/<DATASET>/<MODEL.NAME>/<cfg basename>/pred_test.mat with 'preds' N x J x 3), so
+evaluate_pipeline.py:69-79 can spawn it unchanged.  Multi-GPU: launch with
+`python -m torch.distributed.run --nproc-per-node N tools/test.py ...` (one process per GPU,
+frames sharded, results all-gathered) instead of cfg.GPUS + DataParallel (:98).
+"""
+import argparse
+import os
+import pprint
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.utils.data  # noqa: E402
+
+import scpose  # noqa: E402,F401  (alias of ./spacecraft-pose-estimation_amd)
+from importlib import import_module  # noqa: E402
+
+_P = "spacecraft-pose-estimation_amd"
+config_mod = import_module(_P + ".config")
+models = import_module(_P + ".models")
+dataset = import_module(_P + ".dataset")
+parallel = import_module(_P + ".parallel")
+from_utils = import_module(_P + ".utils.utils")
+transforms = import_module(_P + ".utils.transforms")
+JointsMSELoss = import_module(_P + ".core.loss").JointsMSELoss
+validate = import_module(_P + ".core.function").validate
+cfg, update_config = config_mod.cfg, config_mod.update_config
+
+
+def parse_args():
+    parser = argparse.ArgumentParser(description="Train keypoints network")
+    parser.add_argument("--cfg", help="experiment configure file name", required=True, type=str)
+    parser.add_argument("opts", help="Modify config options using the command-line", default=None, nargs=argparse.REMAINDER)
+    parser.add_argument("--modelDir", help="model directory", type=str, default="")
+    parser.add_argument("--logDir", help="log directory", type=str, default="")
+    parser.add_argument("--dataDir", help="data directory", type=str, default="")
+    parser.add_argument("--prevModelDir", help="prev Model directory", type=str, default="")
+    return parser.parse_args()
+
+
+def main():
+    args = parse_args()
+    update_config(cfg, args)
+    logger, final_output_dir, tb_log_dir = from_utils.create_logger(cfg, args.cfg, "valid")
+    logger.info(pprint.pformat(args))
+    logger.info(cfg)
+
+    ws, rank, local = parallel.world()
+    if not torch.cuda.is_available():
+        raise SystemExit("tools/test.py: no ROCm device visible; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local if ws > 1 else int(cfg.GPUS[0]))
+
+    model = getattr(models, cfg.MODEL.NAME).get_pose_net(cfg, is_train=False)
+    if cfg.TEST.MODEL_FILE:
+        logger.info("=> loading model from {}".format(cfg.TEST.MODEL_FILE))
+        model.load_state_dict(torch.load(cfg.TEST.MODEL_FILE, map_location="cpu"), strict=False)
+    else:
+        model_state_file = os.path.join(final_output_dir, "final_state.pth")
+        logger.info("=> loading model from {}".format(model_state_file))
+        model.load_state_dict(torch.load(model_state_file, map_location="cpu"))
+    model = model.cuda().eval()
+
+    criterion = JointsMSELoss(use_target_weight=cfg.LOSS.USE_TARGET_WEIGHT).cuda()
+    normalize = transforms.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])
+    valid_dataset = getattr(dataset, cfg.DATASET.DATASET)(
+        cfg, cfg.DATASET.ROOT, cfg.DATA_DIR, cfg.DATASET.TEST_SET, False,
+        transforms.Compose([transforms.ToTensor(), normalize]))
+    lo, hi = parallel.shard_range(len(valid_dataset), rank, ws)
+    subset = torch.utils.data.Subset(valid_dataset, range(lo, hi)) if ws > 1 else valid_dataset
+    valid_loader = torch.utils.data.DataLoader(subset, batch_size=cfg.TEST.BATCH_SIZE_PER_GPU * len(cfg.GPUS),
+                                               shuffle=False, num_workers=cfg.WORKERS, pin_memory=True)
+    validate(cfg, valid_loader, valid_dataset, model, criterion, final_output_dir, tb_log_dir, pred_file_name="pred_test")
+
+
+if __name__ == "__main__":
+    main()

@@ -83,6 +83,9 @@ def lib():
         raise NativeError(
             "%s not found: the HIP extension is not built. Run `python -c \"import __graft_entry__ as g; "
             "g.build()\"` (or `make -C %s`). There is no CPU fallback." % (LIB_PATH, os.path.join(_HERE, "csrc")))
+    # PyTorch-ROCm ships its own libamdhip64; load it FIRST so that this library binds to the
+    # same HIP runtime (two runtimes in one process do not see each other's device state).
+    import torch  # noqa: F401
     try:
         handle = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # e.g. libamdhip64 missing

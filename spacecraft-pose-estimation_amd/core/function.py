@@ -1,0 +1,110 @@
+"""validate(): the evaluation loop of landmark_regression/lib/core/function.py:318-459 on the HIP path.
+
+Same signature and outputs (all_preds (N,J,3) f32 [x_img,y_img,maxval], all_boxes (N,6),
+dataset.evaluate -> <pred_file_name>.mat).  Differences in HOW, not WHAT:
+  * the forward is the HIP engine; heatmaps never leave the device -- decode runs there
+    (the reference copies the full heatmap tensor to the host twice per batch, :376/:390);
+  * with WORLD_SIZE > 1 every rank evaluates its contiguous shard of the dataset and the
+    (N,J,3)/(N,6) rows are all-gathered (parallel.py) -- replaces DataParallel;
+  * loss / PCK are logged like the reference (they do not affect any output).
+"""
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+
+from .. import parallel
+from ..utils.transforms import flip_back
+from .evaluate import accuracy
+from .inference import get_final_preds_device
+
+logger = logging.getLogger(__name__)
+
+
+class AverageMeter(object):
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count if self.count != 0 else 0
+
+
+def _print_name_value(name_value, full_arch_name):
+    names = name_value.keys()
+    values = name_value.values()
+    num_values = len(name_value)
+    logger.info("| Arch " + " ".join(["| {}".format(name) for name in names]) + " |")
+    logger.info("|---" * (num_values + 1) + "|")
+    if len(full_arch_name) > 15:
+        full_arch_name = full_arch_name[:8] + "..."
+    logger.info("| " + full_arch_name + " " + " ".join(["| {:.3f}".format(value) for value in values]) + " |")
+
+
+def validate(config, val_loader, val_dataset, model, criterion, output_dir, tb_log_dir, pred_file_name="pred",
+             writer_dict=None, log_metrics=True):
+    batch_time, losses, acc = AverageMeter(), AverageMeter(), AverageMeter()
+    model.eval()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    dist = parallel.init() if parallel.world()[0] > 1 else None
+    num_samples = len(val_dataset)
+    local_preds, local_boxes, image_path = [], [], []
+    with torch.no_grad():
+        end = time.time()
+        for i, (input, target, target_weight, meta) in enumerate(val_loader):
+            input = input.to(dev, non_blocking=True)
+            outputs = model(input)
+            output = outputs[-1] if isinstance(outputs, list) else outputs
+            if config.TEST.FLIP_TEST:
+                out_f = model(input.flip(3))
+                out_f = out_f[-1] if isinstance(out_f, list) else out_f
+                out_f = torch.from_numpy(flip_back(out_f.cpu().numpy(), val_dataset.flip_pairs).copy()).to(dev)
+                if config.TEST.SHIFT_HEATMAP:
+                    out_f[:, :, :, 1:] = out_f.clone()[:, :, :, 0:-1]
+                output = (output + out_f) * 0.5
+            num_images = input.size(0)
+            if log_metrics and criterion is not None:
+                target_d = target.to(dev, non_blocking=True)
+                loss = criterion(output, target_d, target_weight.to(dev, non_blocking=True))
+                losses.update(loss.item(), num_images)
+                _, avg_acc, cnt, _ = accuracy(output.cpu().numpy(), target.numpy())
+                acc.update(avg_acc, cnt)
+            c = meta["center"].float()
+            s = meta["scale"].float()
+            score = meta["score"].double() if torch.is_tensor(meta["score"]) else torch.tensor(meta["score"]).double()
+            xyc = get_final_preds_device(config, output, c.to(dev), s.to(dev))
+            local_preds.append(xyc)
+            boxes = torch.zeros((num_images, 6), dtype=torch.float64)
+            boxes[:, 0:2] = c[:, 0:2].double(); boxes[:, 2:4] = s[:, 0:2].double()
+            boxes[:, 4] = torch.prod(s.double() * 200, 1); boxes[:, 5] = score
+            local_boxes.append(boxes)
+            image_path.extend(meta["image"])
+            batch_time.update(time.time() - end)
+            end = time.time()
+            if i % config.PRINT_FREQ == 0:
+                logger.info("Test: [{0}/{1}]\tTime {bt.val:.3f} ({bt.avg:.3f})\tLoss {loss.val:.4f} ({loss.avg:.4f})\t"
+                            "Accuracy {acc.val:.3f} ({acc.avg:.3f})".format(i, len(val_loader), bt=batch_time, loss=losses, acc=acc))
+        preds_d = torch.cat(local_preds, 0) if local_preds else torch.zeros((0, config.MODEL.NUM_JOINTS, 3), device=dev)
+        boxes_d = (torch.cat(local_boxes, 0) if local_boxes else torch.zeros((0, 6), dtype=torch.float64)).to(dev)
+        if dist is not None:
+            preds_d = parallel.gather_rows(preds_d, num_samples, dist)
+            boxes_d = parallel.gather_rows(boxes_d, num_samples, dist)
+        all_preds = np.zeros((num_samples, config.MODEL.NUM_JOINTS, 3), dtype=np.float32)
+        all_boxes = np.zeros((num_samples, 6))
+        all_preds[: preds_d.shape[0]] = preds_d.cpu().numpy()
+        all_boxes[: boxes_d.shape[0]] = boxes_d.cpu().numpy()
+        name_values, perf_indicator = {"Null": 0}, 0
+        if parallel.world()[1] == 0:
+            name_values, perf_indicator = val_dataset.evaluate(config, all_preds, output_dir, pred_file_name, all_boxes,
+                                                               image_path, [], [])
+            model_name = config.MODEL.NAME
+            for nv in (name_values if isinstance(name_values, list) else [name_values]):
+                _print_name_value(nv, model_name)
+    return perf_indicator

@@ -1,0 +1,127 @@
+"""Inference-side JointsDataset (landmark_regression/lib/dataset/JointsDataset.py:27-229, :264-332).
+
+__getitem__ returns the reference's tuple (input, target, target_weight, meta) for is_train=False:
+image read -> optional BGR/RGB handling -> get_affine_transform(c, s, 0, IMAGE_SIZE) -> bilinear
+warp to the crop -> transform (ToTensor + Normalize) -> gaussian target.  Training-time
+augmentation (flip / scale / rotation / half-body, :158-177) is out of scope and rejected.
+Image decoding uses PIL (cv2 is not available on this image); the crop warp is a NumPy
+restatement of cv2.warpAffine(INTER_LINEAR) (utils/transforms.py) -- SURVEY.md section 8(f) rank 1
+lists the GPU crop kernel as the next component.
+"""
+import copy
+import logging
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from ..utils.transforms import affine_transform, get_affine_transform, warp_affine_bilinear
+
+logger = logging.getLogger(__name__)
+
+
+def _imread_bgr(path):
+    """cv2.imread(path, IMREAD_COLOR | IMREAD_IGNORE_ORIENTATION): HxWx3 uint8 in BGR order, or None."""
+    try:
+        from PIL import Image
+        with Image.open(path) as im:
+            rgb = np.asarray(im.convert("RGB"))
+        return rgb[:, :, ::-1].copy()
+    except Exception:
+        return None
+
+
+class JointsDataset(Dataset):
+    def __init__(self, cfg, root, image_set, is_train, transform=None, numpy_transform=None, multi_scale_target=False):
+        if is_train:
+            raise ValueError("JointsDataset(is_train=True): training augmentation is out of scope of this build")
+        self.num_joints = 0
+        self.pixel_std = 200
+        self.flip_pairs = []
+        self.parent_ids = []
+        self.is_train = is_train
+        self.root = root
+        self.image_set = image_set
+        self.output_path = cfg.OUTPUT_DIR
+        self.data_format = cfg.DATASET.DATA_FORMAT
+        self.color_rgb = cfg.DATASET.COLOR_RGB
+        self.target_type = cfg.MODEL.TARGET_TYPE
+        self.image_size = np.array(cfg.MODEL.IMAGE_SIZE)
+        self.heatmap_size = np.array(cfg.MODEL.HEATMAP_SIZE)
+        self.sigma = cfg.MODEL.SIGMA
+        self.use_different_joints_weight = cfg.LOSS.USE_DIFFERENT_JOINTS_WEIGHT
+        self.joints_weight = 1
+        self.transform = transform
+        self.numpy_transform = numpy_transform
+        self.db = []
+
+    def _get_db(self):
+        raise NotImplementedError
+
+    def evaluate(self, cfg, preds, output_dir, pred_file_name, *args, **kwargs):
+        raise NotImplementedError
+
+    def __len__(self):
+        return len(self.db)
+
+    def __getitem__(self, idx):
+        db_rec = copy.deepcopy(self.db[idx])
+        image_file = db_rec["image"]
+        if self.data_format == "zip":
+            raise ValueError("DATA_FORMAT 'zip' is not supported (unused by the shipped configs)")
+        data_numpy = _imread_bgr(image_file)
+        if data_numpy is None:
+            logger.error("=> fail to read {}".format(image_file))
+            raise ValueError("Fail to read {}".format(image_file))
+        if self.color_rgb:
+            data_numpy = data_numpy[:, :, ::-1]
+        joints = db_rec["joints_3d"]
+        joints_vis = db_rec["joints_3d_vis"]
+        c, s = db_rec["center"], db_rec["scale"]
+        score = db_rec["score"] if "score" in db_rec else 1
+        r = 0
+        if self.numpy_transform:
+            data_numpy = self.numpy_transform(data_numpy)
+        trans = get_affine_transform(c, s, r, self.image_size)
+        input = warp_affine_bilinear(np.ascontiguousarray(data_numpy), trans, (int(self.image_size[0]), int(self.image_size[1])))
+        if self.transform:
+            input = self.transform(input)
+        for i in range(self.num_joints):
+            if joints_vis[i, 0] > 0.0:
+                joints[i, 0:2] = affine_transform(joints[i, 0:2], trans)
+        target, target_weight = self.generate_target(joints, joints_vis)
+        meta = {"image": image_file, "filename": db_rec.get("filename", ""), "imgnum": db_rec.get("imgnum", ""),
+                "joints": joints, "joints_vis": joints_vis, "center": c, "scale": s, "rotation": r, "score": score}
+        return input, torch.from_numpy(target), torch.from_numpy(target_weight), meta
+
+    def generate_target(self, joints, joints_vis):
+        """Gaussian heatmaps, peak 1.0 at the integer centre (JointsDataset.py:264-332)."""
+        target_weight = np.ones((self.num_joints, 1), dtype=np.float32)
+        target_weight[:, 0] = joints_vis[:, 0]
+        assert self.target_type == "gaussian", "Only support gaussian map now!"
+        hw, hh = int(self.heatmap_size[0]), int(self.heatmap_size[1])
+        target = np.zeros((self.num_joints, hh, hw), dtype=np.float32)
+        tmp_size = self.sigma * 3
+        size = 2 * tmp_size + 1
+        x = np.arange(0, size, 1, np.float32)
+        y = x[:, np.newaxis]
+        x0 = y0 = size // 2
+        g = np.exp(-((x - x0) ** 2 + (y - y0) ** 2) / (2 * self.sigma ** 2))
+        feat_stride = self.image_size / self.heatmap_size
+        for j in range(self.num_joints):
+            mu_x = int(joints[j][0] / feat_stride[0] + 0.5)
+            mu_y = int(joints[j][1] / feat_stride[1] + 0.5)
+            ul = [int(mu_x - tmp_size), int(mu_y - tmp_size)]
+            br = [int(mu_x + tmp_size + 1), int(mu_y + tmp_size + 1)]
+            if ul[0] >= hw or ul[1] >= hh or br[0] < 0 or br[1] < 0:
+                target_weight[j] = 0
+                continue
+            g_x = max(0, -ul[0]), min(br[0], hw) - ul[0]
+            g_y = max(0, -ul[1]), min(br[1], hh) - ul[1]
+            img_x = max(0, ul[0]), min(br[0], hw)
+            img_y = max(0, ul[1]), min(br[1], hh)
+            if target_weight[j] > 0.5:
+                target[j][img_y[0]:img_y[1], img_x[0]:img_x[1]] = g[g_y[0]:g_y[1], g_x[0]:g_x[1]]
+        if self.use_different_joints_weight:
+            target_weight = np.multiply(target_weight, self.joints_weight)
+        return target, target_weight

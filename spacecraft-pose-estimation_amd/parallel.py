@@ -1,0 +1,57 @@
+"""One process per GPU, frames sharded by index, one all-gather of the results.
+
+Replaces torch.nn.DataParallel(model, device_ids=cfg.GPUS) of
+landmark_regression/tools/test.py:98 (single process; per-forward parameter broadcast, input
+scatter, heatmap gather).  Here every rank keeps its own resident weights and owns the
+contiguous slice [r*N/R, (r+1)*N/R) of the frame list (annotations[] order is preserved by
+concatenation); the only exchange is an all-gather of small per-frame result rows
+(RCCL over xGMI on GPUs, gloo in the CPU tests).  SURVEY.md section 8(e).
+"""
+import os
+
+import torch
+
+
+def world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+    ws, rank, local = world()
+    if ws == 1:
+        return None
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend, rank=rank, world_size=ws)
+    return dist
+
+
+def shard_range(n, rank, world_size):
+    """Contiguous, order-preserving, balanced split of range(n): first n % R ranks get one extra."""
+    base, rem = divmod(n, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_rows(local, n_total, dist=None):
+    """All-gather ragged row blocks (rank r holds rows shard_range(n_total, r, R)) into the full
+    (n_total, ...) tensor on every rank, in frame order.  One collective: blocks are padded to
+    the largest shard so a single all_gather_into_tensor suffices."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    ws, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [shard_range(n_total, r, ws) for r in range(ws)]
+    maxrows = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((maxrows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((ws * maxrows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad)
+    parts = [out[r * maxrows: r * maxrows + (hi - lo)] for r, (lo, hi) in enumerate(sizes)]
+    return torch.cat(parts, 0)

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/ by IMPORTING THE REFERENCE in the build
+container (it never ships; /root/reference does not exist on the GPU box):
+
+  * lib/models/pose_hrnet.py  -- imported as-is (needs only torch); the reference module is built
+    from a plain-dict cfg, loaded (strict=True) with the seeded synthetic checkpoint, and run in
+    fp32 on seeded inputs.  Vectors: inputs are regenerated from seeds, expected heatmaps stored.
+  * lib/core/inference.py     -- imported under a stub `cv2` module whose getAffineTransform is the
+    6x6 solve OpenCV performs (cv2 itself is a third-party wheel absent from the image); covers
+    get_max_preds and get_final_preds with POST_PROCESS on and off.
+
+Only data is written (npz): no reference source text.  Re-run: python tests/golden/make_golden.py
+"""
+import importlib
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/landmark_regression"
+sys.path.insert(0, ROOT)
+
+from oracle import hrnet_ref as R  # noqa: E402  (only for the seeded checkpoint/input recipe)
+
+
+def ref_pose_hrnet():
+    spec = importlib.util.spec_from_file_location("ref_pose_hrnet", os.path.join(REF, "lib/models/pose_hrnet.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def hrnet_vectors():
+    m = ref_pose_hrnet()
+    cases = {"tiny64": (R.tiny_cfg(), 64, 2, 1, 2), "w32_64": (R.w32_cfg(), 64, 2, 3, 4), "w48_96": (R.w48_cfg(), 96, 1, 5, 6)}
+    out = {}
+    for name, (cfg, size, n, wseed, xseed) in cases.items():
+        net = m.get_pose_net(cfg, False).eval()
+        sd = R.make_state_dict(cfg, seed=wseed)
+        net.load_state_dict(sd, strict=True)
+        x = torch.randn(n, 3, size, size, generator=torch.Generator().manual_seed(xseed))
+        feats = {}
+        hooks = [net.layer1.register_forward_hook(lambda mod, i, o: feats.__setitem__("layer1", o)),
+                 net.stage2.register_forward_hook(lambda mod, i, o: feats.__setitem__("stage2", o)),
+                 net.stage3.register_forward_hook(lambda mod, i, o: feats.__setitem__("stage3", o))]
+        with torch.no_grad():
+            y = net(x)
+        for h in hooks:
+            h.remove()
+        out[name + "/heatmaps"] = y.numpy()
+        out[name + "/meta"] = np.array([size, n, wseed, xseed], dtype=np.int64)
+        # a few intermediate statistics pin the inner structure without storing big tensors
+        out[name + "/layer1_stats"] = np.array([feats["layer1"].mean().item(), feats["layer1"].std().item()])
+        out[name + "/stage2_b1_stats"] = np.array([feats["stage2"][1].mean().item(), feats["stage2"][1].std().item()])
+        out[name + "/stage3_b2_stats"] = np.array([feats["stage3"][2].mean().item(), feats["stage3"][2].std().item()])
+        out[name + "/num_keys"] = np.array([len(sd)], dtype=np.int64)
+        print(name, tuple(y.shape), float(y.std()))
+    np.savez_compressed(os.path.join(HERE, "hrnet_reference_outputs.npz"), **out)
+
+
+def decode_vectors():
+    cv2 = types.ModuleType("cv2")
+
+    def getAffineTransform(src, dst):
+        src = np.asarray(src, np.float32); dst = np.asarray(dst, np.float32)
+        a = np.zeros((6, 6)); b = np.zeros(6)
+        for i in range(3):
+            a[2 * i, 0:3] = (src[i, 0], src[i, 1], 1.0); a[2 * i + 1, 3:6] = (src[i, 0], src[i, 1], 1.0)
+            b[2 * i], b[2 * i + 1] = dst[i, 0], dst[i, 1]
+        return np.linalg.solve(a, b).reshape(2, 3)
+    cv2.getAffineTransform = getAffineTransform
+    sys.modules["cv2"] = cv2
+    sys.path.insert(0, os.path.join(REF, "lib"))
+    inf = importlib.import_module("core.inference")
+
+    class Node:
+        pass
+    rng = np.random.default_rng(42)
+    hm = rng.standard_normal((5, 11, 24, 32)).astype(np.float32)
+    hm[0, 0] = -1.0                       # non-positive map -> coords masked to 0
+    hm[0, 1] = 0.25                       # all equal -> first index
+    hm[0, 2, 0, 0] = 9.0                  # corner peak: no quarter-pixel shift
+    hm[0, 3, 1, 5] = 9.0                  # py == 1: strict inequality
+    hm[0, 4, 10, 30] = 9.0; hm[0, 4, 10, 31] = 8.0    # px == W-2
+    hm[0, 5, 12, 12] = 9.0; hm[0, 5, 12, 11] = hm[0, 5, 12, 13] = 3.0   # sign(0)
+    center = (rng.random((5, 2)) * 1500 + 100).astype(np.float32)
+    scale = (rng.random((5, 2)) * 2.5 + 0.4).astype(np.float32)
+    out = {"heatmaps": hm, "center": center, "scale": scale}
+    for pp in (True, False):
+        cfg = Node(); cfg.TEST = Node(); cfg.TEST.POST_PROCESS = pp
+        preds, maxvals = inf.get_final_preds(cfg, hm.copy(), center, scale)
+        out["preds_pp%d" % pp] = preds
+        out["maxvals_pp%d" % pp] = maxvals
+    coords, mv = inf.get_max_preds(hm.copy())
+    out["max_coords"] = coords; out["max_vals"] = mv
+    np.savez_compressed(os.path.join(HERE, "decode_reference_outputs.npz"), **out)
+    print("decode vectors", hm.shape)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    hrnet_vectors()
+    decode_vectors()

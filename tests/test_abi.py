@@ -1,0 +1,77 @@
+"""The C-ABI shared library loads on a machine without a GPU and exports exactly the entry
+points include/scpose.h declares (no compute calls here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def nat(scpose):
+    from importlib import import_module
+    n = import_module("spacecraft-pose-estimation_amd._native")
+    if not os.path.exists(n.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return n
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "scpose.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(scpose_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree(nat):
+    assert _declared() == sorted(nat.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(nat):
+    lib = nat.lib()
+    for name in _declared():
+        assert hasattr(lib, name), name
+    assert lib.scpose_abi_version() == nat.ABI_VERSION == 1
+
+
+def test_signatures_have_no_torch_types():
+    text = open(os.path.join(ROOT, "include", "scpose.h")).read()
+    assert "torch" not in text.lower().replace("pytorch", "") and "at::" not in text and "std::" not in text
+    assert 'extern "C"' in text
+
+
+def test_argument_errors_without_a_device(nat):
+    """Pure argument validation is reachable without a GPU and reports through scpose_last_error."""
+    import ctypes
+    lib = nat.lib()
+    assert lib.scpose_hrnet_destroy(None) == 0 and lib.scpose_conv_destroy(None) == 0
+    h = ctypes.c_void_p()
+    rc = lib.scpose_hrnet_create(None, None, None, None, 0, 0, ctypes.byref(h))
+    assert rc == -1 and b"null" in lib.scpose_last_error()
+    d = nat.HrnetDesc()
+    d.num_stages = 2
+    rc = lib.scpose_hrnet_create(ctypes.byref(d), None, None, None, 0, 0, ctypes.byref(h))
+    assert rc == -1 and b"num_stages" in lib.scpose_last_error()
+    rc = lib.scpose_decode(None, 4, 11, 8, 8, None, None, 1, None, None)
+    assert rc == -1
+    assert lib.scpose_decode(None, 0, 11, 8, 8, None, None, 1, None, None) == 0     # empty batch is a no-op
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing in the package, the CLIs or the measured part of
+    bench.py may import it (bench.py's cpu_baseline leg is the one allowed user)."""
+    pat = re.compile(r"^\s*(from\s+oracle|import\s+oracle)|import_module\(\s*[\"']oracle|oracle/_ref|libpnp_ref", re.M)
+    offenders = []
+    for base in ("spacecraft-pose-estimation_amd", "landmark_regression", "pose_estimation"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".h")):
+                    p = os.path.join(dp, f)
+                    if pat.search(open(p).read()):
+                        offenders.append(p)
+    assert offenders == []
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    hits = [m.start() for m in pat.finditer(src)]
+    start = src.index("def cpu_baseline"); end = src.index("def main")
+    assert hits and all(start < h < end for h in hits)

@@ -1,0 +1,76 @@
+"""Known-answer tests of the C restatement of OpenCV's EPnP+RANSAC (oracle/pnp_ref.c).
+cv2 is absent from this image and from /root/reference (parity UNPINNED, see the file header):
+these tests anchor the restatement on analytic facts instead -- exact projections recover the
+generating pose, Rodrigues is an involution, undistortion inverts the distortion model, the
+RNG follows the published MWC recurrence, RANSAC rejects gross outliers."""
+import numpy as np
+import pytest
+
+from oracle import pnp_ref as P
+
+
+def test_rng_follows_opencv_mwc_recurrence():
+    state = (1 << 64) - 1
+    want = []
+    for _ in range(12):
+        state = ((state & 0xFFFFFFFF) * 4164903690 + (state >> 32)) & ((1 << 64) - 1)
+        want.append((state & 0xFFFFFFFF) % 11)
+    assert list(P.rng_draws(11, 12)) == want
+
+
+def test_rodrigues_roundtrip_and_special_cases():
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        R = P.random_rotation(rng)
+        rv = P.rodrigues(R)
+        assert np.abs(P.rodrigues(rv) - R).max() < 1e-12
+        assert abs(np.linalg.norm(rv) - P.rot_angle(R, np.eye(3))) < 1e-7
+    assert np.array_equal(P.rodrigues(np.zeros(3)), np.eye(3))
+    Rpi = np.diag([1.0, -1.0, -1.0])                       # theta = pi about x: the s < 1e-5 branch
+    assert np.abs(P.rodrigues(P.rodrigues(Rpi)) - Rpi).max() < 1e-12
+
+
+def test_projection_and_undistortion_are_inverse():
+    rng = np.random.default_rng(1)
+    R = P.random_rotation(rng, 40)
+    t = np.array([0.3, -0.2, 5.0])
+    uv = P.project(R, t)
+    assert np.abs(uv - P.project_numpy(R, t, P.LANDMARKS)).max() < 1e-9
+    pc = P.LANDMARKS @ R.T + t
+    assert np.abs(P.undistort(uv) - pc[:, :2] / pc[:, 2:]).max() < 1e-9
+
+
+@pytest.mark.parametrize("npts", [5, 6, 11])
+def test_epnp_recovers_exact_pose(npts):
+    rng = np.random.default_rng(npts)
+    for _ in range(20):
+        R = P.random_rotation(rng)
+        t = np.array([rng.uniform(-1, 1), rng.uniform(-0.6, 0.6), rng.uniform(3, 10)])
+        obj = P.LANDMARKS[:npts]
+        rv, tv = P.epnp(obj, P.project_numpy(R, t, obj))
+        assert P.rot_angle(P.rodrigues(rv), R) < 1e-6
+        assert np.linalg.norm(tv - t) / np.linalg.norm(t) < 1e-6
+
+
+def test_ransac_clean_noisy_and_outliers():
+    rng = np.random.default_rng(7)
+    kp, Rs, ts = P.synth_keypoints(64, rng, 0.0, 0.0)
+    o = P.solve_batch(kp)
+    assert (o["status"] == 11).all() and (o["iters"] == 1).all()       # all-inlier model -> niters becomes 0
+    assert P.rot_angle(o["R"], Rs).max() < 5e-6                          # float32 keypoints limit this
+    kp, Rs, ts = P.synth_keypoints(64, rng, 1.0, 0.3)                    # 3 of 11 landmarks replaced
+    o = P.solve_batch(kp)
+    assert (o["status"] >= 8).all()
+    assert np.median(P.rot_angle(o["R"], Rs)) < 2e-2
+    assert (o["iters"] < 200).all()
+
+
+def test_confidence_threshold_loop():
+    rng = np.random.default_rng(3)
+    kp, _, _ = P.synth_keypoints(4, rng, 0.5, 0.0)
+    kp[0, :, 2] = 0.0                  # J = 11 < 15: loop runs 100 times, threshold 0.95*0.8^100 = 1.9e-10
+    kp[1, 5:, 2] = 1e-11               # below the final threshold -> 5 points: direct EPnP
+    kp[2, :, 2] = 1e-9                 # above it: all 11 kept
+    o = P.solve_batch(kp)
+    assert list(o["status"][:3]) == [-1, 5, 11]
+    assert abs(0.95 * 0.8 ** 100 - 1.935e-10) < 1e-12
