@@ -3,7 +3,7 @@ signatures, validate(), and the two CLIs on a synthetic scene -- compared with t
 
 Keypoint parity on random-init networks is MARGIN-GATED: random heatmaps are
 not peaked, so bf16 noise may legitimately move an argmax whose runner-up is within the noise.
-For every joint whose oracle top-1/top-2 margin exceeds 6x the measured heatmap deviation the
+For every joint whose argmax margin and quarter-pixel sign tests exceed twice the measured heatmap deviation the
 decoded keypoint must agree within 0.5 px (BASELINE.json north_star)."""
 import json
 import os
@@ -82,10 +82,19 @@ def test_margin_gated_keypoint_parity_w32(pk):
     c = torch.full((8, 2), 700.0); s = torch.full((8, 2), 1.3)
     kp_gpu = pk.ops.decode(hm_gpu, c.cuda(), s.cuda(), True).cpu().numpy()
     kp_ref = D.decode_xyc(True, hm_ref.numpy(), c.numpy(), s.numpy())
-    dev = (hm_gpu.cpu() - hm_ref).abs().flatten(2).amax(2)                        # (N,J) max deviation per map
-    top2 = hm_ref.flatten(2).topk(2, dim=2).values
-    # runner-up outside the 3x3 neighbourhood of the peak would be the honest margin; top-2 is stricter
-    stable = ((top2[:, :, 0] - top2[:, :, 1]) > 6 * dev).numpy()
+    dev = (hm_gpu.cpu() - hm_ref).abs().flatten(2).amax(2).numpy()               # (N,J) max |bf16 deviation| per map
+    top2 = hm_ref.flatten(2).topk(2, dim=2).values.numpy()
+    # A decoded keypoint is PROVABLY unaffected by a perturbation bounded by dev when the argmax
+    # margin and the two quarter-pixel sign tests (inference.py:62-69) each exceed 2*dev.
+    hr = hm_ref.numpy()
+    stable = (top2[:, :, 0] - top2[:, :, 1]) > 2 * dev
+    for n in range(hr.shape[0]):
+        for j in range(hr.shape[1]):
+            py, px = np.unravel_index(hr[n, j].argmax(), hr[n, j].shape)
+            if 1 < px < hr.shape[3] - 1 and 1 < py < hr.shape[2] - 1:
+                dx = hr[n, j, py, px + 1] - hr[n, j, py, px - 1]
+                dy = hr[n, j, py + 1, px] - hr[n, j, py - 1, px]
+                stable[n, j] &= abs(dx) > 2 * dev[n, j] and abs(dy) > 2 * dev[n, j]
     err = np.linalg.norm(kp_gpu[:, :, :2] - kp_ref[:, :, :2], axis=2)
     step = 1.3 * 200 / 32
     print("stable joints %d/%d, max err on stable %.3f px (one heatmap px = %.2f image px)" % (stable.sum(), stable.size, err[stable].max() if stable.any() else 0, step))
@@ -147,7 +156,7 @@ def test_cli_tools_test_and_pose_export(pk, tmp_path):
     kp, Rs, ts = P.synth_keypoints(6, np.random.default_rng(4), 0.5, 0.0)
     from scipy.io import savemat
     savemat(tmp_path / "kp.mat", {"preds": kp})
-    (tmp_path / "landmarks.csv").write_text("x,y,z\n" + "\n".join("%r,%r,%r" % tuple(r) for r in P.LANDMARKS))
+    (tmp_path / "landmarks.csv").write_text("x,y,z\n" + "\n".join(",".join(repr(float(v)) for v in r) for r in P.LANDMARKS))
     (tmp_path / "calib.json").write_text(json.dumps({"intrinsics": {"camera_matrix": P.CAMERA_K.tolist(),
                                                                     "distortion_coefficients": P.CAMERA_DIST.tolist()}}))
     cmd = [sys.executable, "export_predicted_poses_real.py", "--frames_dir", str(tmp_path / "frames"),
