@@ -27,8 +27,12 @@ template <typename T> __device__ __forceinline__ uint32_t ew_to(float f) {
   return (uint32_t)__builtin_bit_cast(uint16_t, t);
 }
 
-template <typename T>
+template <int DT> struct EwDt { typedef __bf16 type; };
+template <> struct EwDt<1> { typedef _Float16 type; };
+
+template <int DT>
 __global__ __launch_bounds__(256) void fuse_sum_kernel(const FuseArgs a) {
+  typedef typename EwDt<DT>::type T;
   const size_t total = (size_t)a.N * a.planes * a.H * a.W;
   for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < total;
        gid += (size_t)gridDim.x * 256) {
@@ -75,17 +79,18 @@ int32_t fuse_sum_launch(const void* const* terms, const int32_t* shifts, int nte
   size_t blocks = (total + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond 32 blocks per CU
   if (dtype == SCPOSE_DT_BF16)
-    hipLaunchKernelGGL(fuse_sum_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(fuse_sum_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
   else
-    hipLaunchKernelGGL(fuse_sum_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(fuse_sum_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
   SCP_CHECK_HIP(hipGetLastError());
   return SCPOSE_OK;
 }
 
 // ---- layout converters (test / debugging plumbing, also the module's generic input path) ----
-template <typename T>
+template <int DT>
 __global__ void nchw_to_blocked_kernel(const float* __restrict__ src, int N, int C, int H, int W,
                                        void* __restrict__ dst) {
+  typedef typename EwDt<DT>::type T;
   const size_t HW = (size_t)H * W;
   const size_t total = (size_t)N * (C / 8) * HW;
   for (size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
@@ -101,9 +106,10 @@ __global__ void nchw_to_blocked_kernel(const float* __restrict__ src, int N, int
   }
 }
 
-template <typename T>
+template <int DT>
 __global__ void blocked_to_nchw_kernel(const void* __restrict__ src, int N, int C, int H, int W,
                                        float* __restrict__ dst) {
+  typedef typename EwDt<DT>::type T;
   const size_t HW = (size_t)H * W;
   const size_t total = (size_t)N * (C / 8) * HW;
   for (size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
@@ -129,9 +135,9 @@ int32_t nchw_to_blocked_launch(const float* src, int N, int C, int H, int W, int
   SCP_REQUIRE(C % 8 == 0, "layout: C=%d must be a multiple of 8", C);
   const size_t total = (size_t)N * (C / 8) * H * W;
   if (dtype == SCPOSE_DT_BF16)
-    hipLaunchKernelGGL(nchw_to_blocked_kernel<__bf16>, dim3(ew_grid(total)), dim3(256), 0, stream, src, N, C, H, W, dst);
+    hipLaunchKernelGGL(nchw_to_blocked_kernel<0>, dim3(ew_grid(total)), dim3(256), 0, stream, src, N, C, H, W, dst);
   else
-    hipLaunchKernelGGL(nchw_to_blocked_kernel<_Float16>, dim3(ew_grid(total)), dim3(256), 0, stream, src, N, C, H, W, dst);
+    hipLaunchKernelGGL(nchw_to_blocked_kernel<1>, dim3(ew_grid(total)), dim3(256), 0, stream, src, N, C, H, W, dst);
   SCP_CHECK_HIP(hipGetLastError());
   return SCPOSE_OK;
 }
@@ -141,9 +147,9 @@ int32_t blocked_to_nchw_launch(const void* src, int N, int C, int H, int W, int 
   SCP_REQUIRE(C % 8 == 0, "layout: C=%d must be a multiple of 8", C);
   const size_t total = (size_t)N * (C / 8) * H * W;
   if (dtype == SCPOSE_DT_BF16)
-    hipLaunchKernelGGL(blocked_to_nchw_kernel<__bf16>, dim3(ew_grid(total)), dim3(256), 0, stream, src, N, C, H, W, dst);
+    hipLaunchKernelGGL(blocked_to_nchw_kernel<0>, dim3(ew_grid(total)), dim3(256), 0, stream, src, N, C, H, W, dst);
   else
-    hipLaunchKernelGGL(blocked_to_nchw_kernel<_Float16>, dim3(ew_grid(total)), dim3(256), 0, stream, src, N, C, H, W, dst);
+    hipLaunchKernelGGL(blocked_to_nchw_kernel<1>, dim3(ew_grid(total)), dim3(256), 0, stream, src, N, C, H, W, dst);
   SCP_CHECK_HIP(hipGetLastError());
   return SCPOSE_OK;
 }

@@ -13,17 +13,21 @@
 
 namespace scpose {
 
+template <int DT> struct StemDt { typedef __bf16 type; };
+template <> struct StemDt<1> { typedef _Float16 type; };
+
 template <typename T> __device__ __forceinline__ uint16_t stem_bits(float f) {
   T t = (T)f;
   return __builtin_bit_cast(uint16_t, t);
 }
 
-template <typename T, int FMT>
+template <int DT, int FMT>
 __global__ __launch_bounds__(256) void stem_conv1_kernel(const void* __restrict__ in,
                                                          const float* __restrict__ w,
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ mean_std,
                                                          int N, int H, int W, void* __restrict__ out) {
+  typedef typename StemDt<DT>::type T;
   const int Ho = H >> 1, Wo = W >> 1;
   const size_t total = (size_t)N * Ho * Wo;
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -89,11 +93,11 @@ int32_t stem_launch(const void* in, int in_fmt, const float* w_folded, const flo
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
   const bool bf = dtype == SCPOSE_DT_BF16;
   if (in_fmt == SCPOSE_IN_F32_NCHW) {
-    if (bf) hipLaunchKernelGGL((stem_conv1_kernel<__bf16, SCPOSE_IN_F32_NCHW>), grid, block, 0, stream, in, w_folded, bias, mean_std, N, H, W, out);
-    else hipLaunchKernelGGL((stem_conv1_kernel<_Float16, SCPOSE_IN_F32_NCHW>), grid, block, 0, stream, in, w_folded, bias, mean_std, N, H, W, out);
+    if (bf) hipLaunchKernelGGL((stem_conv1_kernel<0, SCPOSE_IN_F32_NCHW>), grid, block, 0, stream, in, w_folded, bias, mean_std, N, H, W, out);
+    else hipLaunchKernelGGL((stem_conv1_kernel<1, SCPOSE_IN_F32_NCHW>), grid, block, 0, stream, in, w_folded, bias, mean_std, N, H, W, out);
   } else {
-    if (bf) hipLaunchKernelGGL((stem_conv1_kernel<__bf16, SCPOSE_IN_U8_NHWC>), grid, block, 0, stream, in, w_folded, bias, mean_std, N, H, W, out);
-    else hipLaunchKernelGGL((stem_conv1_kernel<_Float16, SCPOSE_IN_U8_NHWC>), grid, block, 0, stream, in, w_folded, bias, mean_std, N, H, W, out);
+    if (bf) hipLaunchKernelGGL((stem_conv1_kernel<0, SCPOSE_IN_U8_NHWC>), grid, block, 0, stream, in, w_folded, bias, mean_std, N, H, W, out);
+    else hipLaunchKernelGGL((stem_conv1_kernel<1, SCPOSE_IN_U8_NHWC>), grid, block, 0, stream, in, w_folded, bias, mean_std, N, H, W, out);
   }
   SCP_CHECK_HIP(hipGetLastError());
   return SCPOSE_OK;
