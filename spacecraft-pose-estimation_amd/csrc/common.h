@@ -56,6 +56,12 @@ struct ConvLaunch {
   int32_t relu;
   int32_t out_nchw_f32;
   int32_t total_blocks;
+  // pipelined (persistent) variant
+  const void* zero16;    // >= 16 zero bytes in global memory (source of padding pixels for LDS-DMA)
+  int32_t items_total;   // (tile, Cout block) work items
+  int32_t items_per_wg;
+  int32_t grid;          // persistent workgroups
+  int32_t lds_w, lds_x;  // bytes of one weight-chunk / input-chunk LDS buffer
 };
 
 // Per-layer choice of kernel variant + tiling.
@@ -93,6 +99,11 @@ void conv_free(PackedConv* pc);
 int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, const void* res,
                     int relu, int out_nchw_f32, void* out, hipStream_t stream);
 size_t conv_lds_bytes(const PackedConv& pc, int nrep, int th, int tw);
+int plane_stride_for(int stride, int halo_h, int halo_w);
+// software-pipelined persistent variant (conv_pipe.hip); returns SCPOSE_E_INVALID with
+// *fits = false when the double-buffered LDS image does not fit 160 KiB
+int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, hipStream_t stream, bool* fits);
+const void* conv_zero_page();   // lazily allocated 256 zero bytes on the current device
 
 // ---- stem: 3 -> 64, 3x3 stride 2 from f32 NCHW or u8 NHWC ----------------------------------
 int32_t stem_launch(const void* in, int in_fmt, const float* w_folded /*dev [64][27]*/,

@@ -1,0 +1,45 @@
+// Device-side helpers shared by the convolution kernels (MFMA fragments, 16-bit casts, XCD remap).
+#pragma once
+#include "common.h"
+
+namespace scpose {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+template <typename T> struct FragOf;
+template <> struct FragOf<__bf16> { typedef bf16x8 type; };
+template <> struct FragOf<_Float16> { typedef f16x8 type; };
+
+template <typename T>
+__device__ __forceinline__ f32x4 mfma16(typename FragOf<T>::type a, typename FragOf<T>::type b,
+                                        f32x4 c) {
+  if constexpr (sizeof(T) == 2 && __is_same(T, __bf16))
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+template <typename T> __device__ __forceinline__ uint16_t to_bits(float f) {
+  T t = (T)f;
+  return __builtin_bit_cast(uint16_t, t);
+}
+template <typename T> __device__ __forceinline__ float from_bits(uint16_t v) {
+  return (float)__builtin_bit_cast(T, v);
+}
+
+// Blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous range of
+// logical ids so that neighbouring tiles / Cout blocks of one tile hit the same L2.
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+  const int xcd = b & 7, q8 = nb >> 3, r8 = nb & 7;
+  const int base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  return base + (b >> 3);
+}
+
+// DT: 0 = bf16, 1 = f16 (an int so that profiler kernel names demangle: conv_igemm_kernel<0,3,1,3,4>)
+template <int DT> struct DtOf { typedef __bf16 type; };
+template <> struct DtOf<1> { typedef _Float16 type; };
+
+
+}  // namespace scpose

@@ -17,46 +17,12 @@
 //     2*pp + (q&1) at tap pt = 2*s + (q>>1).  The two k-groups that share a ds_read_b128
 //     lane group (q = 0,1 and q = 2,3) therefore differ by one whole LDS plane, whose stride
 //     is padded so both land on disjoint banks.
+#include <stdlib.h>
+
 #include "common.h"
+#include "conv_device.h"
 
 namespace scpose {
-
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-
-template <typename T> struct FragOf;
-template <> struct FragOf<__bf16> { typedef bf16x8 type; };
-template <> struct FragOf<_Float16> { typedef f16x8 type; };
-
-template <typename T>
-__device__ __forceinline__ f32x4 mfma16(typename FragOf<T>::type a, typename FragOf<T>::type b,
-                                        f32x4 c) {
-  if constexpr (sizeof(T) == 2 && __is_same(T, __bf16))
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-  else
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
-
-template <typename T> __device__ __forceinline__ uint16_t to_bits(float f) {
-  T t = (T)f;
-  return __builtin_bit_cast(uint16_t, t);
-}
-template <typename T> __device__ __forceinline__ float from_bits(uint16_t v) {
-  return (float)__builtin_bit_cast(T, v);
-}
-
-// Blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous range of
-// logical ids so that neighbouring tiles / Cout blocks of one tile hit the same L2.
-__device__ __forceinline__ int xcd_remap(int b, int nb) {
-  const int xcd = b & 7, q8 = nb >> 3, r8 = nb & 7;
-  const int base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-  return base + (b >> 3);
-}
-
-// DT: 0 = bf16, 1 = f16 (an int so that profiler kernel names demangle: conv_igemm_kernel<0,3,1,3,4>)
-template <int DT> struct DtOf { typedef __bf16 type; };
-template <> struct DtOf<1> { typedef _Float16 type; };
 
 template <int DT, int KS, int STRIDE, int MREP, int NREP>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvLaunch p) {
@@ -337,6 +303,7 @@ int32_t conv_upload(const float* w, const float* bias, int cout, int cin, int ks
   pack_conv_weights(w, cout, cin, ks, pc->mt, pc->cp, dtype, host.data(), nullptr, nullptr);
   std::vector<float> hb((size_t)pc->n_mblk * pc->mt, 0.f);
   if (bias) for (int i = 0; i < cout; ++i) hb[i] = bias[i];
+  SCP_REQUIRE(conv_zero_page() != nullptr, "conv: cannot allocate the zero page");  // create-time, not in the launch path
   SCP_CHECK_HIP(hipMalloc(&pc->d_w, pc->wbytes));
   SCP_CHECK_HIP(hipMalloc(&pc->d_bias, hb.size() * sizeof(float)));
   SCP_CHECK_HIP(hipMemcpy(pc->d_w, host.data(), pc->wbytes, hipMemcpyHostToDevice));
@@ -350,7 +317,7 @@ void conv_free(PackedConv* pc) {
   pc->d_w = nullptr; pc->d_bias = nullptr;
 }
 
-static int plane_stride_for(int stride, int halo_h, int halo_w) {
+int plane_stride_for(int stride, int halo_h, int halo_w) {
   int bytes = halo_h * halo_w * 16;
   if (stride == 1) return (bytes + 255) & ~255;       // q and q^1 planes: same bank phase
   bytes = (bytes + 31) & ~31;                          // stride 2: odd 16-B slot phase
@@ -439,6 +406,12 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
   SCP_REQUIRE(L.halo_h * L.halo_w <= (pc.stride == 1 ? 2 : 3) * 256, "conv: halo %dx%d too large",
               L.halo_h, L.halo_w);
   SCP_REQUIRE((pc.ksteps_full + 1) * 4 <= 64, "conv: k-offset table overflow (%d ksteps)", pc.ksteps_full);
+  static const bool force_v1 = getenv("SCPOSE_CONV_V1") != nullptr;   // A/B switch for development
+  if (!force_v1) {
+    bool fits = false;
+    const int32_t rc = conv_launch_pipe(pc, L, nrep, stream, &fits);
+    if (fits) return rc;
+  }
   const size_t lds = conv_lds_bytes(pc, nrep, L.th, L.tw);
   SCP_REQUIRE(lds <= 160 * 1024, "conv: LDS %zu bytes exceeds 160 KiB", lds);
   if (pc.dtype == SCPOSE_DT_BF16)

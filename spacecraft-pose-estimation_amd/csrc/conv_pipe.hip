@@ -1,0 +1,312 @@
+// Software-pipelined, persistent implicit-GEMM convolution (same math and data layout as
+// conv_igemm.hip; see that file for the GEMM orientation and K ordering).
+//
+// What changes is HOW the operands reach LDS:
+//   * one workgroup per CU, resident for the whole launch, walks a contiguous range of
+//     (tile, Cout-block) work items; the XCD remap keeps a range inside one XCD's L2;
+//   * every K-chunk (cp input planes + their packed weights) is brought in with LDS-DMA
+//     (global_load_lds_dwordx4: no staging registers, 1 KiB per wave-instruction) into one of TWO
+//     LDS buffers, so the loads of stage s+1 are in flight while the MFMAs of stage s run;
+//     one barrier per stage;
+//   * a layer whose whole K fits one chunk and whose Cout fits one block (the C<=48 high
+//     resolution branch: 35 % of the forward) keeps its packed weights resident in LDS for
+//     the whole launch and only streams activation tiles;
+//   * zero padding comes from a zero page: an out-of-image halo pixel's DMA source address is
+//     redirected to 16 zero bytes, lanes past the halo tile are masked off (EXEC).
+#include "common.h"
+#include "conv_device.h"
+
+namespace scpose {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+__device__ __forceinline__ void dma16(const void* g, void* l_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)l_wave_base, 16, 0, 0);
+}
+
+template <int DT, int KS, int STRIDE, int MREP, int NREP>
+__global__ __launch_bounds__(256) void conv_pipe_kernel(const ConvLaunch p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename DtOf<DT>::type T;
+  typedef typename FragOf<T>::type frag_t;
+  constexpr int MT = 16 * MREP;
+  constexpr int MAXP = (STRIDE == 1) ? 2 : 3;
+  constexpr int KK = KS * KS;
+
+  int* koff = reinterpret_cast<int*>(smem);   // [2][64]: full chunk, last chunk
+  char* wl0 = smem + 512;
+  char* xl0 = wl0 + 2 * p.lds_w;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, r = lane & 15;
+  const int HW = p.H * p.W;
+  const int HP = p.halo_h * p.halo_w;
+  const int npix = p.th * p.tw;
+  const int planes_last = p.cin_planes - (p.nchunks - 1) * p.cp;
+  const bool w_resident = p.nchunks == 1 && p.n_mblk == 1;
+
+  if (tid < 128) {  // K-offset tables (B-operand LDS byte offset of k-group q at k-step s)
+    const int tbl = tid >> 6, e = tid & 63;
+    const int planes = tbl ? planes_last : p.cp;
+    const int npt = (planes >> 1) * KK;
+    const int s = e >> 2, qq = e & 3;
+    const int pt = 2 * s + (qq >> 1);
+    int off = 0;
+    if (pt < npt) {
+      const int pp = pt / KK, tap = pt - pp * KK;
+      const int ky = tap / KS, kx = tap - ky * KS;
+      off = (2 * pp + (qq & 1)) * p.plane_stride + (ky * p.halo_w + kx) * 16;
+    }
+    koff[tid] = off;
+  }
+
+  // tile-independent geometry of this thread's halo pixels and this lane's output pixels
+  int hy[MAXP], hx[MAXP];
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int hp = i * 256 + tid;
+    hy[i] = hp < HP ? hp / p.halo_w : -1;
+    hx[i] = hp < HP ? hp - hy[i] * p.halo_w : 0;
+  }
+  int pixoff[NREP], py[NREP], px[NREP];
+#pragma unroll
+  for (int n = 0; n < NREP; ++n) {
+    const int pidx = (wave * NREP + n) * 16 + r;
+    if (pidx < npix) {
+      py[n] = pidx / p.tw; px[n] = pidx - py[n] * p.tw;
+      pixoff[n] = ((py[n] * STRIDE) * p.halo_w + px[n] * STRIDE) * 16;
+    } else {
+      py[n] = -1; px[n] = 0; pixoff[n] = 0;
+    }
+  }
+
+  const int wg = xcd_remap(blockIdx.x, p.grid);
+  const int it_begin = wg * p.items_per_wg;
+  const int it_end = min(p.items_total, it_begin + p.items_per_wg);
+  const size_t chunk_wbytes = (size_t)p.ksteps_full * (4 * MT * 16);
+
+  auto decode_item = [&](int it, int& mb, int& img, int& oy0, int& ox0) {
+    mb = it % p.n_mblk;
+    int t = it / p.n_mblk;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    img = t / p.tiles_y;
+    oy0 = ty * p.th; ox0 = tx * p.tw;
+  };
+
+  // issue the LDS-DMA of stage (it, c) into buffer `buf`
+  auto issue = [&](int it, int c, int buf, bool with_weights) {
+    int mb, img, oy0, ox0;
+    decode_item(it, mb, img, oy0, ox0);
+    const int planes = c == p.nchunks - 1 ? planes_last : p.cp;
+    if (with_weights) {
+      const int ksteps = (((planes >> 1) * KK) + 1) >> 1;
+      const int nbytes = ksteps * (4 * MT * 16);
+      const char* ws = static_cast<const char*>(p.wpk) + ((size_t)mb * p.nchunks + c) * chunk_wbytes;
+      char* wl = wl0 + (w_resident ? 0 : buf) * p.lds_w;
+      for (int o = 0; o < nbytes; o += 4096) {
+        const int mine = o + tid * 16;
+        if (mine < nbytes) dma16(ws + mine, wl + o + wave * 1024);
+      }
+    }
+    const int iy0 = oy0 * STRIDE - (KS / 2), ix0 = ox0 * STRIDE - (KS / 2);
+    const char* inb = static_cast<const char*>(p.in) + ((size_t)img * p.cin_planes + (size_t)c * p.cp) * HW * 16;
+    char* xl = xl0 + buf * p.lds_x;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      if (hy[i] >= 0) {
+        const int iy = iy0 + hy[i], ix = ix0 + hx[i];
+        const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const size_t g = ok ? (size_t)(iy * p.W + ix) * 16 : 0;
+        for (int pl = 0; pl < planes; ++pl) {
+          const char* src = ok ? inb + (size_t)pl * HW * 16 + g : static_cast<const char*>(p.zero16);
+          dma16(src, xl + pl * p.plane_stride + (i * 256 + wave * 64) * 16);
+        }
+      }
+    }
+  };
+
+  f32x4 acc[MREP][NREP];
+  int ld_it = it_begin, ld_c = 0;       // next stage to load
+  bool w_loaded = false;
+  if (ld_it < it_end) {
+    issue(ld_it, ld_c, 0, true);
+    w_loaded = true;
+    if (++ld_c == p.nchunks) { ld_c = 0; ++ld_it; }
+  }
+  int buf = 0;
+  for (int it = it_begin; it < it_end; ++it) {
+    int mb, img, oy0, ox0;
+    decode_item(it, mb, img, oy0, ox0);
+    for (int c = 0; c < p.nchunks; ++c) {
+      // stage (it, c) has landed once every wave has drained its own DMA and passed the barrier;
+      // the same barrier retires all reads of the buffer the next stage is about to overwrite
+      __syncthreads();
+      if (ld_it < it_end) {
+        issue(ld_it, ld_c, buf ^ 1, !(w_resident && w_loaded));
+        if (++ld_c == p.nchunks) { ld_c = 0; ++ld_it; }
+      }
+      if (c == 0) {
+#pragma unroll
+        for (int m = 0; m < MREP; ++m)
+#pragma unroll
+          for (int n = 0; n < NREP; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      const bool last = c == p.nchunks - 1;
+      const int planes = last ? planes_last : p.cp;
+      const int ksteps = (((planes >> 1) * KK) + 1) >> 1;
+      const int* ko_tbl = koff + (last ? 64 : 0);
+      const char* xl = xl0 + buf * p.lds_x;
+      const char* wq = wl0 + (w_resident ? 0 : buf) * p.lds_w + (q * MT + r) * 16;
+      for (int s = 0; s < ksteps; ++s) {
+        const int ko = ko_tbl[s * 4 + q];
+        frag_t a[MREP], b[NREP];
+#pragma unroll
+        for (int m = 0; m < MREP; ++m)
+          a[m] = *reinterpret_cast<const frag_t*>(wq + s * (4 * MT * 16) + m * 256);
+#pragma unroll
+        for (int n = 0; n < NREP; ++n)
+          b[n] = *reinterpret_cast<const frag_t*>(xl + ko + pixoff[n]);
+#pragma unroll
+        for (int m = 0; m < MREP; ++m)
+#pragma unroll
+          for (int n = 0; n < NREP; ++n) acc[m][n] = mfma16<T>(a[m], b[n], acc[m][n]);
+      }
+      buf ^= 1;
+    }
+
+    // ---- epilogue of item `it` ----
+    const int cout_planes = (p.cout + 7) >> 3;
+    const size_t HoWo = (size_t)p.Ho * p.Wo;
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) {
+      if (py[n] < 0) continue;
+      const int oy = oy0 + py[n], ox = ox0 + px[n];
+      if (oy >= p.Ho || ox >= p.Wo) continue;
+      const size_t opix = (size_t)oy * p.Wo + ox;
+#pragma unroll
+      for (int m = 0; m < MREP; ++m) {
+        const int co = mb * MT + m * 16 + q * 4;
+        if (co >= p.cout) continue;
+        const float4 bs = *reinterpret_cast<const float4*>(p.bias + co);
+        float v0 = acc[m][n][0] + bs.x, v1 = acc[m][n][1] + bs.y;
+        float v2 = acc[m][n][2] + bs.z, v3 = acc[m][n][3] + bs.w;
+        const size_t boff = (((size_t)img * cout_planes + (co >> 3)) * HoWo + opix) * 16 + (co & 7) * 2;
+        if (p.res) {
+          const uint2 rv = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.res) + boff);
+          v0 += from_bits<T>(rv.x & 0xffff); v1 += from_bits<T>(rv.x >> 16);
+          v2 += from_bits<T>(rv.y & 0xffff); v3 += from_bits<T>(rv.y >> 16);
+        }
+        if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+        if (p.out_nchw_f32) {
+          float* o = static_cast<float*>(p.out) + ((size_t)img * p.cout + co) * HoWo + opix;
+          o[0] = v0;
+          if (co + 1 < p.cout) o[HoWo] = v1;
+          if (co + 2 < p.cout) o[2 * HoWo] = v2;
+          if (co + 3 < p.cout) o[3 * HoWo] = v3;
+        } else {
+          uint2 ov;
+          ov.x = (uint32_t)to_bits<T>(v0) | ((uint32_t)to_bits<T>(v1) << 16);
+          ov.y = (uint32_t)to_bits<T>(v2) | ((uint32_t)to_bits<T>(v3) << 16);
+          *reinterpret_cast<uint2*>(static_cast<char*>(p.out) + boff) = ov;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+static void* g_zero_page[16] = {nullptr};
+
+const void* conv_zero_page() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!g_zero_page[dev]) {
+    void* p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+    g_zero_page[dev] = p;
+  }
+  return g_zero_page[dev];
+}
+
+static int device_cus() {
+  static int cus[16] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16) return 256;
+  if (!cus[dev]) {
+    hipDeviceProp_t prop;
+    cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return cus[dev];
+}
+
+template <int DT, int KS, int STRIDE, int MREP>
+static int32_t pipe_nrep(int nrep, const ConvLaunch& L, size_t lds, hipStream_t st) {
+  dim3 grid(L.grid), block(256);
+#define SCP_LAUNCH(NR)                                                                          \
+  case NR: {                                                                                    \
+    auto kern = conv_pipe_kernel<DT, KS, STRIDE, MREP, NR>;                                      \
+    static bool big_lds_enabled = false;                                                        \
+    if (!big_lds_enabled) {                                                                     \
+      SCP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                    \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,             \
+                                        160 * 1024));                                           \
+      big_lds_enabled = true;                                                                   \
+    }                                                                                           \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, L);                                          \
+    break;                                                                                      \
+  }
+  switch (nrep) {
+    SCP_LAUNCH(1) SCP_LAUNCH(2) SCP_LAUNCH(3) SCP_LAUNCH(4)
+    default: set_error("conv: nrep %d unsupported", nrep); return SCPOSE_E_INVALID;
+  }
+#undef SCP_LAUNCH
+  SCP_CHECK_HIP(hipGetLastError());
+  return SCPOSE_OK;
+}
+
+template <int DT, int KS, int STRIDE>
+static int32_t pipe_mrep(int mrep, int nrep, const ConvLaunch& L, size_t lds, hipStream_t st) {
+  switch (mrep) {
+    case 1: return pipe_nrep<DT, KS, STRIDE, 1>(nrep, L, lds, st);
+    case 2: return pipe_nrep<DT, KS, STRIDE, 2>(nrep, L, lds, st);
+    case 3: return pipe_nrep<DT, KS, STRIDE, 3>(nrep, L, lds, st);
+    case 4: return pipe_nrep<DT, KS, STRIDE, 4>(nrep, L, lds, st);
+    case 6: return pipe_nrep<DT, KS, STRIDE, 6>(nrep, L, lds, st);
+  }
+  set_error("conv: mrep %d unsupported", mrep);
+  return SCPOSE_E_INVALID;
+}
+
+template <int DT>
+static int32_t pipe_ks(int ks, int stride, int mrep, int nrep, const ConvLaunch& L, size_t lds, hipStream_t st) {
+  if (ks == 3 && stride == 1) return pipe_mrep<DT, 3, 1>(mrep, nrep, L, lds, st);
+  if (ks == 3 && stride == 2) return pipe_mrep<DT, 3, 2>(mrep, nrep, L, lds, st);
+  if (ks == 1 && stride == 1) return pipe_mrep<DT, 1, 1>(mrep, nrep, L, lds, st);
+  set_error("conv: k=%d stride=%d unsupported", ks, stride);
+  return SCPOSE_E_INVALID;
+}
+
+int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, hipStream_t stream, bool* fits) {
+  L.lds_w = pc.ksteps_full * 4 * pc.mt * 16;
+  L.lds_x = pc.cp * L.plane_stride;
+  const size_t lds = 512 + 2 * (size_t)L.lds_w + 2 * (size_t)L.lds_x;
+  *fits = lds <= 160 * 1024;
+  if (!*fits) return SCPOSE_E_INVALID;
+  L.zero16 = conv_zero_page();
+  SCP_REQUIRE(L.zero16, "conv: cannot allocate the zero page");
+  L.items_total = L.total_blocks;
+  const int cus = device_cus();
+  const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
+  int grid = cus * (per_cu > 2 ? 2 : per_cu);
+  if (grid > L.items_total) grid = L.items_total;
+  L.items_per_wg = (L.items_total + grid - 1) / grid;
+  L.grid = (L.items_total + L.items_per_wg - 1) / L.items_per_wg;
+  if (pc.dtype == SCPOSE_DT_BF16) return pipe_ks<0>(pc.ks, pc.stride, pc.mrep, nrep, L, lds, stream);
+  return pipe_ks<1>(pc.ks, pc.stride, pc.mrep, nrep, L, lds, stream);
+}
+
+}  // namespace scpose
