@@ -13,6 +13,8 @@
 //     the whole launch and only streams activation tiles;
 //   * zero padding comes from a zero page: an out-of-image halo pixel's DMA source address is
 //     redirected to 16 zero bytes, lanes past the halo tile are masked off (EXEC).
+#include <stdlib.h>
+
 #include "common.h"
 #include "conv_device.h"
 
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(const ConvLaunch p) {
     char* xl = xl0 + buf * p.lds_x;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
-      if (hy[i] >= 0) {
+      if (hy[i] >= 0 && !(p.dbg & 4)) {
         const int iy = iy0 + hy[i], ix = ix0 + hx[i];
         const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         const size_t g = ok ? (size_t)(iy * p.W + ix) * 16 : 0;
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(const ConvLaunch p) {
       const int* ko_tbl = koff + (last ? 64 : 0);
       const char* xl = xl0 + buf * p.lds_x;
       const char* wq = wl0 + (w_resident ? 0 : buf) * p.lds_w + (q * MT + r) * 16;
-      for (int s = 0; s < ksteps; ++s) {
+      for (int s = 0; s < ((p.dbg & 1) ? 0 : ksteps); ++s) {
         const int ko = ko_tbl[s * 4 + q];
         frag_t a[MREP], b[NREP];
 #pragma unroll
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(const ConvLaunch p) {
     const size_t HoWo = (size_t)p.Ho * p.Wo;
 #pragma unroll
     for (int n = 0; n < NREP; ++n) {
-      if (py[n] < 0) continue;
+      if (py[n] < 0 || (p.dbg & 2)) continue;
       const int oy = oy0 + py[n], ox = ox0 + px[n];
       if (oy >= p.Ho || ox >= p.Wo) continue;
       const size_t opix = (size_t)oy * p.Wo + ox;
@@ -299,6 +301,7 @@ int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, hipStrea
   L.zero16 = conv_zero_page();
   SCP_REQUIRE(L.zero16, "conv: cannot allocate the zero page");
   L.items_total = L.total_blocks;
+  { static const char* e = getenv("SCPOSE_DBG"); L.dbg = e ? atoi(e) : 0; }
   const int cus = device_cus();
   const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
   int grid = cus * (per_cu > 2 ? 2 : per_cu);

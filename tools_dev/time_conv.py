@@ -1,0 +1,24 @@
+"""Time one conv layer shape: python tools_dev/time_conv.py cin cout k s H N [res]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, scpose
+from importlib import import_module
+ops = import_module("spacecraft-pose-estimation_amd.ops")
+cin, cout, k, s, H, N = [int(v) for v in sys.argv[1:7]]
+res = len(sys.argv) > 7 and sys.argv[7] == "res"
+w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+conv = ops.Conv(w, torch.zeros(cout), stride=s)
+x = torch.randn(N, cin // 8, H, H, 8, device="cuda").bfloat16()
+Ho = (H - 1) // s + 1
+r = torch.randn(N, cout // 8, Ho, Ho, 8, device="cuda").bfloat16() if res else None
+for _ in range(3): y = conv(x, residual=r, relu=True)
+torch.cuda.synchronize()
+st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+st.record()
+it = 20
+for _ in range(it): y = conv(x, residual=r, relu=True)
+en.record(); torch.cuda.synchronize()
+us = st.elapsed_time(en) / it * 1e3
+fl = 2.0 * cin * cout * k * k * Ho * Ho * N
+by = (cin * H * H + cout * Ho * Ho * (2 if res else 1)) * 2.0 * N
+print("dbg=%s conv %d->%d k%d s%d %dx%d N=%d res=%d: %.1f us  %.1f TFLOP/s  %.0f GB/s" % (os.environ.get("SCPOSE_DBG", "0"), cin, cout, k, s, H, H, N, res, us, fl / us / 1e6, by / us / 1e3))
