@@ -1,4 +1,5 @@
-// Implicit-GEMM 3x3 / 1x1 convolution for gfx950 (CDNA4) on v_mfma_f32_16x16x32_{bf16,f16}.
+// Implicit-GEMM 3x3 / 1x1 convolution for gfx950 (CDNA4) on v_mfma_f32_16x16x32_{bf16,f16}:
+// host side (tiling choice, weight packing, launch).  The kernel is in conv_pipe.hip.
 //
 // Replaces every nn.Conv2d + eval BatchNorm2d (+ReLU, +residual add) of the reference
 // landmark_regression/lib/models/pose_hrnet.py (conv3x3 :22-25, BasicBlock :41-57,
@@ -23,170 +24,6 @@
 #include "conv_device.h"
 
 namespace scpose {
-
-template <int DT, int KS, int STRIDE, int MREP, int NREP>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvLaunch p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef typename DtOf<DT>::type T;
-  typedef typename FragOf<T>::type frag_t;
-  constexpr int MT = 16 * MREP;
-  constexpr int MAXP = (STRIDE == 1) ? 2 : 3;   // halo pixels per thread (host guarantees)
-  constexpr int KK = KS * KS;
-
-  int* koff = reinterpret_cast<int*>(smem);                 // 64 entries
-  char* wl = smem + 256;                                    // weights chunk
-  char* xl = wl + p.ksteps_full * (4 * MT * 16);            // input chunk
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q = lane >> 4, r = lane & 15;
-
-  const int bid = xcd_remap(blockIdx.x, p.total_blocks);
-  const int mb = bid % p.n_mblk;
-  int t = bid / p.n_mblk;
-  const int tx = t % p.tiles_x; t /= p.tiles_x;
-  const int ty = t % p.tiles_y;
-  const int img = t / p.tiles_y;
-  const int oy0 = ty * p.th, ox0 = tx * p.tw;
-  const int iy0 = oy0 * STRIDE - (KS / 2), ix0 = ox0 * STRIDE - (KS / 2);
-  const int HW = p.H * p.W;
-  const int HP = p.halo_h * p.halo_w;
-
-  // this thread's halo pixels: global pixel offset (or -1 = zero padding, -2 = none)
-  int goff[MAXP];
-#pragma unroll
-  for (int i = 0; i < MAXP; ++i) {
-    const int hp = tid + i * 256;
-    int g = -2;
-    if (hp < HP) {
-      const int hy = hp / p.halo_w, hx = hp - hy * p.halo_w;
-      const int iy = iy0 + hy, ix = ix0 + hx;
-      g = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? iy * p.W + ix : -1;
-    }
-    goff[i] = g;
-  }
-
-  // this lane's pixels (B-operand column) in each of the wave's NREP tiles
-  int pixoff[NREP];
-  const int npix = p.th * p.tw;
-#pragma unroll
-  for (int n = 0; n < NREP; ++n) {
-    const int pidx = (wave * NREP + n) * 16 + r;
-    int off = 0;
-    if (pidx < npix) {
-      const int y = pidx / p.tw, x = pidx - y * p.tw;
-      off = ((y * STRIDE) * p.halo_w + x * STRIDE) * 16;
-    }
-    pixoff[n] = off;
-  }
-
-  f32x4 acc[MREP][NREP];
-#pragma unroll
-  for (int m = 0; m < MREP; ++m)
-#pragma unroll
-    for (int n = 0; n < NREP; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const char* inb = static_cast<const char*>(p.in) + (size_t)img * p.cin_planes * HW * 16;
-  const size_t chunk_wbytes = (size_t)p.ksteps_full * (4 * MT * 16);
-  const char* wb = static_cast<const char*>(p.wpk) + (size_t)mb * p.nchunks * chunk_wbytes;
-
-  for (int c = 0; c < p.nchunks; ++c) {
-    const int plane0 = c * p.cp;
-    const int planes = min(p.cp, p.cin_planes - plane0);
-    const int npt = (planes >> 1) * KK;
-    const int ksteps = (npt + 1) >> 1;
-
-    __syncthreads();  // all waves finished reading the previous chunk
-    if (tid < (ksteps + 1) * 4) {
-      const int s = tid >> 2, qq = tid & 3;
-      const int pt = 2 * s + (qq >> 1);
-      int off = 0;
-      if (pt < npt) {
-        const int pp = pt / KK, tap = pt - pp * KK;
-        const int ky = tap / KS, kx = tap - ky * KS;
-        off = (2 * pp + (qq & 1)) * p.plane_stride + (ky * p.halo_w + kx) * 16;
-      }
-      koff[tid] = off;
-    }
-    {  // weights: one contiguous LDS image per (Cout block, chunk)
-      const char* ws = wb + (size_t)c * chunk_wbytes;
-      const int nbytes = ksteps * (4 * MT * 16);
-      for (int i = tid * 16; i < nbytes; i += 256 * 16)
-        *reinterpret_cast<uint4*>(wl + i) = *reinterpret_cast<const uint4*>(ws + i);
-    }
-    for (int pl = 0; pl < planes; ++pl) {
-      const char* src = inb + (size_t)(plane0 + pl) * HW * 16;
-      char* dst = xl + pl * p.plane_stride + tid * 16;
-#pragma unroll
-      for (int i = 0; i < MAXP; ++i) {
-        if (goff[i] != -2) {
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (goff[i] >= 0) v = *reinterpret_cast<const uint4*>(src + (size_t)goff[i] * 16);
-          *reinterpret_cast<uint4*>(dst + i * 4096) = v;
-        }
-      }
-    }
-    __syncthreads();
-
-    const char* wq = wl + (q * MT + r) * 16;
-    for (int s = 0; s < ksteps; ++s) {
-      const int ko = koff[s * 4 + q];
-      frag_t a[MREP], b[NREP];
-#pragma unroll
-      for (int m = 0; m < MREP; ++m)
-        a[m] = *reinterpret_cast<const frag_t*>(wq + s * (4 * MT * 16) + m * 256);
-#pragma unroll
-      for (int n = 0; n < NREP; ++n)
-        b[n] = *reinterpret_cast<const frag_t*>(xl + ko + pixoff[n]);
-#pragma unroll
-      for (int m = 0; m < MREP; ++m)
-#pragma unroll
-        for (int n = 0; n < NREP; ++n) acc[m][n] = mfma16<T>(a[m], b[n], acc[m][n]);
-    }
-  }
-
-  // ---- epilogue: + bias (folded BN) [+ residual] [ReLU] -> 16-bit blocked / f32 NCHW ----
-  const int cout_planes = (p.cout + 7) >> 3;
-  const size_t HoWo = (size_t)p.Ho * p.Wo;
-#pragma unroll
-  for (int n = 0; n < NREP; ++n) {
-    const int pidx = (wave * NREP + n) * 16 + r;
-    if (pidx >= npix) continue;
-    const int y = pidx / p.tw, x = pidx - y * p.tw;
-    const int oy = oy0 + y, ox = ox0 + x;
-    if (oy >= p.Ho || ox >= p.Wo) continue;
-    const size_t opix = (size_t)oy * p.Wo + ox;
-#pragma unroll
-    for (int m = 0; m < MREP; ++m) {
-      const int co = mb * MT + m * 16 + q * 4;
-      if (co >= p.cout) continue;
-      const float4 bs = *reinterpret_cast<const float4*>(p.bias + co);
-      float v0 = acc[m][n][0] + bs.x, v1 = acc[m][n][1] + bs.y;
-      float v2 = acc[m][n][2] + bs.z, v3 = acc[m][n][3] + bs.w;
-      const size_t boff =
-          (((size_t)img * cout_planes + (co >> 3)) * HoWo + opix) * 16 + (co & 7) * 2;
-      if (p.res) {
-        const uint2 rv = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.res) + boff);
-        v0 += from_bits<T>(rv.x & 0xffff); v1 += from_bits<T>(rv.x >> 16);
-        v2 += from_bits<T>(rv.y & 0xffff); v3 += from_bits<T>(rv.y >> 16);
-      }
-      if (p.relu) {
-        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-      }
-      if (p.out_nchw_f32) {
-        float* o = static_cast<float*>(p.out) + ((size_t)img * p.cout + co) * HoWo + opix;
-        o[0] = v0;
-        if (co + 1 < p.cout) o[HoWo] = v1;
-        if (co + 2 < p.cout) o[2 * HoWo] = v2;
-        if (co + 3 < p.cout) o[3 * HoWo] = v3;
-      } else {
-        uint2 ov;
-        ov.x = (uint32_t)to_bits<T>(v0) | ((uint32_t)to_bits<T>(v1) << 16);
-        ov.y = (uint32_t)to_bits<T>(v2) | ((uint32_t)to_bits<T>(v3) << 16);
-        *reinterpret_cast<uint2*>(static_cast<char*>(p.out) + boff) = ov;
-      }
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -248,6 +85,13 @@ float host_16_to_f32(uint16_t v, int dtype) {
   return (float)h;
 }
 
+// MFMA accumulator row (4*(lane>>4) + reg) -> output channel within the 16-channel tile:
+// lane groups q = 0,2 (lanes l, l+32) share plane 0 (channels 0-3 | 4-7), q = 1,3 plane 1.
+static inline int conv_row_channel(int row) {
+  const int q = row >> 2, reg = row & 3;
+  return (q & 1) * 8 + (q >> 1) * 4 + reg;
+}
+
 size_t pack_conv_weights(const float* w, int cout, int cin, int ks, int mt, int cp, int dtype,
                          uint16_t* dst, int* nchunks_out, int* ksteps_full_out) {
   const int planes = cin / 8, kk = ks * ks;
@@ -273,7 +117,9 @@ size_t pack_conv_weights(const float* w, int cout, int cin, int ks, int mt, int 
           const int pp = pt / kk, tap = pt % kk;
           const int plane = plane0 + 2 * pp + (q & 1);
           for (int r = 0; r < mt; ++r) {
-            const int co = mb * mt + r;
+            // MFMA row rr of a 16-row tile carries channel conv_row_channel(rr): lanes l and l+32
+            // then hold the two halves of one 8-channel plane (16-byte epilogue stores)
+            const int co = mb * mt + (r & ~15) + conv_row_channel(r & 15);
             if (co >= cout) continue;
             uint16_t* d = base + ((size_t)(s * 4 + q) * mt + r) * 8;
             for (int j = 0; j < 8; ++j) {
@@ -302,7 +148,11 @@ int32_t conv_upload(const float* w, const float* bias, int cout, int cin, int ks
   std::vector<uint16_t> host(pc->wbytes / 2);
   pack_conv_weights(w, cout, cin, ks, pc->mt, pc->cp, dtype, host.data(), nullptr, nullptr);
   std::vector<float> hb((size_t)pc->n_mblk * pc->mt, 0.f);
-  if (bias) for (int i = 0; i < cout; ++i) hb[i] = bias[i];
+  if (bias)   // stored in packed (MFMA row) order, like the weight rows
+    for (size_t pos = 0; pos < hb.size(); ++pos) {
+      const int co = (int)(pos & ~(size_t)15) + conv_row_channel((int)(pos & 15));
+      if (co < cout) hb[pos] = bias[co];
+    }
   SCP_REQUIRE(conv_zero_page() != nullptr, "conv: cannot allocate the zero page");  // create-time, not in the launch path
   SCP_CHECK_HIP(hipMalloc(&pc->d_w, pc->wbytes));
   SCP_CHECK_HIP(hipMalloc(&pc->d_bias, hb.size() * sizeof(float)));
@@ -332,54 +182,6 @@ size_t conv_lds_bytes(const PackedConv& pc, int nrep, int th, int tw) {
          (size_t)pc.cp * plane_stride_for(pc.stride, hh, hw);
 }
 
-template <int T, int KS, int STRIDE, int MREP>
-static int32_t launch_nrep(int nrep, const ConvLaunch& L, size_t lds, hipStream_t st) {
-  dim3 grid(L.total_blocks), block(256);
-#define SCP_LAUNCH(NR)                                                                          \
-  case NR: {                                                                                    \
-    auto kern = conv_igemm_kernel<T, KS, STRIDE, MREP, NR>;                                      \
-    static bool big_lds_enabled = false; /* once per instantiation, outside any graph capture */\
-    if (!big_lds_enabled) {                                                                     \
-      SCP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                    \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize,             \
-                                        160 * 1024));                                           \
-      big_lds_enabled = true;                                                                   \
-    }                                                                                           \
-    hipLaunchKernelGGL(kern, grid, block, lds, st, L);                                          \
-    break;                                                                                      \
-  }
-  switch (nrep) {
-    SCP_LAUNCH(1) SCP_LAUNCH(2) SCP_LAUNCH(3) SCP_LAUNCH(4)
-    default: set_error("conv: nrep %d unsupported", nrep); return SCPOSE_E_INVALID;
-  }
-#undef SCP_LAUNCH
-  SCP_CHECK_HIP(hipGetLastError());
-  return SCPOSE_OK;
-}
-
-template <int T, int KS, int STRIDE>
-static int32_t launch_mrep(int mrep, int nrep, const ConvLaunch& L, size_t lds, hipStream_t st) {
-  switch (mrep) {
-    case 1: return launch_nrep<T, KS, STRIDE, 1>(nrep, L, lds, st);
-    case 2: return launch_nrep<T, KS, STRIDE, 2>(nrep, L, lds, st);
-    case 3: return launch_nrep<T, KS, STRIDE, 3>(nrep, L, lds, st);
-    case 4: return launch_nrep<T, KS, STRIDE, 4>(nrep, L, lds, st);
-    case 6: return launch_nrep<T, KS, STRIDE, 6>(nrep, L, lds, st);
-  }
-  set_error("conv: mrep %d unsupported", mrep);
-  return SCPOSE_E_INVALID;
-}
-
-template <int T>
-static int32_t launch_ks(int ks, int stride, int mrep, int nrep, const ConvLaunch& L, size_t lds,
-                         hipStream_t st) {
-  if (ks == 3 && stride == 1) return launch_mrep<T, 3, 1>(mrep, nrep, L, lds, st);
-  if (ks == 3 && stride == 2) return launch_mrep<T, 3, 2>(mrep, nrep, L, lds, st);
-  if (ks == 1 && stride == 1) return launch_mrep<T, 1, 1>(mrep, nrep, L, lds, st);
-  set_error("conv: k=%d stride=%d unsupported", ks, stride);
-  return SCPOSE_E_INVALID;
-}
-
 int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, const void* res,
                     int relu, int out_nchw_f32, void* out, hipStream_t stream) {
   SCP_REQUIRE(N > 0 && H > 0 && W > 0, "conv: bad shape N=%d H=%d W=%d", N, H, W);
@@ -406,17 +208,13 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
   SCP_REQUIRE(L.halo_h * L.halo_w <= (pc.stride == 1 ? 2 : 3) * 256, "conv: halo %dx%d too large",
               L.halo_h, L.halo_w);
   SCP_REQUIRE((pc.ksteps_full + 1) * 4 <= 64, "conv: k-offset table overflow (%d ksteps)", pc.ksteps_full);
-  static const bool force_v1 = getenv("SCPOSE_CONV_V1") != nullptr;   // A/B switch for development
-  if (!force_v1) {
-    bool fits = false;
-    const int32_t rc = conv_launch_pipe(pc, L, nrep, stream, &fits);
-    if (fits) return rc;
+  bool fits = false;
+  const int32_t rc = conv_launch_pipe(pc, L, nrep, stream, &fits);
+  if (!fits) {
+    set_error("conv: double-buffered LDS image of %d->%d k%d s%d does not fit 160 KiB", pc.cin, pc.cout, pc.ks, pc.stride);
+    return SCPOSE_E_INVALID;
   }
-  const size_t lds = conv_lds_bytes(pc, nrep, L.th, L.tw);
-  SCP_REQUIRE(lds <= 160 * 1024, "conv: LDS %zu bytes exceeds 160 KiB", lds);
-  if (pc.dtype == SCPOSE_DT_BF16)
-    return launch_ks<0>(pc.ks, pc.stride, pc.mrep, nrep, L, lds, stream);
-  return launch_ks<1>(pc.ks, pc.stride, pc.mrep, nrep, L, lds, stream);
+  return rc;
 }
 
 }  // namespace scpose

@@ -178,40 +178,78 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(const ConvLaunch p) {
       buf ^= 1;
     }
 
-    // ---- epilogue of item `it` ----
-    const int cout_planes = (p.cout + 7) >> 3;
-    const size_t HoWo = (size_t)p.Ho * p.Wo;
-#pragma unroll
-    for (int n = 0; n < NREP; ++n) {
-      if (py[n] < 0 || (p.dbg & 2)) continue;
-      const int oy = oy0 + py[n], ox = ox0 + px[n];
-      if (oy >= p.Ho || ox >= p.Wo) continue;
-      const size_t opix = (size_t)oy * p.Wo + ox;
+    // ---- epilogue of item `it`: + bias [+ residual] [ReLU] -> 16-byte (pixel, plane) stores ----
+    // Accumulator rows are channel-permuted at pack time (conv_row_channel) so that lanes l and
+    // l+32 hold the low/high 4 channels of the SAME 8-channel plane.  Two pixel tiles are
+    // processed together: one v_permlane32_swap per dword gives the lower half-wave all 8
+    // channels of tile n0's pixel and the upper half-wave all 8 of tile n1's, i.e. one aligned
+    // 16-byte slot of the blocked output per lane (8-byte half-slot stores ran ~4x slower).
+    if (!(p.dbg & 2)) {
+      const int cout_planes = (p.cout + 7) >> 3;
+      const size_t HoWo = (size_t)p.Ho * p.Wo;
+      const int half = lane >> 5, psel = q & 1;
 #pragma unroll
       for (int m = 0; m < MREP; ++m) {
-        const int co = mb * MT + m * 16 + q * 4;
-        if (co >= p.cout) continue;
-        const float4 bs = *reinterpret_cast<const float4*>(p.bias + co);
-        float v0 = acc[m][n][0] + bs.x, v1 = acc[m][n][1] + bs.y;
-        float v2 = acc[m][n][2] + bs.z, v3 = acc[m][n][3] + bs.w;
-        const size_t boff = (((size_t)img * cout_planes + (co >> 3)) * HoWo + opix) * 16 + (co & 7) * 2;
-        if (p.res) {
-          const uint2 rv = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.res) + boff);
-          v0 += from_bits<T>(rv.x & 0xffff); v1 += from_bits<T>(rv.x >> 16);
-          v2 += from_bits<T>(rv.y & 0xffff); v3 += from_bits<T>(rv.y >> 16);
+        const int co_plane = mb * MT + m * 16 + psel * 8;
+        const float4 bs = *reinterpret_cast<const float4*>(p.bias + mb * MT + m * 16 + q * 4);  // packed row order
+        if (p.out_nchw_f32) {   // final layer: few channels, float32 NCHW
+#pragma unroll
+          for (int n = 0; n < NREP; ++n) {
+            if (py[n] < 0) continue;
+            const int oy = oy0 + py[n], ox = ox0 + px[n];
+            if (oy >= p.Ho || ox >= p.Wo) continue;
+            const int co = co_plane + half * 4;
+            if (co >= p.cout) continue;
+            float v[4] = {acc[m][n][0] + bs.x, acc[m][n][1] + bs.y, acc[m][n][2] + bs.z, acc[m][n][3] + bs.w};
+            float* o = static_cast<float*>(p.out) + ((size_t)img * p.cout + co) * HoWo + (size_t)oy * p.Wo + ox;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (co + j < p.cout) o[j * HoWo] = p.relu ? fmaxf(v[j], 0.f) : v[j];
+          }
+          continue;
         }
-        if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-        if (p.out_nchw_f32) {
-          float* o = static_cast<float*>(p.out) + ((size_t)img * p.cout + co) * HoWo + opix;
-          o[0] = v0;
-          if (co + 1 < p.cout) o[HoWo] = v1;
-          if (co + 2 < p.cout) o[2 * HoWo] = v2;
-          if (co + 3 < p.cout) o[3 * HoWo] = v3;
-        } else {
-          uint2 ov;
-          ov.x = (uint32_t)to_bits<T>(v0) | ((uint32_t)to_bits<T>(v1) << 16);
-          ov.y = (uint32_t)to_bits<T>(v2) | ((uint32_t)to_bits<T>(v3) << 16);
-          *reinterpret_cast<uint2*>(static_cast<char*>(p.out) + boff) = ov;
+#pragma unroll
+        for (int n0 = 0; n0 < NREP; n0 += 2) {
+          constexpr int LASTN = NREP - 1;
+          const int n1 = n0 + 1 <= LASTN ? n0 + 1 : n0;     // odd NREP: last tile pairs with itself
+          const bool paired = n0 + 1 <= LASTN;
+          uint32_t a[4], b[4];
+          a[0] = __float_as_uint(acc[m][n0][0] + bs.x); a[1] = __float_as_uint(acc[m][n0][1] + bs.y);
+          a[2] = __float_as_uint(acc[m][n0][2] + bs.z); a[3] = __float_as_uint(acc[m][n0][3] + bs.w);
+          b[0] = __float_as_uint(acc[m][n1][0] + bs.x); b[1] = __float_as_uint(acc[m][n1][1] + bs.y);
+          b[2] = __float_as_uint(acc[m][n1][2] + bs.z); b[3] = __float_as_uint(acc[m][n1][3] + bs.w);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(a[j], b[j], false, false);
+            a[j] = sw[0]; b[j] = sw[1];
+          }
+          // lower half-wave: a = own (n0, ch 0-3), b = partner's (n0, ch 4-7)
+          // upper half-wave: a = partner's (n1, ch 0-3), b = own (n1, ch 4-7)
+          const int pyv = half ? py[n1] : py[n0], pxv = half ? px[n1] : px[n0];
+          if (pyv < 0 || (!paired && half) || co_plane >= p.cout) continue;
+          const int oy = oy0 + pyv, ox = ox0 + pxv;
+          if (oy >= p.Ho || ox >= p.Wo) continue;
+          const size_t boff = (((size_t)img * cout_planes + (co_plane >> 3)) * HoWo + (size_t)oy * p.Wo + ox) * 16;
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[j] = __uint_as_float(a[j]); v[4 + j] = __uint_as_float(b[j]); }
+          if (p.res) {
+            const uint4 rv = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.res) + boff);
+            v[0] += from_bits<T>(rv.x & 0xffff); v[1] += from_bits<T>(rv.x >> 16);
+            v[2] += from_bits<T>(rv.y & 0xffff); v[3] += from_bits<T>(rv.y >> 16);
+            v[4] += from_bits<T>(rv.z & 0xffff); v[5] += from_bits<T>(rv.z >> 16);
+            v[6] += from_bits<T>(rv.w & 0xffff); v[7] += from_bits<T>(rv.w >> 16);
+          }
+          if (p.relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+          uint4 ov;
+          ov.x = (uint32_t)to_bits<T>(v[0]) | ((uint32_t)to_bits<T>(v[1]) << 16);
+          ov.y = (uint32_t)to_bits<T>(v[2]) | ((uint32_t)to_bits<T>(v[3]) << 16);
+          ov.z = (uint32_t)to_bits<T>(v[4]) | ((uint32_t)to_bits<T>(v[5]) << 16);
+          ov.w = (uint32_t)to_bits<T>(v[6]) | ((uint32_t)to_bits<T>(v[7]) << 16);
+          *reinterpret_cast<uint4*>(static_cast<char*>(p.out) + boff) = ov;
         }
       }
     }
