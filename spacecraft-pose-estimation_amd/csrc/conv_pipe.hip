@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(const ConvLaunch p) {
   constexpr int MAXP = (STRIDE == 1) ? 2 : 3;
   constexpr int KK = KS * KS;
 
-  int* koff = reinterpret_cast<int*>(smem);   // [2][64]: full chunk, last chunk
+  int* koff = reinterpret_cast<int*>(smem);   // [2][64]: B-operand k-offsets of a full / the last chunk
   char* wl0 = smem + 512;
   char* xl0 = wl0 + 2 * p.lds_w;
 
@@ -48,19 +48,15 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(const ConvLaunch p) {
   const int planes_last = p.cin_planes - (p.nchunks - 1) * p.cp;
   const bool w_resident = p.nchunks == 1 && p.n_mblk == 1;
 
-  if (tid < 128) {  // K-offset tables (B-operand LDS byte offset of k-group q at k-step s)
+  if (tid < 128) {  // K-offset tables: LDS byte offset of k-group qq at k-step st (0 for padding)
     const int tbl = tid >> 6, e = tid & 63;
     const int planes = tbl ? planes_last : p.cp;
     const int npt = (planes >> 1) * KK;
-    const int s = e >> 2, qq = e & 3;
-    const int pt = 2 * s + (qq >> 1);
-    int off = 0;
-    if (pt < npt) {
-      const int pp = pt / KK, tap = pt - pp * KK;
-      const int ky = tap / KS, kx = tap - ky * KS;
-      off = (2 * pp + (qq & 1)) * p.plane_stride + (ky * p.halo_w + kx) * 16;
-    }
-    koff[tid] = off;
+    const int st = e >> 2, qq = e & 3;
+    const int pt = 2 * st + (qq >> 1);
+    const int pp = pt / KK, tap = pt - pp * KK;
+    const int ky = tap / KS, kx = tap - ky * KS;
+    koff[tid] = pt < npt ? (2 * pp + (qq & 1)) * p.plane_stride + (ky * p.halo_w + kx) * 16 : 0;
   }
 
   // tile-independent geometry of this thread's halo pixels and this lane's output pixels
@@ -129,26 +125,47 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(const ConvLaunch p) {
     }
   };
 
+  // ---- per-lane epilogue geometry (tile independent) ----
+  // Accumulator rows are channel-permuted at pack time (conv_row_channel) so that lanes l and
+  // l+32 hold the low/high 4 channels of the SAME 8-channel plane.  Two pixel tiles (n0, n1) are
+  // retired together: one v_permlane32_swap per dword gives the lower half-wave all 8 channels
+  // of its n0 pixel and the upper half-wave all 8 of its n1 pixel, i.e. one aligned 16-byte slot
+  // of the blocked tensor per lane (8-byte half-slot stores measured ~4x slower).
+  constexpr int NPAIR = (NREP + 1) / 2;
+  const int half = lane >> 5, psel = q & 1;
+  int epy[NPAIR], epx[NPAIR];
+#pragma unroll
+  for (int np = 0; np < NPAIR; ++np) {
+    const int n0 = 2 * np, n1 = (2 * np + 1 < NREP) ? 2 * np + 1 : 2 * np;
+    const bool paired = 2 * np + 1 < NREP;
+    epy[np] = half ? (paired ? py[n1] : -1) : py[n0];
+    epx[np] = half ? px[n1] : px[n0];
+  }
+  const int cout_planes = (p.cout + 7) >> 3;
+  const size_t HoWo = (size_t)p.Ho * p.Wo;
+
   f32x4 acc[MREP][NREP];
+  uint4 slot[MREP][NPAIR];    // the lane's 16-byte slots of the item being retired: residual in, result out
+  uint32_t ooff[MREP][NPAIR]; // byte offset of the slot inside the image (out and res share it), ~0 = masked
+
   int ld_it = it_begin, ld_c = 0;       // next stage to load
   bool w_loaded = false;
-  if (ld_it < it_end) {
-    issue(ld_it, ld_c, 0, true);
-    w_loaded = true;
-    if (++ld_c == p.nchunks) { ld_c = 0; ++ld_it; }
-  }
+  auto issue_next = [&](int buf) {
+    if (ld_it < it_end) {
+      issue(ld_it, ld_c, buf, !(w_resident && w_loaded));
+      w_loaded = true;
+      if (++ld_c == p.nchunks) { ld_c = 0; ++ld_it; }
+    }
+  };
+  issue_next(0);
+  issue_next(1);
+  __syncthreads();   // (vmcnt(0) + barrier) stages 0 and 1 have landed
+
   int buf = 0;
   for (int it = it_begin; it < it_end; ++it) {
     int mb, img, oy0, ox0;
     decode_item(it, mb, img, oy0, ox0);
     for (int c = 0; c < p.nchunks; ++c) {
-      // stage (it, c) has landed once every wave has drained its own DMA and passed the barrier;
-      // the same barrier retires all reads of the buffer the next stage is about to overwrite
-      __syncthreads();
-      if (ld_it < it_end) {
-        issue(ld_it, ld_c, buf ^ 1, !(w_resident && w_loaded));
-        if (++ld_c == p.nchunks) { ld_c = 0; ++ld_it; }
-      }
       if (c == 0) {
 #pragma unroll
         for (int m = 0; m < MREP; ++m)
@@ -156,102 +173,136 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(const ConvLaunch p) {
           for (int n = 0; n < NREP; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
       const bool last = c == p.nchunks - 1;
-      const int planes = last ? planes_last : p.cp;
-      const int ksteps = (((planes >> 1) * KK) + 1) >> 1;
-      const int* ko_tbl = koff + (last ? 64 : 0);
-      const char* xl = xl0 + buf * p.lds_x;
-      const char* wq = wl0 + (w_resident ? 0 : buf) * p.lds_w + (q * MT + r) * 16;
-      for (int s = 0; s < ((p.dbg & 1) ? 0 : ksteps); ++s) {
-        const int ko = ko_tbl[s * 4 + q];
-        frag_t a[MREP], b[NREP];
-#pragma unroll
-        for (int m = 0; m < MREP; ++m)
-          a[m] = *reinterpret_cast<const frag_t*>(wq + s * (4 * MT * 16) + m * 256);
-#pragma unroll
-        for (int n = 0; n < NREP; ++n)
-          b[n] = *reinterpret_cast<const frag_t*>(xl + ko + pixoff[n]);
-#pragma unroll
-        for (int m = 0; m < MREP; ++m)
-#pragma unroll
-          for (int n = 0; n < NREP; ++n) acc[m][n] = mfma16<T>(a[m], b[n], acc[m][n]);
-      }
-      buf ^= 1;
-    }
 
-    // ---- epilogue of item `it`: + bias [+ residual] [ReLU] -> 16-byte (pixel, plane) stores ----
-    // Accumulator rows are channel-permuted at pack time (conv_row_channel) so that lanes l and
-    // l+32 hold the low/high 4 channels of the SAME 8-channel plane.  Two pixel tiles are
-    // processed together: one v_permlane32_swap per dword gives the lower half-wave all 8
-    // channels of tile n0's pixel and the upper half-wave all 8 of tile n1's, i.e. one aligned
-    // 16-byte slot of the blocked output per lane (8-byte half-slot stores ran ~4x slower).
-    if (!(p.dbg & 2)) {
-      const int cout_planes = (p.cout + 7) >> 3;
-      const size_t HoWo = (size_t)p.Ho * p.Wo;
-      const int half = lane >> 5, psel = q & 1;
+      // residual slots of this item: issued before the MFMA loop, consumed after it
+      const size_t img_off = (size_t)img * cout_planes * HoWo * 16;
+      if (last) {
 #pragma unroll
-      for (int m = 0; m < MREP; ++m) {
-        const int co_plane = mb * MT + m * 16 + psel * 8;
-        const float4 bs = *reinterpret_cast<const float4*>(p.bias + mb * MT + m * 16 + q * 4);  // packed row order
-        if (p.out_nchw_f32) {   // final layer: few channels, float32 NCHW
+        for (int m = 0; m < MREP; ++m) {
+          const int co_plane = mb * MT + m * 16 + psel * 8;
 #pragma unroll
-          for (int n = 0; n < NREP; ++n) {
-            if (py[n] < 0) continue;
-            const int oy = oy0 + py[n], ox = ox0 + px[n];
-            if (oy >= p.Ho || ox >= p.Wo) continue;
-            const int co = co_plane + half * 4;
-            if (co >= p.cout) continue;
-            float v[4] = {acc[m][n][0] + bs.x, acc[m][n][1] + bs.y, acc[m][n][2] + bs.z, acc[m][n][3] + bs.w};
-            float* o = static_cast<float*>(p.out) + ((size_t)img * p.cout + co) * HoWo + (size_t)oy * p.Wo + ox;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (co + j < p.cout) o[j * HoWo] = p.relu ? fmaxf(v[j], 0.f) : v[j];
+          for (int np = 0; np < NPAIR; ++np) {
+            const int oy = oy0 + epy[np], ox = ox0 + epx[np];
+            const bool ok = epy[np] >= 0 && oy < p.Ho && ox < p.Wo && co_plane < p.cout && !p.out_nchw_f32 && !(p.dbg & 2);
+            ooff[m][np] = ok ? (uint32_t)((((size_t)(co_plane >> 3)) * HoWo + (size_t)oy * p.Wo + ox) * 16) : 0xffffffffu;
+            slot[m][np] = make_uint4(0, 0, 0, 0);
+            if (p.res && ok) slot[m][np] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.res) + img_off + ooff[m][np]);
           }
-          continue;
         }
+      }
+
+      {  // ---- MFMA loop over the chunk's k-steps: fragments one step ahead, k-offsets two ----
+        const int planes = last ? planes_last : p.cp;
+        const int npt = (planes >> 1) * KK;
+        const int ksteps = (p.dbg & 1) ? 0 : (npt + 1) >> 1;
+        const int klast = ksteps - 1;
+        const char* xl = xl0 + buf * p.lds_x;
+        const char* wq = wl0 + (w_resident ? 0 : buf) * p.lds_w + (q * MT + r) * 16;
+        const int* kt = koff + (last ? 64 : 0) + q;
+        frag_t a0[MREP], b0[NREP], a1[MREP], b1[NREP];
+        auto load_frags = [&](int st, int ko, frag_t* a, frag_t* b) {
 #pragma unroll
-        for (int n0 = 0; n0 < NREP; n0 += 2) {
-          constexpr int LASTN = NREP - 1;
-          const int n1 = n0 + 1 <= LASTN ? n0 + 1 : n0;     // odd NREP: last tile pairs with itself
-          const bool paired = n0 + 1 <= LASTN;
-          uint32_t a[4], b[4];
-          a[0] = __float_as_uint(acc[m][n0][0] + bs.x); a[1] = __float_as_uint(acc[m][n0][1] + bs.y);
-          a[2] = __float_as_uint(acc[m][n0][2] + bs.z); a[3] = __float_as_uint(acc[m][n0][3] + bs.w);
-          b[0] = __float_as_uint(acc[m][n1][0] + bs.x); b[1] = __float_as_uint(acc[m][n1][1] + bs.y);
-          b[2] = __float_as_uint(acc[m][n1][2] + bs.z); b[3] = __float_as_uint(acc[m][n1][3] + bs.w);
+          for (int m = 0; m < MREP; ++m) a[m] = *reinterpret_cast<const frag_t*>(wq + st * (4 * MT * 16) + m * 256);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(a[j], b[j], false, false);
-            a[j] = sw[0]; b[j] = sw[1];
+          for (int n = 0; n < NREP; ++n) b[n] = *reinterpret_cast<const frag_t*>(xl + ko + pixoff[n]);
+        };
+        auto mfmas = [&](const frag_t* a, const frag_t* b) {
+#pragma unroll
+          for (int m = 0; m < MREP; ++m)
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) acc[m][n] = mfma16<T>(a[m], b[n], acc[m][n]);
+        };
+        if (ksteps > 0) {
+          int ko_a = kt[0], ko_b = kt[4];              // steps 0 and 1 (the table is zero padded)
+          load_frags(0, ko_a, a0, b0);
+          int st = 0;
+          for (; st + 1 < ksteps; st += 2) {            // branch-free body: indices clamp instead
+            ko_a = kt[min(st + 2, klast) * 4];
+            load_frags(st + 1, ko_b, a1, b1);
+            mfmas(a0, b0);
+            ko_b = kt[min(st + 3, klast) * 4];
+            load_frags(min(st + 2, klast), ko_a, a0, b0);
+            mfmas(a1, b1);
           }
-          // lower half-wave: a = own (n0, ch 0-3), b = partner's (n0, ch 4-7)
-          // upper half-wave: a = partner's (n1, ch 0-3), b = own (n1, ch 4-7)
-          const int pyv = half ? py[n1] : py[n0], pxv = half ? px[n1] : px[n0];
-          if (pyv < 0 || (!paired && half) || co_plane >= p.cout) continue;
-          const int oy = oy0 + pyv, ox = ox0 + pxv;
-          if (oy >= p.Ho || ox >= p.Wo) continue;
-          const size_t boff = (((size_t)img * cout_planes + (co_plane >> 3)) * HoWo + (size_t)oy * p.Wo + ox) * 16;
-          float v[8];
+          if (ksteps & 1) mfmas(a0, b0);
+        }
+      }
+
+      if (last && !p.out_nchw_f32) {  // finalize the item into 16-byte slots (registers only)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { v[j] = __uint_as_float(a[j]); v[4 + j] = __uint_as_float(b[j]); }
-          if (p.res) {
-            const uint4 rv = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.res) + boff);
+        for (int m = 0; m < MREP; ++m) {
+          const float4 bs = *reinterpret_cast<const float4*>(p.bias + mb * MT + m * 16 + q * 4);  // packed row order
+#pragma unroll
+          for (int np = 0; np < NPAIR; ++np) {
+            const int n0 = 2 * np, n1 = (2 * np + 1 < NREP) ? 2 * np + 1 : 2 * np;
+            uint32_t a[4], b[4];
+            a[0] = __float_as_uint(acc[m][n0][0] + bs.x); a[1] = __float_as_uint(acc[m][n0][1] + bs.y);
+            a[2] = __float_as_uint(acc[m][n0][2] + bs.z); a[3] = __float_as_uint(acc[m][n0][3] + bs.w);
+            b[0] = __float_as_uint(acc[m][n1][0] + bs.x); b[1] = __float_as_uint(acc[m][n1][1] + bs.y);
+            b[2] = __float_as_uint(acc[m][n1][2] + bs.z); b[3] = __float_as_uint(acc[m][n1][3] + bs.w);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const auto sw = __builtin_amdgcn_permlane32_swap(a[j], b[j], false, false);
+              a[j] = sw[0]; b[j] = sw[1];
+            }
+            // lower half-wave: a = own (n0, ch 0-3), b = partner's (n0, ch 4-7)
+            // upper half-wave: a = partner's (n1, ch 0-3), b = own (n1, ch 4-7)
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = __uint_as_float(a[j]); v[4 + j] = __uint_as_float(b[j]); }
+            const uint4 rv = slot[m][np];
             v[0] += from_bits<T>(rv.x & 0xffff); v[1] += from_bits<T>(rv.x >> 16);
             v[2] += from_bits<T>(rv.y & 0xffff); v[3] += from_bits<T>(rv.y >> 16);
             v[4] += from_bits<T>(rv.z & 0xffff); v[5] += from_bits<T>(rv.z >> 16);
             v[6] += from_bits<T>(rv.w & 0xffff); v[7] += from_bits<T>(rv.w >> 16);
-          }
-          if (p.relu) {
+            if (p.relu) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+              for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+            uint4 ov;
+            ov.x = (uint32_t)to_bits<T>(v[0]) | ((uint32_t)to_bits<T>(v[1]) << 16);
+            ov.y = (uint32_t)to_bits<T>(v[2]) | ((uint32_t)to_bits<T>(v[3]) << 16);
+            ov.z = (uint32_t)to_bits<T>(v[4]) | ((uint32_t)to_bits<T>(v[5]) << 16);
+            ov.w = (uint32_t)to_bits<T>(v[6]) | ((uint32_t)to_bits<T>(v[7]) << 16);
+            slot[m][np] = ov;
           }
-          uint4 ov;
-          ov.x = (uint32_t)to_bits<T>(v[0]) | ((uint32_t)to_bits<T>(v[1]) << 16);
-          ov.y = (uint32_t)to_bits<T>(v[2]) | ((uint32_t)to_bits<T>(v[3]) << 16);
-          ov.z = (uint32_t)to_bits<T>(v[4]) | ((uint32_t)to_bits<T>(v[5]) << 16);
-          ov.w = (uint32_t)to_bits<T>(v[6]) | ((uint32_t)to_bits<T>(v[7]) << 16);
-          *reinterpret_cast<uint4*>(static_cast<char*>(p.out) + boff) = ov;
         }
       }
+
+      // One barrier per stage.  Its vmcnt(0) covers: stage s+1's DMA (in flight for a whole MFMA
+      // loop), the residual loads (already consumed) and the PREVIOUS item's stores.  After it
+      // every wave has finished reading `buf`, so stage s+2 may overwrite it.
+      __syncthreads();
+      issue_next(buf);
+
+      if (last) {
+        if (!p.out_nchw_f32) {   // the stores fly during the next stage's MFMA loop
+#pragma unroll
+          for (int m = 0; m < MREP; ++m)
+#pragma unroll
+            for (int np = 0; np < NPAIR; ++np)
+              if (ooff[m][np] != 0xffffffffu)
+                *reinterpret_cast<uint4*>(static_cast<char*>(p.out) + img_off + ooff[m][np]) = slot[m][np];
+        } else if (!(p.dbg & 2)) {   // final layer: few channels, float32 NCHW, 4-byte stores
+#pragma unroll
+          for (int m = 0; m < MREP; ++m) {
+            const int co = mb * MT + m * 16 + psel * 8 + half * 4;
+            const float4 bs = *reinterpret_cast<const float4*>(p.bias + mb * MT + m * 16 + q * 4);
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) {
+              if (py[n] < 0 || co >= p.cout) continue;
+              const int oy = oy0 + py[n], ox = ox0 + px[n];
+              if (oy >= p.Ho || ox >= p.Wo) continue;
+              const float v[4] = {acc[m][n][0] + bs.x, acc[m][n][1] + bs.y, acc[m][n][2] + bs.z, acc[m][n][3] + bs.w};
+              float* o = static_cast<float*>(p.out) + ((size_t)img * p.cout + co) * HoWo + (size_t)oy * p.Wo + ox;
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (co + j < p.cout) o[j * HoWo] = p.relu ? fmaxf(v[j], 0.f) : v[j];
+            }
+          }
+        }
+      }
+      buf ^= 1;
     }
   }
 }
