@@ -62,6 +62,8 @@ struct ConvLaunch {
   int32_t items_per_wg;
   int32_t grid;          // persistent workgroups
   int32_t lds_w, lds_x;  // bytes of one weight-chunk / input-chunk LDS buffer
+  int32_t lds_bias;      // bytes reserved for the bias vector in LDS
+  int32_t nbuf_w, nbuf_x;  // LDS buffers: weights 1 (resident) or 2, inputs 2 or 3
   int32_t dbg;           // development ablation bits (0 in production): 1 skip MFMA loop, 2 skip epilogue, 4 skip input DMA
 };
 
