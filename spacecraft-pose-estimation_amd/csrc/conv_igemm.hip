@@ -195,12 +195,37 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
   L.cout = pc.cout;
   int nrep;
   choose_tile(pc.ks, pc.stride, L.Ho, L.Wo, &nrep, &L.th, &L.tw);
-  L.tiles_x = (L.Wo + L.tw - 1) / L.tw;
-  L.tiles_y = (L.Ho + L.th - 1) / L.th;
   const int k2 = pc.ks / 2;
-  L.halo_h = (L.th - 1) * pc.stride + 1 + 2 * k2;
-  L.halo_w = (L.tw - 1) * pc.stride + 1 + 2 * k2;
-  L.plane_stride = plane_stride_for(pc.stride, L.halo_h, L.halo_w);
+  auto set_geometry = [&]() {
+    L.tiles_x = (L.Wo + L.tw - 1) / L.tw;
+    L.tiles_y = (L.Ho + L.th - 1) / L.th;
+    L.halo_h = (L.th - 1) * pc.stride + 1 + 2 * k2;
+    L.halo_w = (L.tw - 1) * pc.stride + 1 + 2 * k2;
+    L.plane_stride = plane_stride_for(pc.stride, L.halo_h, L.halo_w);
+    nrep = (L.th * L.tw + 63) / 64;
+  };
+  set_geometry();
+  const bool resident = pc.nchunks == 1 && pc.n_mblk == 1;
+  // Weight-resident layers are bound by HBM, not MFMA: prefer a tile small enough for TWO resident
+  // workgroups per CU (one streams while the other computes) over a big tile with one.
+  if (resident && 2 * conv_pipe_lds_bytes(pc, L.plane_stride) > 160 * 1024 && L.th % 2 == 0 && L.th * L.tw >= 128) {
+    const int th0 = L.th;
+    L.th /= 2;
+    set_geometry();
+    if (2 * conv_pipe_lds_bytes(pc, L.plane_stride) > 160 * 1024) { L.th = th0; set_geometry(); }
+  }
+  // Weight-streaming layers: stage each weight chunk once for a GROUP of nt pixel tiles.  Pick the
+  // smallest nt that brings the LDS-DMA demand (bytes staged per MFMA cycle of a wave) under what
+  // one CU sustains (~16 B/clk measured; 13 leaves headroom), within the accumulator register budget.
+  int nt = 1;
+  if (!resident && pc.ks == 3 && pc.stride == 1 && pc.mrep >= 4) {
+    const double wbytes = (double)pc.ksteps_full * 4 * pc.mt * 16, xbytes = (double)pc.cp * L.plane_stride;
+    const double cyc = (double)pc.ksteps_full * pc.mrep * nrep * 16;
+    for (nt = 1; nt < 3; ++nt) {
+      if ((wbytes + nt * xbytes) / (nt * cyc) <= 13.0) break;
+      if ((nt + 1) * pc.mrep * nrep * 4 > 224) break;
+    }
+  }
   L.cp = pc.cp; L.nchunks = pc.nchunks; L.ksteps_full = pc.ksteps_full;
   L.n_mblk = pc.n_mblk;
   L.relu = relu; L.out_nchw_f32 = out_nchw_f32;
@@ -208,13 +233,7 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
   SCP_REQUIRE(L.halo_h * L.halo_w <= (pc.stride == 1 ? 2 : 3) * 256, "conv: halo %dx%d too large",
               L.halo_h, L.halo_w);
   SCP_REQUIRE((pc.ksteps_full + 1) * 4 <= 64, "conv: k-offset table overflow (%d ksteps)", pc.ksteps_full);
-  bool fits = false;
-  const int32_t rc = conv_launch_pipe(pc, L, nrep, stream, &fits);
-  if (!fits) {
-    set_error("conv: double-buffered LDS image of %d->%d k%d s%d does not fit 160 KiB", pc.cin, pc.cout, pc.ks, pc.stride);
-    return SCPOSE_E_INVALID;
-  }
-  return rc;
+  return conv_launch_pipe(pc, L, nrep, nt, stream);
 }
 
 }  // namespace scpose

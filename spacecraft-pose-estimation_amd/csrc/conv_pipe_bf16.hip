@@ -1,0 +1,10 @@
+// bf16 instantiations of the pipelined convolution kernel (conv_pipe_kernel.h).
+#include <type_traits>
+
+#include "conv_pipe_kernel.h"
+
+namespace scpose {
+int32_t conv_pipe_dispatch_bf16(int ks, int stride, int mrep, int nrep, int nt, const ConvLaunch& L, size_t lds, hipStream_t st) {
+  return pipe_dispatch<0>(ks, stride, mrep, nrep, nt, L, lds, st);
+}
+}  // namespace scpose

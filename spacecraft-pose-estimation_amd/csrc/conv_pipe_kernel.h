@@ -1,0 +1,425 @@
+// Software-pipelined, persistent implicit-GEMM convolution kernel for gfx950 (MFMA 16x16x32).
+//
+// Replaces every nn.Conv2d + eval BatchNorm2d (+ReLU, +residual add) of the reference
+// landmark_regression/lib/models/pose_hrnet.py (conv3x3 :22-25, BasicBlock :41-57,
+// Bottleneck :78-98, transition :343-368, fuse down path :216-237, fuse 1x1 :199-205,
+// final_layer :323-329) except the 3-channel stem conv (stem.hip).
+//
+// GEMM view:  D[cout][pixel] = sum_k Wt[cout][k] * X[k][pixel],  k = (input plane, tap, 8 ch).
+//   * A operand = weights (M = Cout), B operand = activations (N = pixels): an accumulator lane
+//     holds 4 consecutive rows (channels) of ONE pixel, and a B fragment is exactly one 16-byte
+//     (pixel, 8-channel) vector of the blocked [N][C/8][H][W][8] input -- no transposes.
+//   * K order inside a chunk is (plane pair, tap); MFMA k-group q (lane>>4) reads plane
+//     2*pp + (q&1) at tap pt = 2*s + (q>>1).  The two k-groups that share a ds_read_b128 lane
+//     group differ by one whole LDS plane, whose stride is padded to keep them on disjoint banks.
+//   * Cout rows inside each 16-row MFMA tile are permuted at pack time so that lanes l and l+32
+//     hold the two halves of one 8-channel plane: the epilogue pairs two pixel tiles, swaps
+//     halves with v_permlane32_swap and stores aligned 16-byte slots (8-byte half-slot stores
+//     measured ~4x slower).
+//
+// Data movement (measured on MI355X: one CU fills LDS by LDS-DMA at ~16 B/clk from L2 and the
+// HBM share of a CU is ~10 B/clk, so the design minimises bytes staged per MFMA):
+//   * one or two resident workgroups per CU walk a contiguous range of work items; the XCD remap
+//     keeps a range inside one XCD's L2;
+//   * operands reach LDS by global_load_lds_dwordx4 (no staging registers), double buffered: the
+//     DMA of stage s+1 flies while the MFMAs of stage s run; one barrier per stage;
+//   * a work item is a GROUP of NT pixel tiles x one Cout block.  For each K-chunk the packed
+//     weights are staged ONCE and used for all NT tiles (NT accumulator sets in registers), which
+//     divides the dominant weight traffic of the wide low-resolution branches by NT; the next
+//     chunk's weights are streamed in NT slices, one per sub-stage, to keep every stage's DMA
+//     about the same size;
+//   * a layer whose whole K fits one chunk and whose Cout fits one block (the high-resolution
+//     branch) keeps its weights resident in LDS for the whole launch;
+//   * zero padding comes from a zero page (an out-of-image halo pixel's DMA source is redirected
+//     to 16 zero bytes); lanes past the halo tile are masked off (EXEC);
+//   * residual slots are prefetched (inline-asm loads, issued before the stage's DMA) and the
+//     results are finalised in registers before the stage barrier; the stores are issued after it
+//     and complete under the following stages.
+#pragma once
+#include "common.h"
+#include "conv_device.h"
+
+namespace scpose {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native vector: usable as an inline-asm operand
+
+__device__ __forceinline__ void dma16(const void* g, void* l_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)l_wave_base, 16, 0, 0);
+}
+
+template <int DT, int KS, int STRIDE, int MREP, int NREP, int NT>
+__global__ __launch_bounds__(256) void conv_pipe_kernel(const ConvLaunch p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename DtOf<DT>::type T;
+  typedef typename FragOf<T>::type frag_t;
+  constexpr int MT = 16 * MREP;
+  constexpr int MAXP = (STRIDE == 1) ? 2 : 3;
+  constexpr int KK = KS * KS;
+  constexpr int NPAIR = (NREP + 1) / 2;
+
+  // LDS: [k-offset tables 512 B][bias, packed row order][W buffers x nbuf_w][X buffers x 2]
+  int* koff = reinterpret_cast<int*>(smem);
+  float* bias_l = reinterpret_cast<float*>(smem + 512);
+  char* wl0 = smem + 512 + p.lds_bias;
+  char* xl0 = wl0 + p.nbuf_w * p.lds_w;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, r = lane & 15;
+  const int HW = p.H * p.W;
+  const int HP = p.halo_h * p.halo_w;
+  const int npix = p.th * p.tw;
+  const int planes_last = p.cin_planes - (p.nchunks - 1) * p.cp;
+  const bool w_resident = p.nbuf_w == 1;     // whole K in one chunk and one Cout block: weights stay in LDS
+
+  if (tid < 128) {  // K-offset tables: LDS byte offset of k-group qq at k-step st (0 for padding)
+    const int tbl = tid >> 6, e = tid & 63;
+    const int planes = tbl ? planes_last : p.cp;
+    const int npt = (planes >> 1) * KK;
+    const int st = e >> 2, qq = e & 3;
+    const int pt = 2 * st + (qq >> 1);
+    const int pp = pt / KK, tap = pt - pp * KK;
+    const int ky = tap / KS, kx = tap - ky * KS;
+    koff[tid] = pt < npt ? (2 * pp + (qq & 1)) * p.plane_stride + (ky * p.halo_w + kx) * 16 : 0;
+  }
+  for (int i = tid; i < p.n_mblk * MT; i += 256) bias_l[i] = p.bias[i];
+
+  // tile-independent geometry of this thread's halo pixels and this lane's output pixels
+  int hy[MAXP], hx[MAXP];
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int hp = i * 256 + tid;
+    hy[i] = hp < HP ? hp / p.halo_w : -1;
+    hx[i] = hp < HP ? hp - hy[i] * p.halo_w : 0;
+  }
+  int pixoff[NREP], py[NREP], px[NREP];
+#pragma unroll
+  for (int n = 0; n < NREP; ++n) {
+    const int pidx = (wave * NREP + n) * 16 + r;
+    if (pidx < npix) {
+      py[n] = pidx / p.tw; px[n] = pidx - py[n] * p.tw;
+      pixoff[n] = ((py[n] * STRIDE) * p.halo_w + px[n] * STRIDE) * 16;
+    } else {
+      py[n] = -1; px[n] = 0; pixoff[n] = 0;
+    }
+  }
+  const int half = lane >> 5, psel = q & 1;
+  int epy[NPAIR], epx[NPAIR];   // the pixel whose 16-byte slot this lane stores for tile pair np
+#pragma unroll
+  for (int np = 0; np < NPAIR; ++np) {
+    const int n0 = 2 * np, n1 = (2 * np + 1 < NREP) ? 2 * np + 1 : 2 * np;
+    const bool paired = 2 * np + 1 < NREP;
+    epy[np] = half ? (paired ? py[n1] : -1) : py[n0];
+    epx[np] = half ? px[n1] : px[n0];
+  }
+  const int cout_planes = (p.cout + 7) >> 3;
+  const size_t HoWo = (size_t)p.Ho * p.Wo;
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+
+  const int wg = xcd_remap(blockIdx.x, p.grid);
+  const int it_begin = wg * p.items_per_wg;
+  const int it_end = min(p.items_total, it_begin + p.items_per_wg);
+  const size_t chunk_wbytes = (size_t)p.ksteps_full * (4 * MT * 16);
+
+  // item -> (Cout block, first tile of the group); tile -> (image, tile origin); img < 0 = no tile
+  auto item_mb = [&](int it) { return it % p.n_mblk; };
+  auto decode_tile = [&](int it, int j, int& img, int& oy0, int& ox0) {
+    const int t = (it / p.n_mblk) * NT + j;
+    if (t >= p.tiles_total) { img = -1; oy0 = ox0 = 0; return; }
+    img = t / tiles_per_img;
+    const int rem = t - img * tiles_per_img;
+    const int ty = rem / p.tiles_x;
+    oy0 = ty * p.th; ox0 = (rem - ty * p.tiles_x) * p.tw;
+  };
+
+  // ---- LDS-DMA issue ----
+  auto issue_x = [&](int it, int j, int c, int xb) {       // input planes of chunk c for tile j of item it
+    int img, oy0, ox0;
+    decode_tile(it, j, img, oy0, ox0);
+    if (img < 0 || (p.dbg & 4)) return;
+    const int planes = c == p.nchunks - 1 ? planes_last : p.cp;
+    const int iy0 = oy0 * STRIDE - (KS / 2), ix0 = ox0 * STRIDE - (KS / 2);
+    const char* inb = static_cast<const char*>(p.in) + ((size_t)img * p.cin_planes + (size_t)c * p.cp) * HW * 16;
+    char* xl = xl0 + xb * p.lds_x;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      if (hy[i] >= 0) {
+        const int iy = iy0 + hy[i], ix = ix0 + hx[i];
+        const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const size_t g = ok ? (size_t)(iy * p.W + ix) * 16 : 0;
+        for (int pl = 0; pl < planes; ++pl) {
+          const char* src = ok ? inb + (size_t)pl * HW * 16 + g : static_cast<const char*>(p.zero16);
+          dma16(src, xl + pl * p.plane_stride + (i * 256 + wave * 64) * 16);
+        }
+      }
+    }
+  };
+  auto issue_w = [&](int it, int c, int wb, int part, int nparts) {   // slice `part` of nparts of a weight chunk
+    const int planes = c == p.nchunks - 1 ? planes_last : p.cp;
+    const int ksteps = (((planes >> 1) * KK) + 1) >> 1;
+    const int nbytes = ksteps * (4 * MT * 16);
+    const int slice = (((nbytes + nparts - 1) / nparts) + 4095) & ~4095;     // whole 4-KiB rounds of the workgroup
+    const int lo = part * slice, hi = min(nbytes, lo + slice);
+    const char* ws = static_cast<const char*>(p.wpk) + ((size_t)item_mb(it) * p.nchunks + c) * chunk_wbytes;
+    char* wl = wl0 + wb * p.lds_w;
+    for (int o = lo; o < hi; o += 4096) {
+      const int mine = o + tid * 16;
+      if (mine < hi) dma16(ws + mine, wl + o + wave * 1024);
+    }
+  };
+
+  float4 bsv[MREP];   // bias of the (single) Cout block stays in registers; several blocks: re-read per item
+#pragma unroll
+  for (int m = 0; m < MREP; ++m) bsv[m] = *reinterpret_cast<const float4*>(p.bias + m * 16 + q * 4);
+
+  f32x4 acc[NT][MREP][NREP];
+  u32x4 slot[MREP][NPAIR];    // 16-byte slots of the tile being retired: residual in, result out
+  uint32_t ooff[MREP][NPAIR]; // byte offset of the slot inside the image (out and res share it), ~0 = masked
+
+  // prologue: first weight chunk (whole) and the first input tile
+  int wc = 0;                 // running chunk counter of this workgroup: W buffer = wc & 1
+  if (it_begin < it_end) {
+    issue_w(it_begin, 0, 0, 0, 1);
+    issue_x(it_begin, 0, 0, 0);
+  }
+  __syncthreads();            // tables, bias, stage 0 (vmcnt(0) + barrier)
+
+  int xb = 0;                 // X buffer of the stage being computed
+  for (int it = it_begin; it < it_end; ++it) {
+    const int mb = item_mb(it);
+    for (int c = 0; c < p.nchunks; ++c, ++wc) {
+      const bool last = c == p.nchunks - 1;
+      // the chunk after this one (same item, or chunk 0 of the next item)
+      const int nit = last ? it + 1 : it, nc = last ? 0 : c + 1;
+      const bool have_next_chunk = nit < it_end;
+
+      auto stage = [&](auto jtag) {
+        constexpr int J = decltype(jtag)::value;
+        int img, oy0, ox0;
+        decode_tile(it, J, img, oy0, ox0);
+        const size_t img_off = (size_t)(img < 0 ? 0 : img) * cout_planes * HoWo * 16;
+        const bool retire = last && !p.out_nchw_f32;
+        if (c == 0) {
+#pragma unroll
+          for (int m = 0; m < MREP; ++m)
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) acc[J][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // (1) residual slots of this tile: inline-asm loads (hipcc must neither count nor wait for
+        //     them), issued before the DMA and consumed after the stage's wait
+        if (retire) {
+#pragma unroll
+          for (int m = 0; m < MREP; ++m) {
+            const int co_plane = mb * MT + m * 16 + psel * 8;
+#pragma unroll
+            for (int np = 0; np < NPAIR; ++np) {
+              const int oy = oy0 + epy[np], ox = ox0 + epx[np];
+              const bool ok = img >= 0 && epy[np] >= 0 && oy < p.Ho && ox < p.Wo && co_plane < p.cout && !(p.dbg & 2);
+              ooff[m][np] = ok ? (uint32_t)((((size_t)(co_plane >> 3)) * HoWo + (size_t)oy * p.Wo + ox) * 16) : 0xffffffffu;
+              slot[m][np] = u32x4{0u, 0u, 0u, 0u};
+            }
+          }
+          if (p.res) {
+#pragma unroll
+            for (int m = 0; m < MREP; ++m)
+#pragma unroll
+              for (int np = 0; np < NPAIR; ++np) {
+                const char* rp = ooff[m][np] != 0xffffffffu ? static_cast<const char*>(p.res) + img_off + ooff[m][np]
+                                                            : static_cast<const char*>(p.zero16);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(slot[m][np]) : "v"(rp) : "memory");
+              }
+          }
+        }
+        // (2) DMA for the next stage: its input tile, plus this sub-stage's slice of the next weight chunk
+        if (J + 1 < NT) issue_x(it, J + 1, c, xb ^ 1);
+        else if (have_next_chunk) issue_x(nit, 0, nc, xb ^ 1);
+        if (have_next_chunk && !w_resident) issue_w(nit, nc, (wc + 1) & 1, J, NT);
+
+        if (img >= 0) {  // (3) MFMA loop over the chunk's k-steps: fragments one step ahead, k-offsets two
+          const int planes = last ? planes_last : p.cp;
+          const int npt = (planes >> 1) * KK;
+          const int ksteps = (p.dbg & 1) ? 0 : (npt + 1) >> 1;
+          const int klast = ksteps - 1;
+          const char* xl = xl0 + xb * p.lds_x;
+          const char* wq = wl0 + (w_resident ? 0 : (wc & 1)) * p.lds_w + (q * MT + r) * 16;
+          const int* kt = koff + (last ? 64 : 0) + q;
+          frag_t a0[MREP], b0[NREP], a1[MREP], b1[NREP];
+          auto load_frags = [&](int st, int ko, frag_t* a, frag_t* b) {
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) a[m] = *reinterpret_cast<const frag_t*>(wq + st * (4 * MT * 16) + m * 256);
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) b[n] = *reinterpret_cast<const frag_t*>(xl + ko + pixoff[n]);
+          };
+          auto mfmas = [&](const frag_t* a, const frag_t* b) {
+#pragma unroll
+            for (int m = 0; m < MREP; ++m)
+#pragma unroll
+              for (int n = 0; n < NREP; ++n) acc[J][m][n] = mfma16<T>(a[m], b[n], acc[J][m][n]);
+          };
+          if (ksteps > 0) {
+            int ko_a = kt[0], ko_b = kt[4];              // steps 0 and 1 (the table is zero padded)
+            load_frags(0, ko_a, a0, b0);
+            int st = 0;
+            for (; st + 1 < ksteps; st += 2) {            // branch-free body: indices clamp instead
+              ko_a = kt[min(st + 2, klast) * 4];
+              load_frags(st + 1, ko_b, a1, b1);
+              mfmas(a0, b0);
+              ko_b = kt[min(st + 3, klast) * 4];
+              load_frags(min(st + 2, klast), ko_a, a0, b0);
+              mfmas(a1, b1);
+            }
+            if (ksteps & 1) mfmas(a0, b0);
+          }
+        }
+
+        // (4) next stage's operands have landed (this wave's share); residual loads too
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        if (retire) {  // (5) finalize the tile into 16-byte slots (registers only)
+#pragma unroll
+          for (int m = 0; m < MREP; ++m)
+#pragma unroll
+            for (int np = 0; np < NPAIR; ++np) asm volatile("" : "+v"(slot[m][np]));
+#pragma unroll
+          for (int m = 0; m < MREP; ++m) {
+            if (p.n_mblk > 1) bsv[m] = *reinterpret_cast<const float4*>(bias_l + mb * MT + m * 16 + q * 4);
+            const float4 bs = bsv[m];
+#pragma unroll
+            for (int np = 0; np < NPAIR; ++np) {
+              const int n0 = 2 * np, n1 = (2 * np + 1 < NREP) ? 2 * np + 1 : 2 * np;
+              uint32_t a[4], b[4];
+              a[0] = __float_as_uint(acc[J][m][n0][0] + bs.x); a[1] = __float_as_uint(acc[J][m][n0][1] + bs.y);
+              a[2] = __float_as_uint(acc[J][m][n0][2] + bs.z); a[3] = __float_as_uint(acc[J][m][n0][3] + bs.w);
+              b[0] = __float_as_uint(acc[J][m][n1][0] + bs.x); b[1] = __float_as_uint(acc[J][m][n1][1] + bs.y);
+              b[2] = __float_as_uint(acc[J][m][n1][2] + bs.z); b[3] = __float_as_uint(acc[J][m][n1][3] + bs.w);
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(a[jj], b[jj], false, false);
+                a[jj] = sw[0]; b[jj] = sw[1];
+              }
+              // lower half-wave: a = own (n0, ch 0-3), b = partner's (n0, ch 4-7)
+              // upper half-wave: a = partner's (n1, ch 0-3), b = own (n1, ch 4-7)
+              float v[8];
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) { v[jj] = __uint_as_float(a[jj]); v[4 + jj] = __uint_as_float(b[jj]); }
+              const u32x4 rv = slot[m][np];
+              v[0] += from_bits<T>(rv[0] & 0xffff); v[1] += from_bits<T>(rv[0] >> 16);
+              v[2] += from_bits<T>(rv[1] & 0xffff); v[3] += from_bits<T>(rv[1] >> 16);
+              v[4] += from_bits<T>(rv[2] & 0xffff); v[5] += from_bits<T>(rv[2] >> 16);
+              v[6] += from_bits<T>(rv[3] & 0xffff); v[7] += from_bits<T>(rv[3] >> 16);
+              if (p.relu) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v[jj] = fmaxf(v[jj], 0.f);
+              }
+              u32x4 ov;
+              ov[0] = (uint32_t)to_bits<T>(v[0]) | ((uint32_t)to_bits<T>(v[1]) << 16);
+              ov[1] = (uint32_t)to_bits<T>(v[2]) | ((uint32_t)to_bits<T>(v[3]) << 16);
+              ov[2] = (uint32_t)to_bits<T>(v[4]) | ((uint32_t)to_bits<T>(v[5]) << 16);
+              ov[3] = (uint32_t)to_bits<T>(v[6]) | ((uint32_t)to_bits<T>(v[7]) << 16);
+              slot[m][np] = ov;
+            }
+          }
+        }
+
+        // (6) one barrier per stage: every wave has drained its share of the next stage's DMA and
+        //     finished reading this stage's buffers, which the next issue may overwrite
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        if (last && img >= 0) {  // (7) stores complete under the following stages
+          if (retire) {
+#pragma unroll
+            for (int m = 0; m < MREP; ++m)
+#pragma unroll
+              for (int np = 0; np < NPAIR; ++np)
+                if (ooff[m][np] != 0xffffffffu)
+                  *reinterpret_cast<u32x4*>(static_cast<char*>(p.out) + img_off + ooff[m][np]) = slot[m][np];
+          } else if (!(p.dbg & 2)) {   // final layer: few channels, float32 NCHW, 4-byte stores
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+              const int co = mb * MT + m * 16 + psel * 8 + half * 4;
+              const float4 bs = *reinterpret_cast<const float4*>(bias_l + mb * MT + m * 16 + q * 4);
+#pragma unroll
+              for (int n = 0; n < NREP; ++n) {
+                if (py[n] < 0 || co >= p.cout) continue;
+                const int oy = oy0 + py[n], ox = ox0 + px[n];
+                if (oy >= p.Ho || ox >= p.Wo) continue;
+                const float v[4] = {acc[J][m][n][0] + bs.x, acc[J][m][n][1] + bs.y, acc[J][m][n][2] + bs.z, acc[J][m][n][3] + bs.w};
+                float* o = static_cast<float*>(p.out) + ((size_t)img * p.cout + co) * HoWo + (size_t)oy * p.Wo + ox;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                  if (co + jj < p.cout) o[jj * HoWo] = p.relu ? fmaxf(v[jj], 0.f) : v[jj];
+              }
+            }
+          }
+        }
+        xb ^= 1;
+      };
+
+      stage(std::integral_constant<int, 0>{});
+      if constexpr (NT > 1) stage(std::integral_constant<int, 1>{});
+      if constexpr (NT > 2) stage(std::integral_constant<int, 2>{});
+    }
+  }
+}
+
+// ---- launch dispatch (instantiated per dtype in conv_pipe_bf16.hip / conv_pipe_f16.hip) ----
+template <int DT, int KS, int STRIDE, int MREP, int NREP, int NT>
+int32_t pipe_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
+  auto kern = conv_pipe_kernel<DT, KS, STRIDE, MREP, NREP, NT>;
+  static bool big_lds_enabled = false;   // once per instantiation, outside any graph capture
+  if (!big_lds_enabled) {
+    SCP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    big_lds_enabled = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(L.grid), dim3(256), lds, st, L);
+  SCP_CHECK_HIP(hipGetLastError());
+  return SCPOSE_OK;
+}
+
+template <int DT, int KS, int STRIDE, int MREP, int NREP>
+int32_t pipe_nt(int nt, const ConvLaunch& L, size_t lds, hipStream_t st) {
+  if constexpr (KS == 3 && STRIDE == 1 && MREP >= 4) {
+    if (nt == 2) return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 2>(L, lds, st);
+    if (nt == 3) return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 3>(L, lds, st);
+  }
+  if (nt != 1) { set_error("conv: tile group %d unsupported for this variant", nt); return SCPOSE_E_INVALID; }
+  return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 1>(L, lds, st);
+}
+
+template <int DT, int KS, int STRIDE, int MREP>
+int32_t pipe_nrep(int nrep, int nt, const ConvLaunch& L, size_t lds, hipStream_t st) {
+  switch (nrep) {
+    case 1: return pipe_nt<DT, KS, STRIDE, MREP, 1>(nt, L, lds, st);
+    case 2: return pipe_nt<DT, KS, STRIDE, MREP, 2>(nt, L, lds, st);
+    case 3: return pipe_nt<DT, KS, STRIDE, MREP, 3>(nt, L, lds, st);
+    case 4: return pipe_nt<DT, KS, STRIDE, MREP, 4>(nt, L, lds, st);
+  }
+  set_error("conv: nrep %d unsupported", nrep);
+  return SCPOSE_E_INVALID;
+}
+
+template <int DT, int KS, int STRIDE>
+int32_t pipe_mrep(int mrep, int nrep, int nt, const ConvLaunch& L, size_t lds, hipStream_t st) {
+  switch (mrep) {
+    case 1: return pipe_nrep<DT, KS, STRIDE, 1>(nrep, nt, L, lds, st);
+    case 2: return pipe_nrep<DT, KS, STRIDE, 2>(nrep, nt, L, lds, st);
+    case 3: return pipe_nrep<DT, KS, STRIDE, 3>(nrep, nt, L, lds, st);
+    case 4: return pipe_nrep<DT, KS, STRIDE, 4>(nrep, nt, L, lds, st);
+    case 6: return pipe_nrep<DT, KS, STRIDE, 6>(nrep, nt, L, lds, st);
+  }
+  set_error("conv: mrep %d unsupported", mrep);
+  return SCPOSE_E_INVALID;
+}
+
+template <int DT>
+int32_t pipe_dispatch(int ks, int stride, int mrep, int nrep, int nt, const ConvLaunch& L, size_t lds, hipStream_t st) {
+  if (ks == 3 && stride == 1) return pipe_mrep<DT, 3, 1>(mrep, nrep, nt, L, lds, st);
+  if (ks == 3 && stride == 2) return pipe_mrep<DT, 3, 2>(mrep, nrep, nt, L, lds, st);
+  if (ks == 1 && stride == 1) return pipe_mrep<DT, 1, 1>(mrep, nrep, nt, L, lds, st);
+  set_error("conv: k=%d stride=%d unsupported", ks, stride);
+  return SCPOSE_E_INVALID;
+}
+
+}  // namespace scpose
