@@ -66,6 +66,7 @@ struct ConvLaunch {
   int32_t nbuf_w, nbuf_x;  // LDS buffers: weights 1 (resident) or 2, inputs 2 or 3
   int32_t tiles_total;   // N * tiles_x * tiles_y
   int32_t nt;            // pixel tiles per work item (share one staged weight chunk)
+  unsigned long long* dbg_buf;  // development: per-workgroup phase cycle sums (dbg & 8), else null
   int32_t dbg;           // development ablation bits (0 in production): 1 skip MFMA loop, 2 skip epilogue, 4 skip input DMA
 };
 

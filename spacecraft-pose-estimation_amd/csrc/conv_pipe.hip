@@ -1,7 +1,9 @@
 // Host glue of the pipelined convolution: zero page, persistent-grid sizing, dtype dispatch.
 // The kernel template lives in conv_pipe_kernel.h and is instantiated per storage type in
 // conv_pipe_bf16.hip / conv_pipe_f16.hip (two translation units so the build parallelises).
+#include <stdio.h>
 #include <stdlib.h>
+#include <vector>
 
 #include "common.h"
 
@@ -11,6 +13,8 @@ int32_t conv_pipe_dispatch_bf16(int ks, int stride, int mrep, int nrep, int nt, 
 int32_t conv_pipe_dispatch_f16(int ks, int stride, int mrep, int nrep, int nt, const ConvLaunch& L, size_t lds, hipStream_t st);
 
 static void* g_zero_page[16] = {nullptr};
+static unsigned long long* g_dbg_buf = nullptr;
+static int g_dbg_grid = 0;
 
 const void* conv_zero_page() {
   int dev = 0;
@@ -57,6 +61,13 @@ int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, 
   L.nt = nt;
   L.items_total = ((L.tiles_total + nt - 1) / nt) * pc.n_mblk;
   { static const char* e = getenv("SCPOSE_DBG"); L.dbg = e ? atoi(e) : 0; }
+  L.dbg_buf = nullptr;
+  if (L.dbg & 8) {   // development only: phase-cycle dump of the LAST launch, printed by scpose_dbg_dump()
+    static unsigned long long* buf = nullptr;
+    if (!buf) (void)hipMalloc(&buf, 2048 * 4 * 6 * 8);
+    L.dbg_buf = buf;
+    g_dbg_buf = buf; g_dbg_grid = 0;
+  }
   const int cus = device_cus();
   int per_cu = (int)((160 * 1024) / lds);
   per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
@@ -64,8 +75,24 @@ int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, 
   if (grid > L.items_total) grid = L.items_total;
   L.items_per_wg = (L.items_total + grid - 1) / grid;
   L.grid = (L.items_total + L.items_per_wg - 1) / L.items_per_wg;
+  g_dbg_grid = L.grid;
   if (pc.dtype == SCPOSE_DT_BF16) return conv_pipe_dispatch_bf16(pc.ks, pc.stride, pc.mrep, nrep, nt, L, lds, stream);
   return conv_pipe_dispatch_f16(pc.ks, pc.stride, pc.mrep, nrep, nt, L, lds, stream);
 }
 
 }  // namespace scpose
+
+// development helper (not part of include/scpose.h): mean cycles per phase of the last launch
+extern "C" void scpose_dbg_dump(void) {
+  using namespace scpose;
+  if (!g_dbg_buf || g_dbg_grid <= 0) return;
+  (void)hipDeviceSynchronize();
+  const int n = g_dbg_grid * 4 * 6;
+  std::vector<unsigned long long> h(n);
+  (void)hipMemcpy(h.data(), g_dbg_buf, n * 8, hipMemcpyDeviceToHost);
+  const char* names[6] = {"setup+residual+DMA issue", "MFMA loop", "vmcnt wait", "finalize", "barrier", "stores"};
+  double tot = 0, sum[6] = {0};
+  for (int i = 0; i < g_dbg_grid * 4; ++i) for (int k = 0; k < 6; ++k) sum[k] += (double)h[i * 6 + k];
+  for (int k = 0; k < 6; ++k) tot += sum[k];
+  for (int k = 0; k < 6; ++k) printf("  %-26s %10.0f cycles/wave  %5.1f%%\n", names[k], sum[k] / (g_dbg_grid * 4), 100 * sum[k] / tot);
+}

@@ -186,6 +186,9 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(const ConvLaunch p) {
   __syncthreads();            // tables, bias, stage 0 (vmcnt(0) + barrier)
 
   int xb = 0;                 // X buffer of the stage being computed
+  // development instrumentation (dbg & 8): cycles spent per phase, summed over the launch
+  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
+  auto now = [&]() -> unsigned long long { return (p.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull; };
   for (int it = it_begin; it < it_end; ++it) {
     const int mb = item_mb(it);
     for (int c = 0; c < p.nchunks; ++c, ++wc) {
@@ -196,6 +199,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(const ConvLaunch p) {
 
       auto stage = [&](auto jtag) {
         constexpr int J = decltype(jtag)::value;
+        const unsigned long long t0 = now();
         int img, oy0, ox0;
         decode_tile(it, J, img, oy0, ox0);
         const size_t img_off = (size_t)(img < 0 ? 0 : img) * cout_planes * HoWo * 16;
@@ -236,6 +240,7 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(const ConvLaunch p) {
         else if (have_next_chunk) issue_x(nit, 0, nc, xb ^ 1);
         if (have_next_chunk && !w_resident) issue_w(nit, nc, (wc + 1) & 1, J, NT);
 
+        const unsigned long long t1 = now();
         if (img >= 0) {  // (3) MFMA loop over the chunk's k-steps: fragments one step ahead, k-offsets two
           const int planes = last ? planes_last : p.cp;
           const int npt = (planes >> 1) * KK;
@@ -273,8 +278,10 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(const ConvLaunch p) {
           }
         }
 
+        const unsigned long long t2 = now();
         // (4) next stage's operands have landed (this wave's share); residual loads too
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t3 = now();
 
         if (retire) {  // (5) finalize the tile into 16-byte slots (registers only)
 #pragma unroll
@@ -324,8 +331,10 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(const ConvLaunch p) {
 
         // (6) one barrier per stage: every wave has drained its share of the next stage's DMA and
         //     finished reading this stage's buffers, which the next issue may overwrite
+        const unsigned long long t4 = now();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        const unsigned long long t5 = now();
 
         if (last && img >= 0) {  // (7) stores complete under the following stages
           if (retire) {
@@ -354,6 +363,10 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(const ConvLaunch p) {
             }
           }
         }
+        if (p.dbg & 8) {
+          const unsigned long long t6 = now();
+          tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; tph[3] += t4 - t3; tph[4] += t5 - t4; tph[5] += t6 - t5;
+        }
         xb ^= 1;
       };
 
@@ -362,6 +375,8 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(const ConvLaunch p) {
       if constexpr (NT > 2) stage(std::integral_constant<int, 2>{});
     }
   }
+  if ((p.dbg & 8) && p.dbg_buf && lane == 0)
+    for (int k = 0; k < 6; ++k) p.dbg_buf[((size_t)blockIdx.x * 4 + wave) * 6 + k] = tph[k];
 }
 
 // ---- launch dispatch (instantiated per dtype in conv_pipe_bf16.hip / conv_pipe_f16.hip) ----

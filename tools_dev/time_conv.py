@@ -21,4 +21,8 @@ en.record(); torch.cuda.synchronize()
 us = st.elapsed_time(en) / it * 1e3
 fl = 2.0 * cin * cout * k * k * Ho * Ho * N
 by = (cin * H * H + cout * Ho * Ho * (2 if res else 1)) * 2.0 * N
+if int(os.environ.get("SCPOSE_DBG", "0")) & 8:
+    ops.nat.lib()
+    import ctypes
+    ctypes.CDLL(ops.nat.LIB_PATH).scpose_dbg_dump()
 print("dbg=%s conv %d->%d k%d s%d %dx%d N=%d res=%d: %.1f us  %.1f TFLOP/s  %.0f GB/s" % (os.environ.get("SCPOSE_DBG", "0"), cin, cout, k, s, H, H, N, res, us, fl / us / 1e6, by / us / 1e3))
