@@ -107,7 +107,7 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
 size_t conv_lds_bytes(const PackedConv& pc, int nrep, int th, int tw);
 int plane_stride_for(int stride, int halo_h, int halo_w);
 // software-pipelined persistent kernel (conv_pipe_kernel.h); nt = pixel tiles per work item
-int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, hipStream_t stream);
+int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, int occ, hipStream_t stream);
 size_t conv_pipe_lds_bytes(const PackedConv& pc, int plane_stride);
 const void* conv_zero_page();   // lazily allocated 256 zero bytes on the current device
 

@@ -46,7 +46,9 @@ void choose_mrep_cp(int cin, int cout, int ks, int stride, int* mrep, int* cp) {
   int lim;
   if (ks == 1) lim = 8;
   else if (stride == 2) lim = (mr >= 4) ? 2 : 4;
-  else lim = (planes == 6) ? 6 : 4;
+  else if (planes <= 6 && mtiles == mr) lim = 6;   // whole K in one chunk, one Cout block: weights stay resident
+  else if (mr >= 4) lim = 2;                        // weight-streaming 3x3: small chunks so that TWO workgroups fit a CU
+  else lim = 4;
   int c = 2;
   for (int d = lim; d >= 2; d -= 2)
     if (planes % d == 0) { c = d; break; }
@@ -214,18 +216,29 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
     set_geometry();
     if (2 * conv_pipe_lds_bytes(pc, L.plane_stride) > 160 * 1024) { L.th = th0; set_geometry(); }
   }
-  // Weight-streaming layers: stage each weight chunk once for a GROUP of nt pixel tiles.  Pick the
-  // smallest nt that brings the LDS-DMA demand (bytes staged per MFMA cycle of a wave) under what
-  // one CU sustains (~16 B/clk measured; 13 leaves headroom), within the accumulator register budget.
-  int nt = 1;
+  // Weight-streaming 3x3 layers.  Measured on MI355X: a CU's LDS-DMA path moves ~16 B/clk and the
+  // issuing wave stalls for it, so (a) the bytes staged per MFMA must be small -- each weight chunk is
+  // staged once for a GROUP of nt pixel tiles -- and (b) two workgroups must share a CU so that one
+  // wave's DMA issue overlaps the other's MFMAs (2 waves per SIMD => <= 256 registers per wave).
+  int nt = 1, occ = 1;
   if (!resident && pc.ks == 3 && pc.stride == 1 && pc.mrep >= 4) {
-    const double wbytes = (double)pc.ksteps_full * 4 * pc.mt * 16, xbytes = (double)pc.cp * L.plane_stride;
-    const double cyc = (double)pc.ksteps_full * pc.mrep * nrep * 16;
-    for (nt = 1; nt < 3; ++nt) {
-      if ((wbytes + nt * xbytes) / (nt * cyc) <= 13.0) break;
-      if ((nt + 1) * pc.mrep * nrep * 4 > 224) break;
+    // shrink the tile (192 then 128 pixels) until two workgroups' LDS images fit one CU
+    for (int pt = 192; pt >= 128 && 2 * conv_pipe_lds_bytes(pc, L.plane_stride) > 160 * 1024; pt -= 64) {
+      if (L.th * L.tw <= pt) continue;
+      int th = L.th;
+      while (th > 1 && (th * L.tw > pt || L.Ho % th != 0)) --th;
+      if (th * L.tw <= pt) { L.th = th; set_geometry(); }
+    }
+    if (2 * conv_pipe_lds_bytes(pc, L.plane_stride) <= 160 * 1024) occ = 2;
+    const int acc_regs = pc.mrep * nrep * 4;
+    nt = (2 * acc_regs <= (occ == 2 ? 160 : 224)) ? 2 : 1;
+    if (occ == 1 && nt == 2 && 3 * acc_regs <= 224) {
+      const double wbytes = (double)pc.ksteps_full * 4 * pc.mt * 16, xbytes = (double)pc.cp * L.plane_stride;
+      const double cyc = (double)pc.ksteps_full * pc.mrep * nrep * 16;
+      if ((wbytes + 2 * xbytes) / (2 * cyc) > 13.0) nt = 3;
     }
   }
+  if (resident && 2 * conv_pipe_lds_bytes(pc, L.plane_stride) <= 160 * 1024) occ = 2;
   L.cp = pc.cp; L.nchunks = pc.nchunks; L.ksteps_full = pc.ksteps_full;
   L.n_mblk = pc.n_mblk;
   L.relu = relu; L.out_nchw_f32 = out_nchw_f32;
@@ -233,7 +246,7 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
   SCP_REQUIRE(L.halo_h * L.halo_w <= (pc.stride == 1 ? 2 : 3) * 256, "conv: halo %dx%d too large",
               L.halo_h, L.halo_w);
   SCP_REQUIRE((pc.ksteps_full + 1) * 4 <= 64, "conv: k-offset table overflow (%d ksteps)", pc.ksteps_full);
-  return conv_launch_pipe(pc, L, nrep, nt, stream);
+  return conv_launch_pipe(pc, L, nrep, nt, occ, stream);
 }
 
 }  // namespace scpose

@@ -9,8 +9,8 @@
 
 namespace scpose {
 
-int32_t conv_pipe_dispatch_bf16(int ks, int stride, int mrep, int nrep, int nt, const ConvLaunch& L, size_t lds, hipStream_t st);
-int32_t conv_pipe_dispatch_f16(int ks, int stride, int mrep, int nrep, int nt, const ConvLaunch& L, size_t lds, hipStream_t st);
+int32_t conv_pipe_dispatch_bf16(int ks, int stride, int mrep, int nrep, int nt, int occ, const ConvLaunch& L, size_t lds, hipStream_t st);
+int32_t conv_pipe_dispatch_f16(int ks, int stride, int mrep, int nrep, int nt, int occ, const ConvLaunch& L, size_t lds, hipStream_t st);
 
 static void* g_zero_page[16] = {nullptr};
 static unsigned long long* g_dbg_buf = nullptr;
@@ -47,7 +47,7 @@ size_t conv_pipe_lds_bytes(const PackedConv& pc, int plane_stride) {
   return 512 + lds_bias + (resident ? 1 : 2) * lds_w + 2 * (size_t)pc.cp * plane_stride;
 }
 
-int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, hipStream_t stream) {
+int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, int occ, hipStream_t stream) {
   L.lds_w = pc.ksteps_full * 4 * pc.mt * 16;
   L.lds_x = pc.cp * L.plane_stride;
   L.lds_bias = ((pc.n_mblk * pc.mt * 4) + 511) & ~511;
@@ -71,13 +71,14 @@ int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, 
   const int cus = device_cus();
   int per_cu = (int)((160 * 1024) / lds);
   per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+  if (occ < 2) per_cu = 1;   // the variant's register budget assumes one wave per SIMD
   int grid = cus * per_cu;
   if (grid > L.items_total) grid = L.items_total;
   L.items_per_wg = (L.items_total + grid - 1) / grid;
   L.grid = (L.items_total + L.items_per_wg - 1) / L.items_per_wg;
   g_dbg_grid = L.grid;
-  if (pc.dtype == SCPOSE_DT_BF16) return conv_pipe_dispatch_bf16(pc.ks, pc.stride, pc.mrep, nrep, nt, L, lds, stream);
-  return conv_pipe_dispatch_f16(pc.ks, pc.stride, pc.mrep, nrep, nt, L, lds, stream);
+  if (pc.dtype == SCPOSE_DT_BF16) return conv_pipe_dispatch_bf16(pc.ks, pc.stride, pc.mrep, nrep, nt, occ, L, lds, stream);
+  return conv_pipe_dispatch_f16(pc.ks, pc.stride, pc.mrep, nrep, nt, occ, L, lds, stream);
 }
 
 }  // namespace scpose

@@ -4,7 +4,7 @@
 #include "conv_pipe_kernel.h"
 
 namespace scpose {
-int32_t conv_pipe_dispatch_f16(int ks, int stride, int mrep, int nrep, int nt, const ConvLaunch& L, size_t lds, hipStream_t st) {
-  return pipe_dispatch<1>(ks, stride, mrep, nrep, nt, L, lds, st);
+int32_t conv_pipe_dispatch_f16(int ks, int stride, int mrep, int nrep, int nt, int occ, const ConvLaunch& L, size_t lds, hipStream_t st) {
+  return pipe_dispatch<1>(ks, stride, mrep, nrep, nt, occ, L, lds, st);
 }
 }  // namespace scpose

@@ -49,8 +49,10 @@ __device__ __forceinline__ void dma16(const void* g, void* l_wave_base) {
   __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)l_wave_base, 16, 0, 0);
 }
 
-template <int DT, int KS, int STRIDE, int MREP, int NREP, int NT>
-__global__ __launch_bounds__(256) void conv_pipe_kernel(const ConvLaunch p) {
+// OCC = resident workgroups per CU the variant is built for: 2 caps the wave at 256 registers
+// (two waves per SIMD, which also hide LDS latency, so the explicit fragment prefetch is dropped).
+template <int DT, int KS, int STRIDE, int MREP, int NREP, int NT, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_pipe_kernel(const ConvLaunch p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename DtOf<DT>::type T;
   typedef typename FragOf<T>::type frag_t;
@@ -262,7 +264,12 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(const ConvLaunch p) {
 #pragma unroll
               for (int n = 0; n < NREP; ++n) acc[J][m][n] = mfma16<T>(a[m], b[n], acc[J][m][n]);
           };
-          if (ksteps > 0) {
+          if constexpr (OCC >= 2) {
+            for (int st = 0; st < ksteps; ++st) {
+              load_frags(st, kt[st * 4], a0, b0);
+              mfmas(a0, b0);
+            }
+          } else if (ksteps > 0) {
             int ko_a = kt[0], ko_b = kt[4];              // steps 0 and 1 (the table is zero padded)
             load_frags(0, ko_a, a0, b0);
             int st = 0;
@@ -380,9 +387,9 @@ __global__ __launch_bounds__(256) void conv_pipe_kernel(const ConvLaunch p) {
 }
 
 // ---- launch dispatch (instantiated per dtype in conv_pipe_bf16.hip / conv_pipe_f16.hip) ----
-template <int DT, int KS, int STRIDE, int MREP, int NREP, int NT>
+template <int DT, int KS, int STRIDE, int MREP, int NREP, int NT, int OCC>
 int32_t pipe_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
-  auto kern = conv_pipe_kernel<DT, KS, STRIDE, MREP, NREP, NT>;
+  auto kern = conv_pipe_kernel<DT, KS, STRIDE, MREP, NREP, NT, OCC>;
   static bool big_lds_enabled = false;   // once per instantiation, outside any graph capture
   if (!big_lds_enabled) {
     SCP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -394,45 +401,47 @@ int32_t pipe_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
 }
 
 template <int DT, int KS, int STRIDE, int MREP, int NREP>
-int32_t pipe_nt(int nt, const ConvLaunch& L, size_t lds, hipStream_t st) {
+int32_t pipe_nt(int nt, int occ, const ConvLaunch& L, size_t lds, hipStream_t st) {
   if constexpr (KS == 3 && STRIDE == 1 && MREP >= 4) {
-    if (nt == 2) return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 2>(L, lds, st);
-    if (nt == 3) return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 3>(L, lds, st);
+    if (nt == 2 && occ == 2 && MREP * NREP * 8 <= 160) return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 2, 2>(L, lds, st);
+    if (nt == 2) return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 2, 1>(L, lds, st);
+    if (nt == 3 && MREP * NREP * 12 <= 224) return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 3, 1>(L, lds, st);
   }
   if (nt != 1) { set_error("conv: tile group %d unsupported for this variant", nt); return SCPOSE_E_INVALID; }
-  return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 1>(L, lds, st);
+  if (occ == 2 && MREP * NREP * 4 <= 128) return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 1, 2>(L, lds, st);
+  return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 1, 1>(L, lds, st);
 }
 
 template <int DT, int KS, int STRIDE, int MREP>
-int32_t pipe_nrep(int nrep, int nt, const ConvLaunch& L, size_t lds, hipStream_t st) {
+int32_t pipe_nrep(int nrep, int nt, int occ, const ConvLaunch& L, size_t lds, hipStream_t st) {
   switch (nrep) {
-    case 1: return pipe_nt<DT, KS, STRIDE, MREP, 1>(nt, L, lds, st);
-    case 2: return pipe_nt<DT, KS, STRIDE, MREP, 2>(nt, L, lds, st);
-    case 3: return pipe_nt<DT, KS, STRIDE, MREP, 3>(nt, L, lds, st);
-    case 4: return pipe_nt<DT, KS, STRIDE, MREP, 4>(nt, L, lds, st);
+    case 1: return pipe_nt<DT, KS, STRIDE, MREP, 1>(nt, occ, L, lds, st);
+    case 2: return pipe_nt<DT, KS, STRIDE, MREP, 2>(nt, occ, L, lds, st);
+    case 3: return pipe_nt<DT, KS, STRIDE, MREP, 3>(nt, occ, L, lds, st);
+    case 4: return pipe_nt<DT, KS, STRIDE, MREP, 4>(nt, occ, L, lds, st);
   }
   set_error("conv: nrep %d unsupported", nrep);
   return SCPOSE_E_INVALID;
 }
 
 template <int DT, int KS, int STRIDE>
-int32_t pipe_mrep(int mrep, int nrep, int nt, const ConvLaunch& L, size_t lds, hipStream_t st) {
+int32_t pipe_mrep(int mrep, int nrep, int nt, int occ, const ConvLaunch& L, size_t lds, hipStream_t st) {
   switch (mrep) {
-    case 1: return pipe_nrep<DT, KS, STRIDE, 1>(nrep, nt, L, lds, st);
-    case 2: return pipe_nrep<DT, KS, STRIDE, 2>(nrep, nt, L, lds, st);
-    case 3: return pipe_nrep<DT, KS, STRIDE, 3>(nrep, nt, L, lds, st);
-    case 4: return pipe_nrep<DT, KS, STRIDE, 4>(nrep, nt, L, lds, st);
-    case 6: return pipe_nrep<DT, KS, STRIDE, 6>(nrep, nt, L, lds, st);
+    case 1: return pipe_nrep<DT, KS, STRIDE, 1>(nrep, nt, occ, L, lds, st);
+    case 2: return pipe_nrep<DT, KS, STRIDE, 2>(nrep, nt, occ, L, lds, st);
+    case 3: return pipe_nrep<DT, KS, STRIDE, 3>(nrep, nt, occ, L, lds, st);
+    case 4: return pipe_nrep<DT, KS, STRIDE, 4>(nrep, nt, occ, L, lds, st);
+    case 6: return pipe_nrep<DT, KS, STRIDE, 6>(nrep, nt, occ, L, lds, st);
   }
   set_error("conv: mrep %d unsupported", mrep);
   return SCPOSE_E_INVALID;
 }
 
 template <int DT>
-int32_t pipe_dispatch(int ks, int stride, int mrep, int nrep, int nt, const ConvLaunch& L, size_t lds, hipStream_t st) {
-  if (ks == 3 && stride == 1) return pipe_mrep<DT, 3, 1>(mrep, nrep, nt, L, lds, st);
-  if (ks == 3 && stride == 2) return pipe_mrep<DT, 3, 2>(mrep, nrep, nt, L, lds, st);
-  if (ks == 1 && stride == 1) return pipe_mrep<DT, 1, 1>(mrep, nrep, nt, L, lds, st);
+int32_t pipe_dispatch(int ks, int stride, int mrep, int nrep, int nt, int occ, const ConvLaunch& L, size_t lds, hipStream_t st) {
+  if (ks == 3 && stride == 1) return pipe_mrep<DT, 3, 1>(mrep, nrep, nt, occ, L, lds, st);
+  if (ks == 3 && stride == 2) return pipe_mrep<DT, 3, 2>(mrep, nrep, nt, occ, L, lds, st);
+  if (ks == 1 && stride == 1) return pipe_mrep<DT, 1, 1>(mrep, nrep, nt, occ, L, lds, st);
   set_error("conv: k=%d stride=%d unsupported", ks, stride);
   return SCPOSE_E_INVALID;
 }
