@@ -65,7 +65,8 @@ struct ConvLaunch {
   int32_t lds_bias;      // bytes reserved for the bias vector in LDS
   int32_t nbuf_w, nbuf_x;  // LDS buffers: weights 1 (resident) or 2, inputs 2 or 3
   int32_t tiles_total;   // N * tiles_x * tiles_y
-  int32_t nt;            // pixel tiles per work item (share one staged weight chunk)
+  int32_t nt;            // pixel tiles per wave group processed one after the other on one staged weight chunk
+  int32_t groups;        // wave groups (256 threads each) working on different tiles in parallel (1 or 2)
   unsigned long long* dbg_buf;  // development: per-workgroup phase cycle sums (dbg & 8), else null
   int32_t dbg;           // development ablation bits (0 in production): 1 skip MFMA loop, 2 skip epilogue, 4 skip input DMA
 };
@@ -107,8 +108,8 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
 size_t conv_lds_bytes(const PackedConv& pc, int nrep, int th, int tw);
 int plane_stride_for(int stride, int halo_h, int halo_w);
 // software-pipelined persistent kernel (conv_pipe_kernel.h); nt = pixel tiles per work item
-int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, int occ, hipStream_t stream);
-size_t conv_pipe_lds_bytes(const PackedConv& pc, int plane_stride);
+int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, int occ, int groups, hipStream_t stream);
+size_t conv_pipe_lds_bytes(const PackedConv& pc, int plane_stride, int groups);
 const void* conv_zero_page();   // lazily allocated 256 zero bytes on the current device
 
 // ---- stem: 3 -> 64, 3x3 stride 2 from f32 NCHW or u8 NHWC ----------------------------------

@@ -210,35 +210,23 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
   const bool resident = pc.nchunks == 1 && pc.n_mblk == 1;
   // Weight-resident layers are bound by HBM, not MFMA: prefer a tile small enough for TWO resident
   // workgroups per CU (one streams while the other computes) over a big tile with one.
-  if (resident && 2 * conv_pipe_lds_bytes(pc, L.plane_stride) > 160 * 1024 && L.th % 2 == 0 && L.th * L.tw >= 128) {
+  if (resident && 2 * conv_pipe_lds_bytes(pc, L.plane_stride, 1) > 160 * 1024 && L.th % 2 == 0 && L.th * L.tw >= 128) {
     const int th0 = L.th;
     L.th /= 2;
     set_geometry();
-    if (2 * conv_pipe_lds_bytes(pc, L.plane_stride) > 160 * 1024) { L.th = th0; set_geometry(); }
+    if (2 * conv_pipe_lds_bytes(pc, L.plane_stride, 1) > 160 * 1024) { L.th = th0; set_geometry(); }
   }
   // Weight-streaming 3x3 layers.  Measured on MI355X: a CU's LDS-DMA path moves ~16 B/clk and the
-  // issuing wave stalls for it, so (a) the bytes staged per MFMA must be small -- each weight chunk is
-  // staged once for a GROUP of nt pixel tiles -- and (b) two workgroups must share a CU so that one
-  // wave's DMA issue overlaps the other's MFMAs (2 waves per SIMD => <= 256 registers per wave).
-  int nt = 1, occ = 1;
+  // issuing wave stalls for it.  So (a) the bytes staged per MFMA must be small: one staged weight
+  // chunk serves TWO pixel tiles; and (b) DMA issue must overlap MFMAs: the two tiles belong to two
+  // wave groups of one 512-thread workgroup (two waves per SIMD, <= 256 registers each).
+  int nt = 1, occ = 1, groups = 1;
   if (!resident && pc.ks == 3 && pc.stride == 1 && pc.mrep >= 4) {
-    // shrink the tile (192 then 128 pixels) until two workgroups' LDS images fit one CU
-    for (int pt = 192; pt >= 128 && 2 * conv_pipe_lds_bytes(pc, L.plane_stride) > 160 * 1024; pt -= 64) {
-      if (L.th * L.tw <= pt) continue;
-      int th = L.th;
-      while (th > 1 && (th * L.tw > pt || L.Ho % th != 0)) --th;
-      if (th * L.tw <= pt) { L.th = th; set_geometry(); }
-    }
-    if (2 * conv_pipe_lds_bytes(pc, L.plane_stride) <= 160 * 1024) occ = 2;
-    const int acc_regs = pc.mrep * nrep * 4;
-    nt = (2 * acc_regs <= (occ == 2 ? 160 : 224)) ? 2 : 1;
-    if (occ == 1 && nt == 2 && 3 * acc_regs <= 224) {
-      const double wbytes = (double)pc.ksteps_full * 4 * pc.mt * 16, xbytes = (double)pc.cp * L.plane_stride;
-      const double cyc = (double)pc.ksteps_full * pc.mrep * nrep * 16;
-      if ((wbytes + 2 * xbytes) / (2 * cyc) > 13.0) nt = 3;
-    }
+    groups = 2;
+    if (conv_pipe_lds_bytes(pc, L.plane_stride, 2) > 160 * 1024) groups = 1;
+    if (groups == 1 && 2 * pc.mrep * nrep * 4 <= 224) nt = 2;
   }
-  if (resident && 2 * conv_pipe_lds_bytes(pc, L.plane_stride) <= 160 * 1024) occ = 2;
+  if (resident && 2 * conv_pipe_lds_bytes(pc, L.plane_stride, 1) <= 160 * 1024) occ = 2;
   L.cp = pc.cp; L.nchunks = pc.nchunks; L.ksteps_full = pc.ksteps_full;
   L.n_mblk = pc.n_mblk;
   L.relu = relu; L.out_nchw_f32 = out_nchw_f32;
@@ -246,7 +234,7 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
   SCP_REQUIRE(L.halo_h * L.halo_w <= (pc.stride == 1 ? 2 : 3) * 256, "conv: halo %dx%d too large",
               L.halo_h, L.halo_w);
   SCP_REQUIRE((pc.ksteps_full + 1) * 4 <= 64, "conv: k-offset table overflow (%d ksteps)", pc.ksteps_full);
-  return conv_launch_pipe(pc, L, nrep, nt, occ, stream);
+  return conv_launch_pipe(pc, L, nrep, nt, occ, groups, stream);
 }
 
 }  // namespace scpose

@@ -40,26 +40,27 @@ static int device_cus() {
   return cus[dev];
 }
 
-size_t conv_pipe_lds_bytes(const PackedConv& pc, int plane_stride) {
+size_t conv_pipe_lds_bytes(const PackedConv& pc, int plane_stride, int groups) {
   const bool resident = pc.nchunks == 1 && pc.n_mblk == 1;
   const size_t lds_w = (size_t)pc.ksteps_full * 4 * pc.mt * 16;
   const size_t lds_bias = (((size_t)pc.n_mblk * pc.mt * 4) + 511) & ~(size_t)511;
-  return 512 + lds_bias + (resident ? 1 : 2) * lds_w + 2 * (size_t)pc.cp * plane_stride;
+  return 512 + lds_bias + (resident ? 1 : 2) * lds_w + 2 * (size_t)groups * pc.cp * plane_stride;
 }
 
-int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, int occ, hipStream_t stream) {
+int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, int occ, int groups, hipStream_t stream) {
   L.lds_w = pc.ksteps_full * 4 * pc.mt * 16;
   L.lds_x = pc.cp * L.plane_stride;
   L.lds_bias = ((pc.n_mblk * pc.mt * 4) + 511) & ~511;
   L.nbuf_w = (pc.nchunks == 1 && pc.n_mblk == 1) ? 1 : 2;
   L.nbuf_x = 2;
-  const size_t lds = conv_pipe_lds_bytes(pc, L.plane_stride);
+  const size_t lds = conv_pipe_lds_bytes(pc, L.plane_stride, groups);
+  L.groups = groups;
   SCP_REQUIRE(lds <= 160 * 1024, "conv: LDS image of %d->%d k%d s%d (%zu B) does not fit 160 KiB", pc.cin, pc.cout, pc.ks, pc.stride, lds);
   L.zero16 = conv_zero_page();
   SCP_REQUIRE(L.zero16, "conv: cannot allocate the zero page");
   L.tiles_total = L.N * L.tiles_x * L.tiles_y;
   L.nt = nt;
-  L.items_total = ((L.tiles_total + nt - 1) / nt) * pc.n_mblk;
+  L.items_total = ((L.tiles_total + nt * groups - 1) / (nt * groups)) * pc.n_mblk;
   { static const char* e = getenv("SCPOSE_DBG"); L.dbg = e ? atoi(e) : 0; }
   L.dbg_buf = nullptr;
   if (L.dbg & 8) {   // development only: phase-cycle dump of the LAST launch, printed by scpose_dbg_dump()
@@ -71,7 +72,7 @@ int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, 
   const int cus = device_cus();
   int per_cu = (int)((160 * 1024) / lds);
   per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
-  if (occ < 2) per_cu = 1;   // the variant's register budget assumes one wave per SIMD
+  if (occ < 2 || groups > 1) per_cu = 1;   // the variant's register budget assumes one workgroup per CU
   int grid = cus * per_cu;
   if (grid > L.items_total) grid = L.items_total;
   L.items_per_wg = (L.items_total + grid - 1) / grid;

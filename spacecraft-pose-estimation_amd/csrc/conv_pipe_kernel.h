@@ -51,8 +51,14 @@ __device__ __forceinline__ void dma16(const void* g, void* l_wave_base) {
 
 // OCC = resident workgroups per CU the variant is built for: 2 caps the wave at 256 registers
 // (two waves per SIMD, which also hide LDS latency, so the explicit fragment prefetch is dropped).
-template <int DT, int KS, int STRIDE, int MREP, int NREP, int NT, int OCC>
-__global__ __launch_bounds__(256, OCC) void conv_pipe_kernel(const ConvLaunch p) {
+// G = wave groups per workgroup (1 or 2; 256 threads each).  With G = 2 the two groups work on
+// two DIFFERENT pixel tiles in parallel from ONE staged copy of the weight chunk: the weight
+// bytes per MFMA halve like NT = 2, but with two waves per SIMD one group's DMA-issue stalls
+// (the LDS-DMA path accepts ~16 B/clk per CU and the issuing wave waits for it) overlap the
+// other group's MFMAs.
+template <int DT, int KS, int STRIDE, int MREP, int NREP, int NT, int OCC, int G>
+__global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(const ConvLaunch p) {
+  static_assert(G == 1 || NT == 1, "parallel tile groups and sequential tile groups are exclusive");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename DtOf<DT>::type T;
   typedef typename FragOf<T>::type frag_t;
@@ -67,7 +73,10 @@ __global__ __launch_bounds__(256, OCC) void conv_pipe_kernel(const ConvLaunch p)
   char* wl0 = smem + 512 + p.lds_bias;
   char* xl0 = wl0 + p.nbuf_w * p.lds_w;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave_all = threadIdx.x >> 6;           // 0 .. 4G-1: weight-chunk DMA is spread over all waves
+  const int grp = wave_all >> 2;                     // this wave's tile group
+  const int wave = wave_all & 3, tid = threadIdx.x & 255;   // position inside the group
   const int q = lane >> 4, r = lane & 15;
   const int HW = p.H * p.W;
   const int HP = p.halo_h * p.halo_w;
@@ -75,17 +84,17 @@ __global__ __launch_bounds__(256, OCC) void conv_pipe_kernel(const ConvLaunch p)
   const int planes_last = p.cin_planes - (p.nchunks - 1) * p.cp;
   const bool w_resident = p.nbuf_w == 1;     // whole K in one chunk and one Cout block: weights stay in LDS
 
-  if (tid < 128) {  // K-offset tables: LDS byte offset of k-group qq at k-step st (0 for padding)
-    const int tbl = tid >> 6, e = tid & 63;
+  if (threadIdx.x < 128) {  // K-offset tables: LDS byte offset of k-group qq at k-step st (0 for padding)
+    const int tbl = threadIdx.x >> 6, e = threadIdx.x & 63;
     const int planes = tbl ? planes_last : p.cp;
     const int npt = (planes >> 1) * KK;
     const int st = e >> 2, qq = e & 3;
     const int pt = 2 * st + (qq >> 1);
     const int pp = pt / KK, tap = pt - pp * KK;
     const int ky = tap / KS, kx = tap - ky * KS;
-    koff[tid] = pt < npt ? (2 * pp + (qq & 1)) * p.plane_stride + (ky * p.halo_w + kx) * 16 : 0;
+    koff[threadIdx.x] = pt < npt ? (2 * pp + (qq & 1)) * p.plane_stride + (ky * p.halo_w + kx) * 16 : 0;
   }
-  for (int i = tid; i < p.n_mblk * MT; i += 256) bias_l[i] = p.bias[i];
+  for (int i = threadIdx.x; i < p.n_mblk * MT; i += 256 * G) bias_l[i] = p.bias[i];
 
   // tile-independent geometry of this thread's halo pixels and this lane's output pixels
   int hy[MAXP], hx[MAXP];
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256, OCC) void conv_pipe_kernel(const ConvLaunch p)
   // item -> (Cout block, first tile of the group); tile -> (image, tile origin); img < 0 = no tile
   auto item_mb = [&](int it) { return it % p.n_mblk; };
   auto decode_tile = [&](int it, int j, int& img, int& oy0, int& ox0) {
-    const int t = (it / p.n_mblk) * NT + j;
+    const int t = (it / p.n_mblk) * (NT * G) + j + grp * NT;
     if (t >= p.tiles_total) { img = -1; oy0 = ox0 = 0; return; }
     img = t / tiles_per_img;
     const int rem = t - img * tiles_per_img;
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(256, OCC) void conv_pipe_kernel(const ConvLaunch p)
     const int planes = c == p.nchunks - 1 ? planes_last : p.cp;
     const int iy0 = oy0 * STRIDE - (KS / 2), ix0 = ox0 * STRIDE - (KS / 2);
     const char* inb = static_cast<const char*>(p.in) + ((size_t)img * p.cin_planes + (size_t)c * p.cp) * HW * 16;
-    char* xl = xl0 + xb * p.lds_x;
+    char* xl = xl0 + (grp * 2 + xb) * p.lds_x;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
       if (hy[i] >= 0) {
@@ -161,13 +170,13 @@ __global__ __launch_bounds__(256, OCC) void conv_pipe_kernel(const ConvLaunch p)
     const int planes = c == p.nchunks - 1 ? planes_last : p.cp;
     const int ksteps = (((planes >> 1) * KK) + 1) >> 1;
     const int nbytes = ksteps * (4 * MT * 16);
-    const int slice = (((nbytes + nparts - 1) / nparts) + 4095) & ~4095;     // whole 4-KiB rounds of the workgroup
+    const int slice = (((nbytes + nparts - 1) / nparts) + 4096 * G - 1) / (4096 * G) * (4096 * G);   // whole rounds of the workgroup
     const int lo = part * slice, hi = min(nbytes, lo + slice);
     const char* ws = static_cast<const char*>(p.wpk) + ((size_t)item_mb(it) * p.nchunks + c) * chunk_wbytes;
     char* wl = wl0 + wb * p.lds_w;
-    for (int o = lo; o < hi; o += 4096) {
-      const int mine = o + tid * 16;
-      if (mine < hi) dma16(ws + mine, wl + o + wave * 1024);
+    for (int o = lo; o < hi; o += 4096 * G) {
+      const int mine = o + (int)threadIdx.x * 16;
+      if (mine < hi) dma16(ws + mine, wl + o + wave_all * 1024);
     }
   };
 
@@ -248,7 +257,7 @@ __global__ __launch_bounds__(256, OCC) void conv_pipe_kernel(const ConvLaunch p)
           const int npt = (planes >> 1) * KK;
           const int ksteps = (p.dbg & 1) ? 0 : (npt + 1) >> 1;
           const int klast = ksteps - 1;
-          const char* xl = xl0 + xb * p.lds_x;
+          const char* xl = xl0 + (grp * 2 + xb) * p.lds_x;
           const char* wq = wl0 + (w_resident ? 0 : (wc & 1)) * p.lds_w + (q * MT + r) * 16;
           const int* kt = koff + (last ? 64 : 0) + q;
           frag_t a0[MREP], b0[NREP], a1[MREP], b1[NREP];
@@ -383,19 +392,19 @@ __global__ __launch_bounds__(256, OCC) void conv_pipe_kernel(const ConvLaunch p)
     }
   }
   if ((p.dbg & 8) && p.dbg_buf && lane == 0)
-    for (int k = 0; k < 6; ++k) p.dbg_buf[((size_t)blockIdx.x * 4 + wave) * 6 + k] = tph[k];
+    for (int k = 0; k < 6; ++k) p.dbg_buf[((size_t)blockIdx.x * 4 * G + wave_all) * 6 + k] = tph[k];
 }
 
 // ---- launch dispatch (instantiated per dtype in conv_pipe_bf16.hip / conv_pipe_f16.hip) ----
-template <int DT, int KS, int STRIDE, int MREP, int NREP, int NT, int OCC>
+template <int DT, int KS, int STRIDE, int MREP, int NREP, int NT, int OCC, int G = 1>
 int32_t pipe_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
-  auto kern = conv_pipe_kernel<DT, KS, STRIDE, MREP, NREP, NT, OCC>;
+  auto kern = conv_pipe_kernel<DT, KS, STRIDE, MREP, NREP, NT, OCC, G>;
   static bool big_lds_enabled = false;   // once per instantiation, outside any graph capture
   if (!big_lds_enabled) {
     SCP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     big_lds_enabled = true;
   }
-  hipLaunchKernelGGL(kern, dim3(L.grid), dim3(256), lds, st, L);
+  hipLaunchKernelGGL(kern, dim3(L.grid), dim3(256 * G), lds, st, L);
   SCP_CHECK_HIP(hipGetLastError());
   return SCPOSE_OK;
 }
@@ -403,6 +412,10 @@ int32_t pipe_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
 template <int DT, int KS, int STRIDE, int MREP, int NREP>
 int32_t pipe_nt(int nt, int occ, const ConvLaunch& L, size_t lds, hipStream_t st) {
   if constexpr (KS == 3 && STRIDE == 1 && MREP >= 4) {
+    if (L.groups == 2) {
+      if (nt != 1) { set_error("conv: parallel tile groups need nt = 1"); return SCPOSE_E_INVALID; }
+      return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 1, 1, 2>(L, lds, st);
+    }
     if (nt == 2 && occ == 2 && MREP * NREP * 8 <= 160) return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 2, 2>(L, lds, st);
     if (nt == 2) return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 2, 1>(L, lds, st);
     if (nt == 3 && MREP * NREP * 12 <= 224) return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 3, 1>(L, lds, st);
