@@ -104,25 +104,27 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
     hy[i] = hp < HP ? hp / p.halo_w : -1;
     hx[i] = hp < HP ? hp - hy[i] * p.halo_w : 0;
   }
-  int pixoff[NREP], py[NREP], px[NREP];
+  // pixel n-tile of this lane -> (y, x) inside the output tile, y = -1 past the tile
+  auto pix_yx = [&](int n, int& y, int& x) {
+    const int pidx = (wave * NREP + n) * 16 + r;
+    if (pidx < npix) { y = pidx / p.tw; x = pidx - y * p.tw; } else { y = -1; x = 0; }
+  };
+  int pixoff[NREP];
 #pragma unroll
   for (int n = 0; n < NREP; ++n) {
-    const int pidx = (wave * NREP + n) * 16 + r;
-    if (pidx < npix) {
-      py[n] = pidx / p.tw; px[n] = pidx - py[n] * p.tw;
-      pixoff[n] = ((py[n] * STRIDE) * p.halo_w + px[n] * STRIDE) * 16;
-    } else {
-      py[n] = -1; px[n] = 0; pixoff[n] = 0;
-    }
+    int y, x;
+    pix_yx(n, y, x);
+    pixoff[n] = y >= 0 ? ((y * STRIDE) * p.halo_w + x * STRIDE) * 16 : 0;
   }
   const int half = lane >> 5, psel = q & 1;
   int epy[NPAIR], epx[NPAIR];   // the pixel whose 16-byte slot this lane stores for tile pair np
 #pragma unroll
   for (int np = 0; np < NPAIR; ++np) {
-    const int n0 = 2 * np, n1 = (2 * np + 1 < NREP) ? 2 * np + 1 : 2 * np;
     const bool paired = 2 * np + 1 < NREP;
-    epy[np] = half ? (paired ? py[n1] : -1) : py[n0];
-    epx[np] = half ? px[n1] : px[n0];
+    int y, x;
+    pix_yx(half && paired ? 2 * np + 1 : 2 * np, y, x);
+    epy[np] = (half && !paired) ? -1 : y;
+    epx[np] = x;
   }
   const int cout_planes = (p.cout + 7) >> 3;
   const size_t HoWo = (size_t)p.Ho * p.Wo;
@@ -180,13 +182,24 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
     }
   };
 
-  float4 bsv[MREP];   // bias of the (single) Cout block stays in registers; several blocks: re-read per item
+  // bias: with the full register file (one wave per SIMD) a single Cout block's bias stays in
+  // registers for the whole launch; otherwise it is read from LDS when a tile retires
+  constexpr bool BIAS_REGS = (G == 1 && OCC == 1);
+  float4 bsv[BIAS_REGS ? MREP : 1];
+  if constexpr (BIAS_REGS) {
 #pragma unroll
-  for (int m = 0; m < MREP; ++m) bsv[m] = *reinterpret_cast<const float4*>(p.bias + m * 16 + q * 4);
+    for (int m = 0; m < MREP; ++m) bsv[m] = *reinterpret_cast<const float4*>(p.bias + m * 16 + q * 4);
+  }
 
   f32x4 acc[NT][MREP][NREP];
   u32x4 slot[MREP][NPAIR];    // 16-byte slots of the tile being retired: residual in, result out
-  uint32_t ooff[MREP][NPAIR]; // byte offset of the slot inside the image (out and res share it), ~0 = masked
+  // byte offset of the lane's slot (m, np) inside the image (out and res share it), ~0 = masked
+  auto slot_off = [&](int m, int np, int mb, int img, int oy0, int ox0) -> uint32_t {
+    const int co_plane = mb * MT + m * 16 + psel * 8;
+    const int oy = oy0 + epy[np], ox = ox0 + epx[np];
+    const bool ok = img >= 0 && epy[np] >= 0 && oy < p.Ho && ox < p.Wo && co_plane < p.cout && !(p.dbg & 2);
+    return ok ? (uint32_t)((((size_t)(co_plane >> 3)) * HoWo + (size_t)oy * p.Wo + ox) * 16) : 0xffffffffu;
+  };
 
   // prologue: first weight chunk (whole) and the first input tile
   int wc = 0;                 // running chunk counter of this workgroup: W buffer = wc & 1
@@ -225,23 +238,17 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
         //     them), issued before the DMA and consumed after the stage's wait
         if (retire) {
 #pragma unroll
-          for (int m = 0; m < MREP; ++m) {
-            const int co_plane = mb * MT + m * 16 + psel * 8;
+          for (int m = 0; m < MREP; ++m)
 #pragma unroll
-            for (int np = 0; np < NPAIR; ++np) {
-              const int oy = oy0 + epy[np], ox = ox0 + epx[np];
-              const bool ok = img >= 0 && epy[np] >= 0 && oy < p.Ho && ox < p.Wo && co_plane < p.cout && !(p.dbg & 2);
-              ooff[m][np] = ok ? (uint32_t)((((size_t)(co_plane >> 3)) * HoWo + (size_t)oy * p.Wo + ox) * 16) : 0xffffffffu;
-              slot[m][np] = u32x4{0u, 0u, 0u, 0u};
-            }
-          }
+            for (int np = 0; np < NPAIR; ++np) slot[m][np] = u32x4{0u, 0u, 0u, 0u};
           if (p.res) {
 #pragma unroll
             for (int m = 0; m < MREP; ++m)
 #pragma unroll
               for (int np = 0; np < NPAIR; ++np) {
-                const char* rp = ooff[m][np] != 0xffffffffu ? static_cast<const char*>(p.res) + img_off + ooff[m][np]
-                                                            : static_cast<const char*>(p.zero16);
+                const uint32_t off = slot_off(m, np, mb, img, oy0, ox0);
+                const char* rp = off != 0xffffffffu ? static_cast<const char*>(p.res) + img_off + off
+                                                    : static_cast<const char*>(p.zero16);
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(slot[m][np]) : "v"(rp) : "memory");
               }
           }
@@ -306,8 +313,13 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
             for (int np = 0; np < NPAIR; ++np) asm volatile("" : "+v"(slot[m][np]));
 #pragma unroll
           for (int m = 0; m < MREP; ++m) {
-            if (p.n_mblk > 1) bsv[m] = *reinterpret_cast<const float4*>(bias_l + mb * MT + m * 16 + q * 4);
-            const float4 bs = bsv[m];
+            float4 bs;
+            if constexpr (BIAS_REGS) {
+              if (p.n_mblk > 1) bsv[m] = *reinterpret_cast<const float4*>(bias_l + mb * MT + m * 16 + q * 4);
+              bs = bsv[m];
+            } else {
+              bs = *reinterpret_cast<const float4*>(bias_l + mb * MT + m * 16 + q * 4);
+            }
 #pragma unroll
             for (int np = 0; np < NPAIR; ++np) {
               const int n0 = 2 * np, n1 = (2 * np + 1 < NREP) ? 2 * np + 1 : 2 * np;
@@ -357,9 +369,10 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
 #pragma unroll
             for (int m = 0; m < MREP; ++m)
 #pragma unroll
-              for (int np = 0; np < NPAIR; ++np)
-                if (ooff[m][np] != 0xffffffffu)
-                  *reinterpret_cast<u32x4*>(static_cast<char*>(p.out) + img_off + ooff[m][np]) = slot[m][np];
+              for (int np = 0; np < NPAIR; ++np) {
+                const uint32_t off = slot_off(m, np, mb, img, oy0, ox0);
+                if (off != 0xffffffffu) *reinterpret_cast<u32x4*>(static_cast<char*>(p.out) + img_off + off) = slot[m][np];
+              }
           } else if (!(p.dbg & 2)) {   // final layer: few channels, float32 NCHW, 4-byte stores
 #pragma unroll
             for (int m = 0; m < MREP; ++m) {
@@ -367,8 +380,10 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
               const float4 bs = *reinterpret_cast<const float4*>(bias_l + mb * MT + m * 16 + q * 4);
 #pragma unroll
               for (int n = 0; n < NREP; ++n) {
-                if (py[n] < 0 || co >= p.cout) continue;
-                const int oy = oy0 + py[n], ox = ox0 + px[n];
+                int pyn, pxn;
+                pix_yx(n, pyn, pxn);
+                if (pyn < 0 || co >= p.cout) continue;
+                const int oy = oy0 + pyn, ox = ox0 + pxn;
                 if (oy >= p.Ho || ox >= p.Wo) continue;
                 const float v[4] = {acc[J][m][n][0] + bs.x, acc[J][m][n][1] + bs.y, acc[J][m][n][2] + bs.z, acc[J][m][n][3] + bs.w};
                 float* o = static_cast<float*>(p.out) + ((size_t)img * p.cout + co) * HoWo + (size_t)oy * p.Wo + ox;
