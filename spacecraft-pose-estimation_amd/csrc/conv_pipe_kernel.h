@@ -146,39 +146,56 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
     oy0 = ty * p.th; ox0 = (rem - ty * p.tiles_x) * p.tw;
   };
 
-  // ---- LDS-DMA issue ----
-  auto issue_x = [&](int it, int j, int c, int xb) {       // input planes of chunk c for tile j of item it
+  // ---- LDS-DMA plan of one stage: a weight slice and the input planes of one tile chunk ----
+  // The pieces (one wave-instruction = 1 KiB each) are NOT issued in one burst: the LDS-DMA path of
+  // a CU accepts ~16 B/clk and a wave that issues into a full queue stalls, MFMAs included.  They
+  // are fed into the MFMA loop of the stage before, a few per k-step, so the queue stays short and
+  // the copy runs underneath the matrix pipe.
+  struct DmaPlan {
+    const char* ws; char* wl; int w_lo, w_hi, nw;     // weight slice [w_lo, w_hi) of a packed chunk; nw rounds
+    const char* xsrc[MAXP]; bool xin[MAXP];           // this lane's source of plane 0, segment i (or the zero page)
+    char* xl; int planes, nx;                         // nx = planes * MAXP pieces (0: no tile)
+  };
+  auto plan_clear = [&](DmaPlan& d) { d.nw = 0; d.nx = 0; d.w_lo = d.w_hi = 0; d.planes = 1; };
+  auto plan_x = [&](DmaPlan& d, int it, int j, int c, int xb) {   // input planes of chunk c, tile j of item it
     int img, oy0, ox0;
     decode_tile(it, j, img, oy0, ox0);
     if (img < 0 || (p.dbg & 4)) return;
-    const int planes = c == p.nchunks - 1 ? planes_last : p.cp;
+    d.planes = c == p.nchunks - 1 ? planes_last : p.cp;
+    d.nx = d.planes * MAXP;
     const int iy0 = oy0 * STRIDE - (KS / 2), ix0 = ox0 * STRIDE - (KS / 2);
     const char* inb = static_cast<const char*>(p.in) + ((size_t)img * p.cin_planes + (size_t)c * p.cp) * HW * 16;
-    char* xl = xl0 + (grp * 2 + xb) * p.lds_x;
+    d.xl = xl0 + (grp * 2 + xb) * p.lds_x;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
-      if (hy[i] >= 0) {
-        const int iy = iy0 + hy[i], ix = ix0 + hx[i];
-        const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        const size_t g = ok ? (size_t)(iy * p.W + ix) * 16 : 0;
-        for (int pl = 0; pl < planes; ++pl) {
-          const char* src = ok ? inb + (size_t)pl * HW * 16 + g : static_cast<const char*>(p.zero16);
-          dma16(src, xl + pl * p.plane_stride + (i * 256 + wave * 64) * 16);
-        }
-      }
+      const int iy = iy0 + hy[i], ix = ix0 + hx[i];
+      d.xin[i] = hy[i] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      d.xsrc[i] = d.xin[i] ? inb + (size_t)(iy * p.W + ix) * 16 : static_cast<const char*>(p.zero16);
     }
   };
-  auto issue_w = [&](int it, int c, int wb, int part, int nparts) {   // slice `part` of nparts of a weight chunk
+  auto plan_w = [&](DmaPlan& d, int it, int c, int wb, int part, int nparts) {   // slice `part` of a weight chunk
     const int planes = c == p.nchunks - 1 ? planes_last : p.cp;
     const int ksteps = (((planes >> 1) * KK) + 1) >> 1;
     const int nbytes = ksteps * (4 * MT * 16);
     const int slice = (((nbytes + nparts - 1) / nparts) + 4096 * G - 1) / (4096 * G) * (4096 * G);   // whole rounds of the workgroup
-    const int lo = part * slice, hi = min(nbytes, lo + slice);
-    const char* ws = static_cast<const char*>(p.wpk) + ((size_t)item_mb(it) * p.nchunks + c) * chunk_wbytes;
-    char* wl = wl0 + wb * p.lds_w;
-    for (int o = lo; o < hi; o += 4096 * G) {
+    d.w_lo = part * slice; d.w_hi = min(nbytes, d.w_lo + slice);
+    d.nw = d.w_hi > d.w_lo ? (d.w_hi - d.w_lo + 4096 * G - 1) / (4096 * G) : 0;
+    d.ws = static_cast<const char*>(p.wpk) + ((size_t)item_mb(it) * p.nchunks + c) * chunk_wbytes;
+    d.wl = wl0 + wb * p.lds_w;
+  };
+  auto issue_piece = [&](const DmaPlan& d, int e) {
+    if (e < d.nw) {
+      const int o = d.w_lo + e * (4096 * G);
       const int mine = o + (int)threadIdx.x * 16;
-      if (mine < hi) dma16(ws + mine, wl + o + wave_all * 1024);
+      if (mine < d.w_hi) dma16(d.ws + mine, d.wl + o + wave_all * 1024);
+    } else if (e - d.nw < d.nx) {
+      const int x = e - d.nw;
+      const int i = x / d.planes, pl = x - i * d.planes;
+      const char* src = d.xsrc[0]; bool in = d.xin[0]; bool act = hy[0] >= 0;
+#pragma unroll
+      for (int k = 1; k < MAXP; ++k)
+        if (i == k) { src = d.xsrc[k]; in = d.xin[k]; act = hy[k] >= 0; }
+      if (act) dma16(in ? src + (size_t)pl * HW * 16 : src, d.xl + pl * p.plane_stride + (i * 256 + wave * 64) * 16);
     }
   };
 
@@ -204,8 +221,11 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
   // prologue: first weight chunk (whole) and the first input tile
   int wc = 0;                 // running chunk counter of this workgroup: W buffer = wc & 1
   if (it_begin < it_end) {
-    issue_w(it_begin, 0, 0, 0, 1);
-    issue_x(it_begin, 0, 0, 0);
+    DmaPlan d0;
+    plan_clear(d0);
+    plan_w(d0, it_begin, 0, 0, 0, 1);
+    plan_x(d0, it_begin, 0, 0, 0);
+    for (int e = 0; e < d0.nw + d0.nx; ++e) issue_piece(d0, e);
   }
   __syncthreads();            // tables, bias, stage 0 (vmcnt(0) + barrier)
 
@@ -253,10 +273,15 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
               }
           }
         }
-        // (2) DMA for the next stage: its input tile, plus this sub-stage's slice of the next weight chunk
-        if (J + 1 < NT) issue_x(it, J + 1, c, xb ^ 1);
-        else if (have_next_chunk) issue_x(nit, 0, nc, xb ^ 1);
-        if (have_next_chunk && !w_resident) issue_w(nit, nc, (wc + 1) & 1, J, NT);
+        // (2) DMA plan of the next stage: its input tile, plus this sub-stage's slice of the next weight
+        //     chunk.  The pieces are issued from inside the MFMA loop below.
+        DmaPlan dn;
+        plan_clear(dn);
+        if (J + 1 < NT) plan_x(dn, it, J + 1, c, xb ^ 1);
+        else if (have_next_chunk) plan_x(dn, nit, 0, nc, xb ^ 1);
+        if (have_next_chunk && !w_resident) plan_w(dn, nit, nc, (wc + 1) & 1, J, NT);
+        const int npieces = dn.nw + dn.nx;
+        int piece = 0;
 
         const unsigned long long t1 = now();
         if (img >= 0) {  // (3) MFMA loop over the chunk's k-steps: fragments one step ahead, k-offsets two
@@ -280,10 +305,18 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
 #pragma unroll
               for (int n = 0; n < NREP; ++n) acc[J][m][n] = mfma16<T>(a[m], b[n], acc[J][m][n]);
           };
-          if constexpr (OCC >= 2) {
+          // pieces per k-step: everything goes out in the first ~2/3 of the loop so that the tail of the
+          // loop covers the landing latency of the last piece
+          const int front = max(1, (2 * ksteps + 2) / 3);
+          const int quota = (npieces + front - 1) / front;
+          auto feed = [&]() {
+            for (int k = 0; k < quota && piece < npieces; ++k) issue_piece(dn, piece++);
+          };
+          if constexpr (OCC >= 2 || G == 2) {
             for (int st = 0; st < ksteps; ++st) {
               load_frags(st, kt[st * 4], a0, b0);
               mfmas(a0, b0);
+              feed();
             }
           } else if (ksteps > 0) {
             int ko_a = kt[0], ko_b = kt[4];              // steps 0 and 1 (the table is zero padded)
@@ -293,13 +326,16 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
               ko_a = kt[min(st + 2, klast) * 4];
               load_frags(st + 1, ko_b, a1, b1);
               mfmas(a0, b0);
+              feed();
               ko_b = kt[min(st + 3, klast) * 4];
               load_frags(min(st + 2, klast), ko_a, a0, b0);
               mfmas(a1, b1);
+              feed();
             }
             if (ksteps & 1) mfmas(a0, b0);
           }
         }
+        while (piece < npieces) issue_piece(dn, piece++);   // no tile / short loop: whatever is left
 
         const unsigned long long t2 = now();
         // (4) next stage's operands have landed (this wave's share); residual loads too
