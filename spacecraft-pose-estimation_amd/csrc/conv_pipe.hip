@@ -12,6 +12,9 @@ namespace scpose {
 int32_t conv_pipe_dispatch_bf16(int ks, int stride, int mrep, int nrep, int nt, int occ, const ConvLaunch& L, size_t lds, hipStream_t st);
 int32_t conv_pipe_dispatch_f16(int ks, int stride, int mrep, int nrep, int nt, int occ, const ConvLaunch& L, size_t lds, hipStream_t st);
 
+int32_t conv_stag_dispatch_bf16(int mrep, int nrep, const ConvLaunch& L, size_t lds, hipStream_t st);
+int32_t conv_stag_dispatch_f16(int mrep, int nrep, const ConvLaunch& L, size_t lds, hipStream_t st);
+
 static void* g_zero_page[16] = {nullptr};
 static unsigned long long* g_dbg_buf = nullptr;
 static int g_dbg_grid = 0;
@@ -44,7 +47,8 @@ size_t conv_pipe_lds_bytes(const PackedConv& pc, int plane_stride, int groups) {
   const bool resident = pc.nchunks == 1 && pc.n_mblk == 1;
   const size_t lds_w = (size_t)pc.ksteps_full * 4 * pc.mt * 16;
   const size_t lds_bias = (((size_t)pc.n_mblk * pc.mt * 4) + 511) & ~(size_t)511;
-  return 512 + lds_bias + (resident ? 1 : 2) * lds_w + 2 * (size_t)groups * pc.cp * plane_stride;
+  if (groups == 2) return 512 + lds_bias + 3 * lds_w + 4 * (size_t)pc.cp * plane_stride;   // staggered two-group schedule
+  return 512 + lds_bias + (resident ? 1 : 2) * lds_w + 2 * (size_t)pc.cp * plane_stride;
 }
 
 int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, int occ, int groups, hipStream_t stream) {
@@ -65,7 +69,8 @@ int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, 
   L.dbg_buf = nullptr;
   if (L.dbg & 8) {   // development only: phase-cycle dump of the LAST launch, printed by scpose_dbg_dump()
     static unsigned long long* buf = nullptr;
-    if (!buf) (void)hipMalloc(&buf, 2048 * 4 * 6 * 8);
+    if (!buf) (void)hipMalloc(&buf, 2048 * 8 * 6 * 8);
+    (void)hipMemsetAsync(buf, 0, 2048 * 8 * 6 * 8, stream);
     L.dbg_buf = buf;
     g_dbg_buf = buf; g_dbg_grid = 0;
   }
@@ -78,6 +83,10 @@ int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, 
   L.items_per_wg = (L.items_total + grid - 1) / grid;
   L.grid = (L.items_total + L.items_per_wg - 1) / L.items_per_wg;
   g_dbg_grid = L.grid;
+  if (groups == 2) {
+    if (pc.dtype == SCPOSE_DT_BF16) return conv_stag_dispatch_bf16(pc.mrep, nrep, L, lds, stream);
+    return conv_stag_dispatch_f16(pc.mrep, nrep, L, lds, stream);
+  }
   if (pc.dtype == SCPOSE_DT_BF16) return conv_pipe_dispatch_bf16(pc.ks, pc.stride, pc.mrep, nrep, nt, occ, L, lds, stream);
   return conv_pipe_dispatch_f16(pc.ks, pc.stride, pc.mrep, nrep, nt, occ, L, lds, stream);
 }
@@ -89,12 +98,13 @@ extern "C" void scpose_dbg_dump(void) {
   using namespace scpose;
   if (!g_dbg_buf || g_dbg_grid <= 0) return;
   (void)hipDeviceSynchronize();
-  const int n = g_dbg_grid * 4 * 6;
+  const int n = g_dbg_grid * 8 * 6;   // up to 8 waves per workgroup (unused slots stay zero)
   std::vector<unsigned long long> h(n);
   (void)hipMemcpy(h.data(), g_dbg_buf, n * 8, hipMemcpyDeviceToHost);
   const char* names[6] = {"setup+residual+DMA issue", "MFMA loop", "vmcnt wait", "finalize", "barrier", "stores"};
   double tot = 0, sum[6] = {0};
-  for (int i = 0; i < g_dbg_grid * 4; ++i) for (int k = 0; k < 6; ++k) sum[k] += (double)h[i * 6 + k];
+  int nw = 0;
+  for (int i = 0; i < g_dbg_grid * 8; ++i) { double t = 0; for (int k = 0; k < 6; ++k) { sum[k] += (double)h[i * 6 + k]; t += (double)h[i * 6 + k]; } nw += t > 0; }
   for (int k = 0; k < 6; ++k) tot += sum[k];
-  for (int k = 0; k < 6; ++k) printf("  %-26s %10.0f cycles/wave  %5.1f%%\n", names[k], sum[k] / (g_dbg_grid * 4), 100 * sum[k] / tot);
+  for (int k = 0; k < 6; ++k) printf("  %-26s %10.0f cycles/wave  %5.1f%%\n", names[k], sum[k] / (nw ? nw : 1), 100 * sum[k] / tot);
 }

@@ -147,10 +147,10 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
   };
 
   // ---- LDS-DMA plan of one stage: a weight slice and the input planes of one tile chunk ----
-  // The pieces (one wave-instruction = 1 KiB each) are NOT issued in one burst: the LDS-DMA path of
-  // a CU accepts ~16 B/clk and a wave that issues into a full queue stalls, MFMAs included.  They
-  // are fed into the MFMA loop of the stage before, a few per k-step, so the queue stays short and
-  // the copy runs underneath the matrix pipe.
+  // Measured on MI355X: the LDS-DMA path of a CU accepts ~16 B/clk and a wave that issues into a
+  // full queue stalls -- its MFMAs included (feeding the pieces into the MFMA loop a few per k-step
+  // made the loop 2.8x slower).  So the pieces of a stage are issued in one burst BEFORE the MFMA
+  // loop, and the overlap has to come from another wave on the same SIMD.
   struct DmaPlan {
     const char* ws; char* wl; int w_lo, w_hi, nw;     // weight slice [w_lo, w_hi) of a packed chunk; nw rounds
     const char* xsrc[MAXP]; bool xin[MAXP];           // this lane's source of plane 0, segment i (or the zero page)
@@ -280,8 +280,7 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
         if (J + 1 < NT) plan_x(dn, it, J + 1, c, xb ^ 1);
         else if (have_next_chunk) plan_x(dn, nit, 0, nc, xb ^ 1);
         if (have_next_chunk && !w_resident) plan_w(dn, nit, nc, (wc + 1) & 1, J, NT);
-        const int npieces = dn.nw + dn.nx;
-        int piece = 0;
+        for (int e = 0; e < dn.nw + dn.nx; ++e) issue_piece(dn, e);
 
         const unsigned long long t1 = now();
         if (img >= 0) {  // (3) MFMA loop over the chunk's k-steps: fragments one step ahead, k-offsets two
@@ -305,18 +304,10 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
 #pragma unroll
               for (int n = 0; n < NREP; ++n) acc[J][m][n] = mfma16<T>(a[m], b[n], acc[J][m][n]);
           };
-          // pieces per k-step: everything goes out in the first ~2/3 of the loop so that the tail of the
-          // loop covers the landing latency of the last piece
-          const int front = max(1, (2 * ksteps + 2) / 3);
-          const int quota = (npieces + front - 1) / front;
-          auto feed = [&]() {
-            for (int k = 0; k < quota && piece < npieces; ++k) issue_piece(dn, piece++);
-          };
           if constexpr (OCC >= 2 || G == 2) {
             for (int st = 0; st < ksteps; ++st) {
               load_frags(st, kt[st * 4], a0, b0);
               mfmas(a0, b0);
-              feed();
             }
           } else if (ksteps > 0) {
             int ko_a = kt[0], ko_b = kt[4];              // steps 0 and 1 (the table is zero padded)
@@ -326,16 +317,13 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
               ko_a = kt[min(st + 2, klast) * 4];
               load_frags(st + 1, ko_b, a1, b1);
               mfmas(a0, b0);
-              feed();
               ko_b = kt[min(st + 3, klast) * 4];
               load_frags(min(st + 2, klast), ko_a, a0, b0);
               mfmas(a1, b1);
-              feed();
             }
             if (ksteps & 1) mfmas(a0, b0);
           }
         }
-        while (piece < npieces) issue_piece(dn, piece++);   // no tile / short loop: whatever is left
 
         const unsigned long long t2 = now();
         // (4) next stage's operands have landed (this wave's share); residual loads too
@@ -443,7 +431,7 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
     }
   }
   if ((p.dbg & 8) && p.dbg_buf && lane == 0)
-    for (int k = 0; k < 6; ++k) p.dbg_buf[((size_t)blockIdx.x * 4 * G + wave_all) * 6 + k] = tph[k];
+    for (int k = 0; k < 6; ++k) p.dbg_buf[((size_t)blockIdx.x * 8 + wave_all) * 6 + k] = tph[k];
 }
 
 // ---- launch dispatch (instantiated per dtype in conv_pipe_bf16.hip / conv_pipe_f16.hip) ----
@@ -463,10 +451,6 @@ int32_t pipe_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
 template <int DT, int KS, int STRIDE, int MREP, int NREP>
 int32_t pipe_nt(int nt, int occ, const ConvLaunch& L, size_t lds, hipStream_t st) {
   if constexpr (KS == 3 && STRIDE == 1 && MREP >= 4) {
-    if (L.groups == 2) {
-      if (nt != 1) { set_error("conv: parallel tile groups need nt = 1"); return SCPOSE_E_INVALID; }
-      return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 1, 1, 2>(L, lds, st);
-    }
     if (nt == 2 && occ == 2 && MREP * NREP * 8 <= 160) return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 2, 2>(L, lds, st);
     if (nt == 2) return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 2, 1>(L, lds, st);
     if (nt == 3 && MREP * NREP * 12 <= 224) return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 3, 1>(L, lds, st);
