@@ -30,6 +30,11 @@
 //     about the same size;
 //   * a layer whose whole K fits one chunk and whose Cout fits one block (the high-resolution
 //     branch) keeps its weights resident in LDS for the whole launch;
+//   * measured: the LDS-DMA path of a CU accepts ~16 B/clk and a wave that issues into a full queue
+//     stalls, MFMAs included (feeding the pieces from inside the MFMA loop made the loop 2.8x
+//     slower), so a stage's pieces go out in one burst before the MFMA loop; the overlap comes from
+//     the second resident workgroup (weight-resident layers) or from the staggered two-group
+//     schedule of conv_stag_kernel.h (weight-streaming layers);
 //   * zero padding comes from a zero page (an out-of-image halo pixel's DMA source is redirected
 //     to 16 zero bytes); lanes past the halo tile are masked off (EXEC);
 //   * residual slots are prefetched (inline-asm loads, issued before the stage's DMA) and the
@@ -104,27 +109,25 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
     hy[i] = hp < HP ? hp / p.halo_w : -1;
     hx[i] = hp < HP ? hp - hy[i] * p.halo_w : 0;
   }
-  // pixel n-tile of this lane -> (y, x) inside the output tile, y = -1 past the tile
-  auto pix_yx = [&](int n, int& y, int& x) {
-    const int pidx = (wave * NREP + n) * 16 + r;
-    if (pidx < npix) { y = pidx / p.tw; x = pidx - y * p.tw; } else { y = -1; x = 0; }
-  };
-  int pixoff[NREP];
+  int pixoff[NREP], py[NREP], px[NREP];
 #pragma unroll
   for (int n = 0; n < NREP; ++n) {
-    int y, x;
-    pix_yx(n, y, x);
-    pixoff[n] = y >= 0 ? ((y * STRIDE) * p.halo_w + x * STRIDE) * 16 : 0;
+    const int pidx = (wave * NREP + n) * 16 + r;
+    if (pidx < npix) {
+      py[n] = pidx / p.tw; px[n] = pidx - py[n] * p.tw;
+      pixoff[n] = ((py[n] * STRIDE) * p.halo_w + px[n] * STRIDE) * 16;
+    } else {
+      py[n] = -1; px[n] = 0; pixoff[n] = 0;
+    }
   }
   const int half = lane >> 5, psel = q & 1;
   int epy[NPAIR], epx[NPAIR];   // the pixel whose 16-byte slot this lane stores for tile pair np
 #pragma unroll
   for (int np = 0; np < NPAIR; ++np) {
+    const int n0 = 2 * np, n1 = (2 * np + 1 < NREP) ? 2 * np + 1 : 2 * np;
     const bool paired = 2 * np + 1 < NREP;
-    int y, x;
-    pix_yx(half && paired ? 2 * np + 1 : 2 * np, y, x);
-    epy[np] = (half && !paired) ? -1 : y;
-    epx[np] = x;
+    epy[np] = half ? (paired ? py[n1] : -1) : py[n0];
+    epx[np] = half ? px[n1] : px[n0];
   }
   const int cout_planes = (p.cout + 7) >> 3;
   const size_t HoWo = (size_t)p.Ho * p.Wo;
@@ -146,86 +149,55 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
     oy0 = ty * p.th; ox0 = (rem - ty * p.tiles_x) * p.tw;
   };
 
-  // ---- LDS-DMA plan of one stage: a weight slice and the input planes of one tile chunk ----
-  // Measured on MI355X: the LDS-DMA path of a CU accepts ~16 B/clk and a wave that issues into a
-  // full queue stalls -- its MFMAs included (feeding the pieces into the MFMA loop a few per k-step
-  // made the loop 2.8x slower).  So the pieces of a stage are issued in one burst BEFORE the MFMA
-  // loop, and the overlap has to come from another wave on the same SIMD.
-  struct DmaPlan {
-    const char* ws; char* wl; int w_lo, w_hi, nw;     // weight slice [w_lo, w_hi) of a packed chunk; nw rounds
-    const char* xsrc[MAXP]; bool xin[MAXP];           // this lane's source of plane 0, segment i (or the zero page)
-    char* xl; int planes, nx;                         // nx = planes * MAXP pieces (0: no tile)
-  };
-  auto plan_clear = [&](DmaPlan& d) { d.nw = 0; d.nx = 0; d.w_lo = d.w_hi = 0; d.planes = 1; };
-  auto plan_x = [&](DmaPlan& d, int it, int j, int c, int xb) {   // input planes of chunk c, tile j of item it
+  // ---- LDS-DMA issue ----
+  auto issue_x = [&](int it, int j, int c, int xb) {       // input planes of chunk c for tile j of item it
     int img, oy0, ox0;
     decode_tile(it, j, img, oy0, ox0);
     if (img < 0 || (p.dbg & 4)) return;
-    d.planes = c == p.nchunks - 1 ? planes_last : p.cp;
-    d.nx = d.planes * MAXP;
+    const int planes = c == p.nchunks - 1 ? planes_last : p.cp;
     const int iy0 = oy0 * STRIDE - (KS / 2), ix0 = ox0 * STRIDE - (KS / 2);
     const char* inb = static_cast<const char*>(p.in) + ((size_t)img * p.cin_planes + (size_t)c * p.cp) * HW * 16;
-    d.xl = xl0 + (grp * 2 + xb) * p.lds_x;
+    char* xl = xl0 + (grp * 2 + xb) * p.lds_x;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
-      const int iy = iy0 + hy[i], ix = ix0 + hx[i];
-      d.xin[i] = hy[i] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      d.xsrc[i] = d.xin[i] ? inb + (size_t)(iy * p.W + ix) * 16 : static_cast<const char*>(p.zero16);
+      if (hy[i] >= 0) {
+        const int iy = iy0 + hy[i], ix = ix0 + hx[i];
+        const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const size_t g = ok ? (size_t)(iy * p.W + ix) * 16 : 0;
+        for (int pl = 0; pl < planes; ++pl) {
+          const char* src = ok ? inb + (size_t)pl * HW * 16 + g : static_cast<const char*>(p.zero16);
+          dma16(src, xl + pl * p.plane_stride + (i * 256 + wave * 64) * 16);
+        }
+      }
     }
   };
-  auto plan_w = [&](DmaPlan& d, int it, int c, int wb, int part, int nparts) {   // slice `part` of a weight chunk
+  auto issue_w = [&](int it, int c, int wb, int part, int nparts) {   // slice `part` of nparts of a weight chunk
     const int planes = c == p.nchunks - 1 ? planes_last : p.cp;
     const int ksteps = (((planes >> 1) * KK) + 1) >> 1;
     const int nbytes = ksteps * (4 * MT * 16);
     const int slice = (((nbytes + nparts - 1) / nparts) + 4096 * G - 1) / (4096 * G) * (4096 * G);   // whole rounds of the workgroup
-    d.w_lo = part * slice; d.w_hi = min(nbytes, d.w_lo + slice);
-    d.nw = d.w_hi > d.w_lo ? (d.w_hi - d.w_lo + 4096 * G - 1) / (4096 * G) : 0;
-    d.ws = static_cast<const char*>(p.wpk) + ((size_t)item_mb(it) * p.nchunks + c) * chunk_wbytes;
-    d.wl = wl0 + wb * p.lds_w;
-  };
-  auto issue_piece = [&](const DmaPlan& d, int e) {
-    if (e < d.nw) {
-      const int o = d.w_lo + e * (4096 * G);
+    const int lo = part * slice, hi = min(nbytes, lo + slice);
+    const char* ws = static_cast<const char*>(p.wpk) + ((size_t)item_mb(it) * p.nchunks + c) * chunk_wbytes;
+    char* wl = wl0 + wb * p.lds_w;
+    for (int o = lo; o < hi; o += 4096 * G) {
       const int mine = o + (int)threadIdx.x * 16;
-      if (mine < d.w_hi) dma16(d.ws + mine, d.wl + o + wave_all * 1024);
-    } else if (e - d.nw < d.nx) {
-      const int x = e - d.nw;
-      const int i = x / d.planes, pl = x - i * d.planes;
-      const char* src = d.xsrc[0]; bool in = d.xin[0]; bool act = hy[0] >= 0;
-#pragma unroll
-      for (int k = 1; k < MAXP; ++k)
-        if (i == k) { src = d.xsrc[k]; in = d.xin[k]; act = hy[k] >= 0; }
-      if (act) dma16(in ? src + (size_t)pl * HW * 16 : src, d.xl + pl * p.plane_stride + (i * 256 + wave * 64) * 16);
+      if (mine < hi) dma16(ws + mine, wl + o + wave_all * 1024);
     }
   };
 
-  // bias: with the full register file (one wave per SIMD) a single Cout block's bias stays in
-  // registers for the whole launch; otherwise it is read from LDS when a tile retires
-  constexpr bool BIAS_REGS = (G == 1 && OCC == 1);
-  float4 bsv[BIAS_REGS ? MREP : 1];
-  if constexpr (BIAS_REGS) {
+  float4 bsv[MREP];   // bias of the (single) Cout block stays in registers; several blocks: re-read per item
 #pragma unroll
-    for (int m = 0; m < MREP; ++m) bsv[m] = *reinterpret_cast<const float4*>(p.bias + m * 16 + q * 4);
-  }
+  for (int m = 0; m < MREP; ++m) bsv[m] = *reinterpret_cast<const float4*>(p.bias + m * 16 + q * 4);
 
   f32x4 acc[NT][MREP][NREP];
   u32x4 slot[MREP][NPAIR];    // 16-byte slots of the tile being retired: residual in, result out
-  // byte offset of the lane's slot (m, np) inside the image (out and res share it), ~0 = masked
-  auto slot_off = [&](int m, int np, int mb, int img, int oy0, int ox0) -> uint32_t {
-    const int co_plane = mb * MT + m * 16 + psel * 8;
-    const int oy = oy0 + epy[np], ox = ox0 + epx[np];
-    const bool ok = img >= 0 && epy[np] >= 0 && oy < p.Ho && ox < p.Wo && co_plane < p.cout && !(p.dbg & 2);
-    return ok ? (uint32_t)((((size_t)(co_plane >> 3)) * HoWo + (size_t)oy * p.Wo + ox) * 16) : 0xffffffffu;
-  };
+  uint32_t ooff[MREP][NPAIR]; // byte offset of the slot inside the image (out and res share it), ~0 = masked
 
   // prologue: first weight chunk (whole) and the first input tile
   int wc = 0;                 // running chunk counter of this workgroup: W buffer = wc & 1
   if (it_begin < it_end) {
-    DmaPlan d0;
-    plan_clear(d0);
-    plan_w(d0, it_begin, 0, 0, 0, 1);
-    plan_x(d0, it_begin, 0, 0, 0);
-    for (int e = 0; e < d0.nw + d0.nx; ++e) issue_piece(d0, e);
+    issue_w(it_begin, 0, 0, 0, 1);
+    issue_x(it_begin, 0, 0, 0);
   }
   __syncthreads();            // tables, bias, stage 0 (vmcnt(0) + barrier)
 
@@ -258,29 +230,31 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
         //     them), issued before the DMA and consumed after the stage's wait
         if (retire) {
 #pragma unroll
-          for (int m = 0; m < MREP; ++m)
+          for (int m = 0; m < MREP; ++m) {
+            const int co_plane = mb * MT + m * 16 + psel * 8;
 #pragma unroll
-            for (int np = 0; np < NPAIR; ++np) slot[m][np] = u32x4{0u, 0u, 0u, 0u};
+            for (int np = 0; np < NPAIR; ++np) {
+              const int oy = oy0 + epy[np], ox = ox0 + epx[np];
+              const bool ok = img >= 0 && epy[np] >= 0 && oy < p.Ho && ox < p.Wo && co_plane < p.cout && !(p.dbg & 2);
+              ooff[m][np] = ok ? (uint32_t)((((size_t)(co_plane >> 3)) * HoWo + (size_t)oy * p.Wo + ox) * 16) : 0xffffffffu;
+              slot[m][np] = u32x4{0u, 0u, 0u, 0u};
+            }
+          }
           if (p.res) {
 #pragma unroll
             for (int m = 0; m < MREP; ++m)
 #pragma unroll
               for (int np = 0; np < NPAIR; ++np) {
-                const uint32_t off = slot_off(m, np, mb, img, oy0, ox0);
-                const char* rp = off != 0xffffffffu ? static_cast<const char*>(p.res) + img_off + off
-                                                    : static_cast<const char*>(p.zero16);
+                const char* rp = ooff[m][np] != 0xffffffffu ? static_cast<const char*>(p.res) + img_off + ooff[m][np]
+                                                            : static_cast<const char*>(p.zero16);
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(slot[m][np]) : "v"(rp) : "memory");
               }
           }
         }
-        // (2) DMA plan of the next stage: its input tile, plus this sub-stage's slice of the next weight
-        //     chunk.  The pieces are issued from inside the MFMA loop below.
-        DmaPlan dn;
-        plan_clear(dn);
-        if (J + 1 < NT) plan_x(dn, it, J + 1, c, xb ^ 1);
-        else if (have_next_chunk) plan_x(dn, nit, 0, nc, xb ^ 1);
-        if (have_next_chunk && !w_resident) plan_w(dn, nit, nc, (wc + 1) & 1, J, NT);
-        for (int e = 0; e < dn.nw + dn.nx; ++e) issue_piece(dn, e);
+        // (2) DMA for the next stage: its input tile, plus this sub-stage's slice of the next weight chunk
+        if (J + 1 < NT) issue_x(it, J + 1, c, xb ^ 1);
+        else if (have_next_chunk) issue_x(nit, 0, nc, xb ^ 1);
+        if (have_next_chunk && !w_resident) issue_w(nit, nc, (wc + 1) & 1, J, NT);
 
         const unsigned long long t1 = now();
         if (img >= 0) {  // (3) MFMA loop over the chunk's k-steps: fragments one step ahead, k-offsets two
@@ -304,7 +278,7 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
 #pragma unroll
               for (int n = 0; n < NREP; ++n) acc[J][m][n] = mfma16<T>(a[m], b[n], acc[J][m][n]);
           };
-          if constexpr (OCC >= 2 || G == 2) {
+          if constexpr (OCC >= 2) {
             for (int st = 0; st < ksteps; ++st) {
               load_frags(st, kt[st * 4], a0, b0);
               mfmas(a0, b0);
@@ -337,13 +311,8 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
             for (int np = 0; np < NPAIR; ++np) asm volatile("" : "+v"(slot[m][np]));
 #pragma unroll
           for (int m = 0; m < MREP; ++m) {
-            float4 bs;
-            if constexpr (BIAS_REGS) {
-              if (p.n_mblk > 1) bsv[m] = *reinterpret_cast<const float4*>(bias_l + mb * MT + m * 16 + q * 4);
-              bs = bsv[m];
-            } else {
-              bs = *reinterpret_cast<const float4*>(bias_l + mb * MT + m * 16 + q * 4);
-            }
+            if (p.n_mblk > 1) bsv[m] = *reinterpret_cast<const float4*>(bias_l + mb * MT + m * 16 + q * 4);
+            const float4 bs = bsv[m];
 #pragma unroll
             for (int np = 0; np < NPAIR; ++np) {
               const int n0 = 2 * np, n1 = (2 * np + 1 < NREP) ? 2 * np + 1 : 2 * np;
@@ -393,10 +362,9 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
 #pragma unroll
             for (int m = 0; m < MREP; ++m)
 #pragma unroll
-              for (int np = 0; np < NPAIR; ++np) {
-                const uint32_t off = slot_off(m, np, mb, img, oy0, ox0);
-                if (off != 0xffffffffu) *reinterpret_cast<u32x4*>(static_cast<char*>(p.out) + img_off + off) = slot[m][np];
-              }
+              for (int np = 0; np < NPAIR; ++np)
+                if (ooff[m][np] != 0xffffffffu)
+                  *reinterpret_cast<u32x4*>(static_cast<char*>(p.out) + img_off + ooff[m][np]) = slot[m][np];
           } else if (!(p.dbg & 2)) {   // final layer: few channels, float32 NCHW, 4-byte stores
 #pragma unroll
             for (int m = 0; m < MREP; ++m) {
@@ -404,10 +372,8 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
               const float4 bs = *reinterpret_cast<const float4*>(bias_l + mb * MT + m * 16 + q * 4);
 #pragma unroll
               for (int n = 0; n < NREP; ++n) {
-                int pyn, pxn;
-                pix_yx(n, pyn, pxn);
-                if (pyn < 0 || co >= p.cout) continue;
-                const int oy = oy0 + pyn, ox = ox0 + pxn;
+                if (py[n] < 0 || co >= p.cout) continue;
+                const int oy = oy0 + py[n], ox = ox0 + px[n];
                 if (oy >= p.Ho || ox >= p.Wo) continue;
                 const float v[4] = {acc[J][m][n][0] + bs.x, acc[J][m][n][1] + bs.y, acc[J][m][n][2] + bs.z, acc[J][m][n][3] + bs.w};
                 float* o = static_cast<float*>(p.out) + ((size_t)img * p.cout + co) * HoWo + (size_t)oy * p.Wo + ox;

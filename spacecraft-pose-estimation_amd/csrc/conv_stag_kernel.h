@@ -32,6 +32,20 @@
 
 namespace scpose {
 
+// s_waitcnt takes an immediate: a wave-uniform runtime count goes through a switch.
+#define SCP_WAITVM_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+__device__ __forceinline__ void wait_vm(int n) {
+  switch (n) {
+    SCP_WAITVM_CASE(0) SCP_WAITVM_CASE(1) SCP_WAITVM_CASE(2) SCP_WAITVM_CASE(3) SCP_WAITVM_CASE(4)
+    SCP_WAITVM_CASE(5) SCP_WAITVM_CASE(6) SCP_WAITVM_CASE(7) SCP_WAITVM_CASE(8) SCP_WAITVM_CASE(9)
+    SCP_WAITVM_CASE(10) SCP_WAITVM_CASE(11) SCP_WAITVM_CASE(12) SCP_WAITVM_CASE(13) SCP_WAITVM_CASE(14)
+    SCP_WAITVM_CASE(15) SCP_WAITVM_CASE(16) SCP_WAITVM_CASE(17) SCP_WAITVM_CASE(18) SCP_WAITVM_CASE(19)
+    SCP_WAITVM_CASE(20) SCP_WAITVM_CASE(21) SCP_WAITVM_CASE(22) SCP_WAITVM_CASE(23) SCP_WAITVM_CASE(24)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // conservative: drain everything
+  }
+}
+#undef SCP_WAITVM_CASE
+
 template <int DT, int MREP, int NREP>
 __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvLaunch p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -120,8 +134,9 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvLaunch p) {
   };
 
   // LDS-DMA of stage s issued by THIS group: its input tile chunk and its half of the weight chunk
-  auto issue_stage = [&](int s) {
-    if (s >= S) return;
+  auto issue_stage = [&](int s) -> int {      // returns the number of DMA instructions THIS WAVE issued
+    int cnt = 0;
+    if (s >= S) return cnt;
     int it, c;
     stage_of(s, it, c);
     const int planes = c == p.nchunks - 1 ? planes_last : p.cp;
@@ -134,17 +149,19 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvLaunch p) {
       char* wl = wl0 + (s % 3) * p.lds_w;
       for (int o = lo; o < hi; o += 4096) {
         const int mine = o + tid * 16;
+        if (o + wave * 1024 < hi) ++cnt;            // lane 0 of this wave is inside the slice
         if (mine < hi) dma16(ws + mine, wl + o + wave * 1024);
       }
     }
     int img, oy0, ox0;
     decode_tile(it, img, oy0, ox0);
-    if (img < 0 || (p.dbg & 4)) return;
+    if (img < 0 || (p.dbg & 4)) return cnt;
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
     const char* inb = static_cast<const char*>(p.in) + ((size_t)img * p.cin_planes + (size_t)c * p.cp) * HW * 16;
     char* xl = xl0 + (grp * 2 + (s & 1)) * p.lds_x;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
+      if (i * 256 + wave * 64 < HP) cnt += planes;  // lane 0 of this wave is inside the halo tile
       if (hy[i] >= 0) {
         const int iy = iy0 + hy[i], ix = ix0 + hx[i];
         const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
@@ -155,6 +172,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvLaunch p) {
         }
       }
     }
+    return cnt;
   };
 
   f32x4 acc[MREP][NREP];
@@ -194,23 +212,6 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvLaunch p) {
 #pragma unroll
           for (int n = 0; n < NREP; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      if (last) {   // residual slots: inline-asm loads, drained by the vmcnt(0) at the end of the phase
-#pragma unroll
-        for (int m = 0; m < MREP; ++m)
-#pragma unroll
-          for (int np = 0; np < NPAIR; ++np) slot[m][np] = u32x4{0u, 0u, 0u, 0u};
-        if (p.res) {
-#pragma unroll
-          for (int m = 0; m < MREP; ++m)
-#pragma unroll
-            for (int np = 0; np < NPAIR; ++np) {
-              const uint32_t off = slot_off(m, np, mb, img, oy0, ox0);
-              const char* rp = off != 0xffffffffu ? static_cast<const char*>(p.res) + img_off + off
-                                                  : static_cast<const char*>(p.zero16);
-              asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(slot[m][np]) : "v"(rp) : "memory");
-            }
-        }
-      }
       const unsigned long long t1 = now();
       if (img >= 0) {
         const int planes = last ? planes_last : p.cp;
@@ -219,88 +220,120 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvLaunch p) {
         const char* xl = xl0 + (grp * 2 + (s & 1)) * p.lds_x;
         const char* wq = wl0 + (s % 3) * p.lds_w + (q * MT + r) * 16;
         const int* kt = koff + (last ? 64 : 0) + q;
-        for (int st = 0; st < ksteps; ++st) {   // two waves per SIMD hide the LDS latency: no explicit prefetch
-          const int ko = kt[st * 4];
-          frag_t a[MREP], b[NREP];
+        // fragments one k-step ahead, k-offsets two: the partner wave on this SIMD sits in the DMA queue
+        // during this phase, so nothing else hides the LDS latency
+        const int klast = ksteps - 1;
+        frag_t a0[MREP], b0[NREP], a1[MREP], b1[NREP];
+        auto load_frags = [&](int st, int ko, frag_t* a, frag_t* b) {
 #pragma unroll
           for (int m = 0; m < MREP; ++m) a[m] = *reinterpret_cast<const frag_t*>(wq + st * (4 * MT * 16) + m * 256);
 #pragma unroll
           for (int n = 0; n < NREP; ++n) b[n] = *reinterpret_cast<const frag_t*>(xl + ko + pixoff[n]);
+        };
+        auto mfmas = [&](const frag_t* a, const frag_t* b) {
 #pragma unroll
           for (int m = 0; m < MREP; ++m)
 #pragma unroll
             for (int n = 0; n < NREP; ++n) acc[m][n] = mfma16<T>(a[m], b[n], acc[m][n]);
+        };
+        if (ksteps > 0) {
+          int ko_a = kt[0], ko_b = kt[4];
+          load_frags(0, ko_a, a0, b0);
+          int st = 0;
+          for (; st + 1 < ksteps; st += 2) {
+            ko_a = kt[min(st + 2, klast) * 4];
+            load_frags(st + 1, ko_b, a1, b1);
+            mfmas(a0, b0);
+            ko_b = kt[min(st + 3, klast) * 4];
+            load_frags(min(st + 2, klast), ko_a, a0, b0);
+            mfmas(a1, b1);
+          }
+          if (ksteps & 1) mfmas(a0, b0);
         }
       }
       const unsigned long long t2 = now();
-      // the DMA this group issued one phase ago (stage s+1's ... s+2's operands) and the residual loads
+      // the DMA and stores this group issued one phase ago have had this whole phase to complete
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned long long t3 = now();
-      if (last) {   // finalize the tile into 16-byte slots (registers only); stored next phase
-#pragma unroll
-        for (int m = 0; m < MREP; ++m)
-#pragma unroll
-          for (int np = 0; np < NPAIR; ++np) asm volatile("" : "+v"(slot[m][np]));
-#pragma unroll
-        for (int m = 0; m < MREP; ++m) {
-          const float4 bs = *reinterpret_cast<const float4*>(bias_l + mb * MT + m * 16 + q * 4);
-#pragma unroll
-          for (int np = 0; np < NPAIR; ++np) {
-            const int n0 = 2 * np, n1 = (2 * np + 1 < NREP) ? 2 * np + 1 : 2 * np;
-            uint32_t a[4], b[4];
-            a[0] = __float_as_uint(acc[m][n0][0] + bs.x); a[1] = __float_as_uint(acc[m][n0][1] + bs.y);
-            a[2] = __float_as_uint(acc[m][n0][2] + bs.z); a[3] = __float_as_uint(acc[m][n0][3] + bs.w);
-            b[0] = __float_as_uint(acc[m][n1][0] + bs.x); b[1] = __float_as_uint(acc[m][n1][1] + bs.y);
-            b[2] = __float_as_uint(acc[m][n1][2] + bs.z); b[3] = __float_as_uint(acc[m][n1][3] + bs.w);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              const auto sw = __builtin_amdgcn_permlane32_swap(a[jj], b[jj], false, false);
-              a[jj] = sw[0]; b[jj] = sw[1];
-            }
-            float v[8];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) { v[jj] = __uint_as_float(a[jj]); v[4 + jj] = __uint_as_float(b[jj]); }
-            const u32x4 rv = slot[m][np];
-            v[0] += from_bits<T>(rv[0] & 0xffff); v[1] += from_bits<T>(rv[0] >> 16);
-            v[2] += from_bits<T>(rv[1] & 0xffff); v[3] += from_bits<T>(rv[1] >> 16);
-            v[4] += from_bits<T>(rv[2] & 0xffff); v[5] += from_bits<T>(rv[2] >> 16);
-            v[6] += from_bits<T>(rv[3] & 0xffff); v[7] += from_bits<T>(rv[3] >> 16);
-            if (p.relu) {
-#pragma unroll
-              for (int jj = 0; jj < 8; ++jj) v[jj] = fmaxf(v[jj], 0.f);
-            }
-            u32x4 ov;
-            ov[0] = (uint32_t)to_bits<T>(v[0]) | ((uint32_t)to_bits<T>(v[1]) << 16);
-            ov[1] = (uint32_t)to_bits<T>(v[2]) | ((uint32_t)to_bits<T>(v[3]) << 16);
-            ov[2] = (uint32_t)to_bits<T>(v[4]) | ((uint32_t)to_bits<T>(v[5]) << 16);
-            ov[3] = (uint32_t)to_bits<T>(v[6]) | ((uint32_t)to_bits<T>(v[7]) << 16);
-            slot[m][np] = ov;
-          }
-        }
-      }
-      if (p.dbg & 8) { const unsigned long long t4 = now(); tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; tph[3] += t4 - t3; }
+      if (p.dbg & 8) { tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; }
     } else if (u >= 1 && (u & 1)) {
-      // ------------------ store stage s (if it retired a tile), issue the DMA of stage s+2 ------------------
+      // ------- issue the DMA of stage s+2; while it queues, retire stage s's tile if s was its last chunk -------
       const int s = (u - 1) >> 1;
       if (s < S) {
         int it, c;
         stage_of(s, it, c);
-        if (c == p.nchunks - 1) {
-          int img, oy0, ox0;
-          decode_tile(it, img, oy0, ox0);
-          if (img >= 0) {
-            const int mb = it % p.n_mblk;
-            const size_t img_off = (size_t)img * cout_planes * HoWo * 16;
+        int img, oy0, ox0;
+        decode_tile(it, img, oy0, ox0);
+        const bool retire = c == p.nchunks - 1 && img >= 0;
+        const int mb = it % p.n_mblk;
+        const size_t img_off = (size_t)(img < 0 ? 0 : img) * cout_planes * HoWo * 16;
+        float4 bsv[MREP];
+        if (retire) {
+          // bias first: hipcc drains vmcnt before an LDS read that follows LDS-DMA, and right now
+          // nothing is outstanding (this group drained at the end of its MFMA phase)
+#pragma unroll
+          for (int m = 0; m < MREP; ++m) bsv[m] = *reinterpret_cast<const float4*>(bias_l + mb * MT + m * 16 + q * 4);
+#pragma unroll
+          for (int m = 0; m < MREP; ++m)
+#pragma unroll
+            for (int np = 0; np < NPAIR; ++np) slot[m][np] = u32x4{0u, 0u, 0u, 0u};
+          if (p.res) {   // residual slots: inline-asm loads, OLDER than the DMA below
 #pragma unroll
             for (int m = 0; m < MREP; ++m)
 #pragma unroll
               for (int np = 0; np < NPAIR; ++np) {
                 const uint32_t off = slot_off(m, np, mb, img, oy0, ox0);
-                if (off != 0xffffffffu) *reinterpret_cast<u32x4*>(static_cast<char*>(p.out) + img_off + off) = slot[m][np];
+                const char* rp = off != 0xffffffffu ? static_cast<const char*>(p.res) + img_off + off
+                                                    : static_cast<const char*>(p.zero16);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(slot[m][np]) : "v"(rp) : "memory");
               }
           }
         }
-        issue_stage(s + 2);
+        const int newest = __builtin_amdgcn_readfirstlane(issue_stage(s + 2));   // stalls in the DMA queue
+        if (retire) {
+          wait_vm(newest);   // everything older than the DMA just issued, i.e. the residual loads
+#pragma unroll
+          for (int m = 0; m < MREP; ++m)
+#pragma unroll
+            for (int np = 0; np < NPAIR; ++np) asm volatile("" : "+v"(slot[m][np]));
+#pragma unroll
+          for (int m = 0; m < MREP; ++m) {
+            const float4 bs = bsv[m];
+#pragma unroll
+            for (int np = 0; np < NPAIR; ++np) {
+              const int n0 = 2 * np, n1 = (2 * np + 1 < NREP) ? 2 * np + 1 : 2 * np;
+              uint32_t a[4], b[4];
+              a[0] = __float_as_uint(acc[m][n0][0] + bs.x); a[1] = __float_as_uint(acc[m][n0][1] + bs.y);
+              a[2] = __float_as_uint(acc[m][n0][2] + bs.z); a[3] = __float_as_uint(acc[m][n0][3] + bs.w);
+              b[0] = __float_as_uint(acc[m][n1][0] + bs.x); b[1] = __float_as_uint(acc[m][n1][1] + bs.y);
+              b[2] = __float_as_uint(acc[m][n1][2] + bs.z); b[3] = __float_as_uint(acc[m][n1][3] + bs.w);
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(a[jj], b[jj], false, false);
+                a[jj] = sw[0]; b[jj] = sw[1];
+              }
+              float v[8];
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) { v[jj] = __uint_as_float(a[jj]); v[4 + jj] = __uint_as_float(b[jj]); }
+              const u32x4 rv = slot[m][np];
+              v[0] += from_bits<T>(rv[0] & 0xffff); v[1] += from_bits<T>(rv[0] >> 16);
+              v[2] += from_bits<T>(rv[1] & 0xffff); v[3] += from_bits<T>(rv[1] >> 16);
+              v[4] += from_bits<T>(rv[2] & 0xffff); v[5] += from_bits<T>(rv[2] >> 16);
+              v[6] += from_bits<T>(rv[3] & 0xffff); v[7] += from_bits<T>(rv[3] >> 16);
+              if (p.relu) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v[jj] = fmaxf(v[jj], 0.f);
+              }
+              u32x4 ov;
+              ov[0] = (uint32_t)to_bits<T>(v[0]) | ((uint32_t)to_bits<T>(v[1]) << 16);
+              ov[1] = (uint32_t)to_bits<T>(v[2]) | ((uint32_t)to_bits<T>(v[3]) << 16);
+              ov[2] = (uint32_t)to_bits<T>(v[4]) | ((uint32_t)to_bits<T>(v[5]) << 16);
+              ov[3] = (uint32_t)to_bits<T>(v[6]) | ((uint32_t)to_bits<T>(v[7]) << 16);
+              const uint32_t off = slot_off(m, np, mb, img, oy0, ox0);
+              if (off != 0xffffffffu) *reinterpret_cast<u32x4*>(static_cast<char*>(p.out) + img_off + off) = ov;
+            }
+          }
+        }
       }
       if (p.dbg & 8) { tph[5] += now() - t0; }
     }
