@@ -223,12 +223,12 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
   int nt = 1, occ = 1, groups = 1;
   if (!resident && pc.ks == 3 && pc.stride == 1 && pc.mrep >= 4) {
     groups = 2;
-    if (pc.mrep * nrep > 18) {   // 256-register budget of the two-group variant: at most 6 x 3 MFMA tiles per wave
+    if (pc.mrep * nrep > 24) {   // 256-register budget of the two-group variant: at most 6 x 4 MFMA tiles per wave
       int th = L.th;
-      while (th > 1 && (pc.mrep * ((th * L.tw + 63) / 64) > 18 || L.Ho % th != 0)) --th;
-      if (pc.mrep * ((th * L.tw + 63) / 64) <= 18) { L.th = th; set_geometry(); }
+      while (th > 1 && (pc.mrep * ((th * L.tw + 63) / 64) > 24 || L.Ho % th != 0)) --th;
+      if (pc.mrep * ((th * L.tw + 63) / 64) <= 24) { L.th = th; set_geometry(); }
     }
-    if (conv_pipe_lds_bytes(pc, L.plane_stride, 2) > 160 * 1024 || pc.mrep * nrep > 18) groups = 1;
+    if (conv_pipe_lds_bytes(pc, L.plane_stride, 2) > 160 * 1024 || pc.mrep * nrep > 24) groups = 1;
     if (groups == 1 && 2 * pc.mrep * nrep * 4 <= 224) nt = 2;
   }
   if (resident && 2 * conv_pipe_lds_bytes(pc, L.plane_stride, 1) <= 160 * 1024) occ = 2;

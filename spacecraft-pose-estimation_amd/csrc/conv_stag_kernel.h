@@ -176,7 +176,6 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvLaunch p) {
   };
 
   f32x4 acc[MREP][NREP];
-  u32x4 slot[MREP][NPAIR];
   auto slot_off = [&](int m, int np, int mb, int img, int oy0, int ox0) -> uint32_t {
     const int co_plane = mb * MT + m * 16 + psel * 8;
     const int oy = oy0 + epy[np], ox = ox0 + epx[np];
@@ -201,11 +200,9 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvLaunch p) {
       const int s = u >> 1;
       int it, c;
       stage_of(s, it, c);
-      const int mb = it % p.n_mblk;
       const bool last = c == p.nchunks - 1;
       int img, oy0, ox0;
       decode_tile(it, img, oy0, ox0);
-      const size_t img_off = (size_t)(img < 0 ? 0 : img) * cout_planes * HoWo * 16;
       if (c == 0) {
 #pragma unroll
         for (int m = 0; m < MREP; ++m)
@@ -267,38 +264,24 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvLaunch p) {
         const bool retire = c == p.nchunks - 1 && img >= 0;
         const int mb = it % p.n_mblk;
         const size_t img_off = (size_t)(img < 0 ? 0 : img) * cout_planes * HoWo * 16;
-        float4 bsv[MREP];
+        issue_stage(s + 2);   // this wave now sits in the DMA queue while the other group runs its MFMAs
         if (retire) {
-          // bias first: hipcc drains vmcnt before an LDS read that follows LDS-DMA, and right now
-          // nothing is outstanding (this group drained at the end of its MFMA phase)
-#pragma unroll
-          for (int m = 0; m < MREP; ++m) bsv[m] = *reinterpret_cast<const float4*>(bias_l + mb * MT + m * 16 + q * 4);
-#pragma unroll
-          for (int m = 0; m < MREP; ++m)
-#pragma unroll
-            for (int np = 0; np < NPAIR; ++np) slot[m][np] = u32x4{0u, 0u, 0u, 0u};
-          if (p.res) {   // residual slots: inline-asm loads, OLDER than the DMA below
-#pragma unroll
-            for (int m = 0; m < MREP; ++m)
-#pragma unroll
-              for (int np = 0; np < NPAIR; ++np) {
-                const uint32_t off = slot_off(m, np, mb, img, oy0, ox0);
-                const char* rp = off != 0xffffffffu ? static_cast<const char*>(p.res) + img_off + off
-                                                    : static_cast<const char*>(p.zero16);
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(slot[m][np]) : "v"(rp) : "memory");
-              }
-          }
-        }
-        const int newest = __builtin_amdgcn_readfirstlane(issue_stage(s + 2));   // stalls in the DMA queue
-        if (retire) {
-          wait_vm(newest);   // everything older than the DMA just issued, i.e. the residual loads
-#pragma unroll
-          for (int m = 0; m < MREP; ++m)
-#pragma unroll
-            for (int np = 0; np < NPAIR; ++np) asm volatile("" : "+v"(slot[m][np]));
+          // Row by row: residual slots (plain loads), bias from LDS, finalize, 16-byte stores.  hipcc
+          // drains vmcnt for them, i.e. this phase also waits for the burst above to land -- only on
+          // the one stage in nchunks that retires a tile, and it keeps the kernel free of long-lived
+          // epilogue registers (spills cost a vmcnt(0) each, in the middle of the DMA stream).
 #pragma unroll
           for (int m = 0; m < MREP; ++m) {
-            const float4 bs = bsv[m];
+            u32x4 rv[NPAIR];
+            uint32_t off[NPAIR];
+#pragma unroll
+            for (int np = 0; np < NPAIR; ++np) {
+              off[np] = slot_off(m, np, mb, img, oy0, ox0);
+              rv[np] = u32x4{0u, 0u, 0u, 0u};
+              if (p.res && off[np] != 0xffffffffu)
+                rv[np] = *reinterpret_cast<const u32x4*>(static_cast<const char*>(p.res) + img_off + off[np]);
+            }
+            const float4 bs = *reinterpret_cast<const float4*>(bias_l + mb * MT + m * 16 + q * 4);
 #pragma unroll
             for (int np = 0; np < NPAIR; ++np) {
               const int n0 = 2 * np, n1 = (2 * np + 1 < NREP) ? 2 * np + 1 : 2 * np;
@@ -315,11 +298,10 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvLaunch p) {
               float v[8];
 #pragma unroll
               for (int jj = 0; jj < 4; ++jj) { v[jj] = __uint_as_float(a[jj]); v[4 + jj] = __uint_as_float(b[jj]); }
-              const u32x4 rv = slot[m][np];
-              v[0] += from_bits<T>(rv[0] & 0xffff); v[1] += from_bits<T>(rv[0] >> 16);
-              v[2] += from_bits<T>(rv[1] & 0xffff); v[3] += from_bits<T>(rv[1] >> 16);
-              v[4] += from_bits<T>(rv[2] & 0xffff); v[5] += from_bits<T>(rv[2] >> 16);
-              v[6] += from_bits<T>(rv[3] & 0xffff); v[7] += from_bits<T>(rv[3] >> 16);
+              v[0] += from_bits<T>(rv[np][0] & 0xffff); v[1] += from_bits<T>(rv[np][0] >> 16);
+              v[2] += from_bits<T>(rv[np][1] & 0xffff); v[3] += from_bits<T>(rv[np][1] >> 16);
+              v[4] += from_bits<T>(rv[np][2] & 0xffff); v[5] += from_bits<T>(rv[np][2] >> 16);
+              v[6] += from_bits<T>(rv[np][3] & 0xffff); v[7] += from_bits<T>(rv[np][3] >> 16);
               if (p.relu) {
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) v[jj] = fmaxf(v[jj], 0.f);
@@ -329,8 +311,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvLaunch p) {
               ov[1] = (uint32_t)to_bits<T>(v[2]) | ((uint32_t)to_bits<T>(v[3]) << 16);
               ov[2] = (uint32_t)to_bits<T>(v[4]) | ((uint32_t)to_bits<T>(v[5]) << 16);
               ov[3] = (uint32_t)to_bits<T>(v[6]) | ((uint32_t)to_bits<T>(v[7]) << 16);
-              const uint32_t off = slot_off(m, np, mb, img, oy0, ox0);
-              if (off != 0xffffffffu) *reinterpret_cast<u32x4*>(static_cast<char*>(p.out) + img_off + off) = ov;
+              if (off[np] != 0xffffffffu) *reinterpret_cast<u32x4*>(static_cast<char*>(p.out) + img_off + off[np]) = ov;
             }
           }
         }
@@ -363,7 +344,7 @@ template <int DT>
 int32_t stag_dispatch(int mrep, int nrep, const ConvLaunch& L, size_t lds, hipStream_t st) {
 #define SCP_STAG(M, N) if (mrep == M && nrep == N) return stag_launch_one<DT, M, N>(L, lds, st);
   SCP_STAG(4, 1) SCP_STAG(4, 2) SCP_STAG(4, 3) SCP_STAG(4, 4)
-  SCP_STAG(6, 1) SCP_STAG(6, 2) SCP_STAG(6, 3)
+  SCP_STAG(6, 1) SCP_STAG(6, 2) SCP_STAG(6, 3) SCP_STAG(6, 4)
 #undef SCP_STAG
   set_error("conv: staggered variant mrep %d nrep %d not built", mrep, nrep);
   return SCPOSE_E_INVALID;
