@@ -14,6 +14,8 @@ def demangle(n):
 
 def short(n):
     n = demangle(n)
+    m = re.search(r"(conv_\w+_kernel<[^>]*>)", n)
+    if m: return m.group(1).replace(" ", "")
     m = re.search(r"conv_igemm_kernel<(.*)>", n)
     if m:
         a = [x.strip() for x in m.group(1).split(",")]
@@ -22,7 +24,7 @@ def short(n):
     return n[:60]
 
 stats_dir, fetch_dir, write_dir, out = sys.argv[1:5]
-rows = list(csv.DictReader(open(glob.glob(stats_dir + "/*/*kernel_stats.csv")[0])))
+rows = list(csv.DictReader(open((glob.glob(stats_dir + "/*/*kernel_stats.csv") + glob.glob(stats_dir + "/*kernel_stats.csv"))[0])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 lines = ["kernel,calls,avg_us,total_ms,pct"]
 for r in rows:
@@ -32,7 +34,7 @@ open(out + "_kernel_stats.csv", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[:16]))
 
 def pmc(d, counter):
-    f = glob.glob(d + "/*/*counter_collection.csv")
+    f = glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv")
     if not f: return {}
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f[0])):
