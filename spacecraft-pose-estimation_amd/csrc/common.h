@@ -33,6 +33,19 @@ const char* last_error();
     }                                     \
   } while (0)
 
+// Exact unsigned division by a launch-time constant (n < 2^31): q = (mulhi(n, mul) + n*add) >> shift.
+struct FastDiv {
+  uint32_t mul, shift, add, d;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f; f.d = d ? d : 1;
+  uint32_t s = 0;
+  while ((2u << s) <= f.d) ++s;                 // s = floor(log2 d)
+  if ((f.d & (f.d - 1)) == 0) { f.mul = 0; f.add = 1; f.shift = s; }
+  else { f.mul = (uint32_t)((((uint64_t)1 << (32 + s)) / f.d) + 1); f.add = 0; f.shift = s; }
+  return f;
+}
+
 // ---- 3x3 / 1x1 implicit-GEMM convolution ---------------------------------------------------
 // Device-side description of one convolution launch.  All tensors are "blocked":
 // [N][C/8][H][W][8] 16-bit elements.
@@ -67,6 +80,7 @@ struct ConvLaunch {
   int32_t tiles_total;   // N * tiles_x * tiles_y
   int32_t nt;            // pixel tiles per wave group processed one after the other on one staged weight chunk
   int32_t groups;        // wave groups (256 threads each) working on different tiles in parallel (1 or 2)
+  FastDiv fd_npix, fd_tw, fd_hp, fd_halo_w, fd_tiles_img, fd_tiles_x, fd_nmblk;   // conv_m32: divisions by launch constants
   unsigned long long* dbg_buf;  // development: per-workgroup phase cycle sums (dbg & 8), else null
   int32_t dbg;           // development ablation bits (0 in production): 1 skip MFMA loop, 2 skip epilogue, 4 skip input DMA
 };
@@ -88,6 +102,8 @@ struct PackedConv {
   void* d_w = nullptr;     // device packed weights
   float* d_bias = nullptr; // device bias (n_mblk*mt)
   int mrep;
+  int variant = 0;     // 0: 16x16x32 MFMA kernels (conv_pipe / conv_stag), 1: 32x32x16 kernel (conv_m32)
+  int wm = 1;          // variant 1: waves along Cout (mt = 32*mrep*wm)
 };
 
 // Pick (mrep, cp) for a layer independent of the spatial size; tiles are chosen per launch.
@@ -111,6 +127,14 @@ int plane_stride_for(int stride, int halo_h, int halo_w);
 int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, int occ, int groups, hipStream_t stream);
 size_t conv_pipe_lds_bytes(const PackedConv& pc, int plane_stride, int groups);
 const void* conv_zero_page();   // lazily allocated 256 zero bytes on the current device
+int conv_device_cus();
+unsigned long long* conv_dbg_buffer(hipStream_t stream);   // development instrumentation
+void conv_dbg_set_grid(int grid);
+// 32x32x16-MFMA kernel (conv_m32_kernel.h): layer eligibility + variant, packing, launch
+bool conv_m32_choose(int cin, int cout, int ks, int stride, int* mr, int* wm, int* cp);
+size_t pack_conv_weights_m32(const float* w, int cout, int cin, int ks, int mt, int cp, int dtype,
+                             uint16_t* dst, int* nchunks, int* ksteps_full);
+int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream);   // SCPOSE_E_UNSUPPORTED-free: returns 1 if the shape has no good tiling (caller falls back)
 
 // ---- stem: 3 -> 64, 3x3 stride 2 from f32 NCHW or u8 NHWC ----------------------------------
 int32_t stem_launch(const void* in, int in_fmt, const float* w_folded /*dev [64][27]*/,

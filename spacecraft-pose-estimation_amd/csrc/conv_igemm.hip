@@ -142,19 +142,33 @@ int32_t conv_upload(const float* w, const float* bias, int cout, int cin, int ks
   SCP_REQUIRE(cout > 0, "conv: Cout=%d", cout);
   SCP_REQUIRE(dtype == SCPOSE_DT_BF16 || dtype == SCPOSE_DT_F16, "conv: dtype %d", dtype);
   pc->cin = cin; pc->cout = cout; pc->ks = ks; pc->stride = stride; pc->dtype = dtype;
-  choose_mrep_cp(cin, cout, ks, stride, &pc->mrep, &pc->cp);
-  pc->mt = 16 * pc->mrep;
-  pc->n_mblk = (cout + pc->mt - 1) / pc->mt;
-  pc->wbytes = pack_conv_weights(w, cout, cin, ks, pc->mt, pc->cp, dtype, nullptr, &pc->nchunks,
-                                 &pc->ksteps_full);
-  std::vector<uint16_t> host(pc->wbytes / 2);
-  pack_conv_weights(w, cout, cin, ks, pc->mt, pc->cp, dtype, host.data(), nullptr, nullptr);
-  std::vector<float> hb((size_t)pc->n_mblk * pc->mt, 0.f);
-  if (bias)   // stored in packed (MFMA row) order, like the weight rows
-    for (size_t pos = 0; pos < hb.size(); ++pos) {
-      const int co = (int)(pos & ~(size_t)15) + conv_row_channel((int)(pos & 15));
-      if (co < cout) hb[pos] = bias[co];
-    }
+  std::vector<uint16_t> host;
+  std::vector<float> hb;
+  if (conv_m32_choose(cin, cout, ks, stride, &pc->mrep, &pc->wm, &pc->cp)) {   // 32x32x16 MFMA kernel
+    pc->variant = 1;
+    pc->mt = 32 * pc->mrep * pc->wm;
+    pc->n_mblk = (cout + pc->mt - 1) / pc->mt;
+    pc->wbytes = pack_conv_weights_m32(w, cout, cin, ks, pc->mt, pc->cp, dtype, nullptr, &pc->nchunks, &pc->ksteps_full);
+    host.resize(pc->wbytes / 2);
+    pack_conv_weights_m32(w, cout, cin, ks, pc->mt, pc->cp, dtype, host.data(), nullptr, nullptr);
+    hb.assign((size_t)pc->n_mblk * pc->mt, 0.f);
+    if (bias) for (int co = 0; co < cout; ++co) hb[co] = bias[co];   // natural channel order
+  } else {
+    pc->variant = 0; pc->wm = 1;
+    choose_mrep_cp(cin, cout, ks, stride, &pc->mrep, &pc->cp);
+    pc->mt = 16 * pc->mrep;
+    pc->n_mblk = (cout + pc->mt - 1) / pc->mt;
+    pc->wbytes = pack_conv_weights(w, cout, cin, ks, pc->mt, pc->cp, dtype, nullptr, &pc->nchunks,
+                                   &pc->ksteps_full);
+    host.resize(pc->wbytes / 2);
+    pack_conv_weights(w, cout, cin, ks, pc->mt, pc->cp, dtype, host.data(), nullptr, nullptr);
+    hb.assign((size_t)pc->n_mblk * pc->mt, 0.f);
+    if (bias)   // stored in packed (MFMA row) order, like the weight rows
+      for (size_t pos = 0; pos < hb.size(); ++pos) {
+        const int co = (int)(pos & ~(size_t)15) + conv_row_channel((int)(pos & 15));
+        if (co < cout) hb[pos] = bias[co];
+      }
+  }
   SCP_REQUIRE(conv_zero_page() != nullptr, "conv: cannot allocate the zero page");  // create-time, not in the launch path
   SCP_CHECK_HIP(hipMalloc(&pc->d_w, pc->wbytes));
   SCP_CHECK_HIP(hipMalloc(&pc->d_bias, hb.size() * sizeof(float)));
@@ -195,6 +209,11 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
   L.Wo = (W - 1) / pc.stride + 1;
   L.cin_planes = pc.cin / 8;
   L.cout = pc.cout;
+  if (pc.variant == 1) {
+    SCP_REQUIRE(!out_nchw_f32, "conv m32: float32 NCHW output unsupported");
+    L.relu = relu; L.out_nchw_f32 = 0;
+    return conv_launch_m32(pc, L, stream);
+  }
   int nrep;
   choose_tile(pc.ks, pc.stride, L.Ho, L.Wo, &nrep, &L.th, &L.tw);
   const int k2 = pc.ks / 2;

@@ -1,0 +1,150 @@
+// Host side of the 32x32x16-MFMA convolution (conv_m32_kernel.h): eligibility, weight packing,
+// tile search, launch.  See the kernel header for the design and the measurements behind it.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace scpose {
+
+int32_t conv_m32_dispatch_bf16(int mr, int wm, int nr, int occ, const ConvLaunch& L, size_t lds, hipStream_t st);
+int32_t conv_m32_dispatch_f16(int mr, int wm, int nr, int occ, const ConvLaunch& L, size_t lds, hipStream_t st);
+
+// kernel variants built (keep in step with m32_dispatch): occ = resident workgroups per CU
+struct M32Variant { int mr, wm, nr, occ; };
+static const M32Variant kVariants[] = {
+  {3, 1, 3, 1}, {3, 1, 2, 2},
+  {2, 1, 2, 1}, {2, 1, 4, 1}, {2, 1, 3, 2},
+};
+
+bool conv_m32_choose(int cin, int cout, int ks, int stride, int* mr, int* wm, int* cp) {
+  static const char* e = getenv("SCPOSE_M32");
+  if (e && atoi(e) == 0) return false;
+  if (ks != 3 || stride != 1 || cin % 16 != 0) return false;
+  int m = 0, w = 1;
+  if (cout % 96 == 0) m = 3;          // Cout blocks of 96 (HRNet-W48: 96, 192, 384)
+  else if (cout % 64 == 0) m = 2;     // Cout blocks of 64 (HRNet-W32: 64, 128, 256; layer1)
+  else return false;
+  *mr = m; *wm = w;
+  const int planes = cin / 8;
+  // whole K in one chunk with resident weights when it fits comfortably, else stream 2-plane chunks
+  const int mt = 32 * m * w;
+  const size_t whole = (size_t)(planes / 2) * 9 * 2 * mt * 16;
+  *cp = (cout == mt && whole <= 60 * 1024 && planes <= 6) ? planes : 2;
+  return true;
+}
+
+size_t pack_conv_weights_m32(const float* w, int cout, int cin, int ks, int mt, int cp, int dtype,
+                             uint16_t* dst, int* nchunks_out, int* ksteps_full_out) {
+  const int planes = cin / 8, kk = ks * ks;
+  const int nchunks = (planes + cp - 1) / cp;
+  const int ksteps_full = (cp / 2) * kk;
+  const int n_mblk = (cout + mt - 1) / mt;
+  const size_t chunk_elems = (size_t)ksteps_full * 2 * mt * 8;
+  const size_t total = (size_t)n_mblk * nchunks * chunk_elems;
+  if (nchunks_out) *nchunks_out = nchunks;
+  if (ksteps_full_out) *ksteps_full_out = ksteps_full;
+  if (!dst) return total * 2;
+  memset(dst, 0, total * 2);
+  for (int mb = 0; mb < n_mblk; ++mb)
+    for (int c = 0; c < nchunks; ++c) {
+      const int plane0 = c * cp;
+      const int pl = (planes - plane0) < cp ? (planes - plane0) : cp;
+      uint16_t* base = dst + ((size_t)mb * nchunks + c) * chunk_elems;
+      for (int pp = 0; pp < pl / 2; ++pp)
+        for (int tap = 0; tap < kk; ++tap)
+          for (int kg = 0; kg < 2; ++kg) {
+            const int st = pp * kk + tap;
+            const int plane = plane0 + 2 * pp + kg;
+            for (int r = 0; r < mt; ++r) {
+              const int co = mb * mt + r;   // natural channel order
+              if (co >= cout) continue;
+              uint16_t* d = base + ((size_t)(st * 2 + kg) * mt + r) * 8;
+              for (int j = 0; j < 8; ++j)
+                d[j] = host_f32_to_16(w[((size_t)co * cin + plane * 8 + j) * kk + tap], dtype);
+            }
+          }
+    }
+  return total * 2;
+}
+
+static size_t m32_lds_bytes(const PackedConv& pc, int plane_stride) {
+  const bool resident = pc.nchunks == 1 && pc.n_mblk == 1;
+  const size_t lds_w = (size_t)pc.ksteps_full * 2 * pc.mt * 16;
+  const size_t lds_bias = (((size_t)pc.n_mblk * pc.mt * 4) + 511) & ~(size_t)511;
+  return 1024 + lds_bias + (resident ? 1 : 2) * lds_w + 2 * (size_t)pc.cp * plane_stride;
+}
+
+int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream) {
+  const int wn = 4 / pc.wm;
+  const int k2 = pc.ks / 2;
+  static const char* occ_env = getenv("SCPOSE_M32_OCC");
+  const int occ_only = occ_env ? atoi(occ_env) : 0;
+  // tile search over the built variants: maximise useful MFMA columns, prefer two workgroups per CU
+  // (one computes while the other is stalled in its memory instructions), then pixels per weight chunk
+  double best = -1.0;
+  int b_th = 0, b_tw = 0, b_nseg = 0, b_nr = 0, b_ps = 0, b_occ = 1;
+  const int tw_cand[8] = {L.Wo, 64, 48, 32, 24, 16, 12, 8};
+  for (const M32Variant& v : kVariants) {
+    if (v.mr != pc.mrep || v.wm != pc.wm || (occ_only && v.occ != occ_only)) continue;
+    const int nr = v.nr;
+    const int cap = wn * nr * 32;
+    const int halo_cap = v.occ == 1 ? 1024 : 512;
+    const size_t lds_cap = v.occ == 1 ? 160 * 1024 : 80 * 1024;
+    for (int ti = 0; ti < 8; ++ti) {
+      const int tw = tw_cand[ti];
+      if (tw > L.Wo || tw > cap || (ti > 0 && tw >= L.Wo)) continue;
+      for (int th = 1; th <= L.Ho && th * tw <= cap; ++th) {
+        const int hh = (th - 1) * pc.stride + 1 + 2 * k2, hw = (tw - 1) * pc.stride + 1 + 2 * k2;
+        for (int nseg = 1; nseg <= 4; ++nseg) {
+          if (nseg * th * tw > cap || nseg * hh * hw > halo_cap) break;
+          const int ps = (nseg * hh * hw * 16 + 255) & ~255;
+          if (m32_lds_bytes(pc, ps) > lds_cap) break;
+          const int tx = (L.Wo + tw - 1) / tw, ty = (L.Ho + th - 1) / th;
+          const double eff = (double)L.Ho * L.Wo / ((double)tx * ty / nseg * cap);
+          const double score = eff * (v.occ == 2 ? 1.25 : 1.0) / (1.0 + 2.0 / (wn * nr)) - 0.02 * (double)(hh * hw) / (th * tw);
+          if (score > best) { best = score; b_th = th; b_tw = tw; b_nseg = nseg; b_nr = nr; b_ps = ps; b_occ = v.occ; }
+        }
+      }
+    }
+  }
+  SCP_REQUIRE(best > 0, "conv m32: no tiling for %dx%d output", L.Ho, L.Wo);
+  L.th = b_th; L.tw = b_tw; L.nt = b_nseg;
+  L.tiles_x = (L.Wo + L.tw - 1) / L.tw;
+  L.tiles_y = (L.Ho + L.th - 1) / L.th;
+  L.halo_h = (L.th - 1) * pc.stride + 1 + 2 * k2;
+  L.halo_w = (L.tw - 1) * pc.stride + 1 + 2 * k2;
+  L.plane_stride = b_ps;
+  L.cp = pc.cp; L.nchunks = pc.nchunks; L.ksteps_full = pc.ksteps_full; L.n_mblk = pc.n_mblk;
+  L.lds_w = pc.ksteps_full * 2 * pc.mt * 16;
+  L.lds_x = pc.cp * L.plane_stride;
+  L.lds_bias = ((pc.n_mblk * pc.mt * 4) + 511) & ~511;
+  L.nbuf_w = (pc.nchunks == 1 && pc.n_mblk == 1) ? 1 : 2;
+  L.nbuf_x = 2;
+  L.groups = 1;
+  const size_t lds = m32_lds_bytes(pc, L.plane_stride);
+  L.zero16 = conv_zero_page();
+  SCP_REQUIRE(L.zero16, "conv: cannot allocate the zero page");
+  L.tiles_total = L.N * L.tiles_x * L.tiles_y;
+  L.total_blocks = L.tiles_total * pc.n_mblk;
+  L.items_total = ((L.tiles_total + L.nt - 1) / L.nt) * pc.n_mblk;
+  { static const char* e = getenv("SCPOSE_DBG"); L.dbg = e ? atoi(e) : 0; }
+  L.dbg_buf = nullptr;
+  if (L.dbg & 8) L.dbg_buf = conv_dbg_buffer(stream);
+  if (L.dbg & 32)
+    fprintf(stderr, "m32 %d->%d %dx%d: mr=%d nr=%d occ=%d tile %dx%d nseg=%d halo %dx%d lds=%zu items=%d\n", pc.cin, pc.cout, L.Ho, L.Wo,
+            pc.mrep, b_nr, b_occ, L.th, L.tw, L.nt, L.halo_h, L.halo_w, lds, L.items_total);
+  L.fd_npix = make_fastdiv(L.th * L.tw); L.fd_tw = make_fastdiv(L.tw);
+  L.fd_hp = make_fastdiv(L.halo_h * L.halo_w); L.fd_halo_w = make_fastdiv(L.halo_w);
+  L.fd_tiles_img = make_fastdiv(L.tiles_x * L.tiles_y); L.fd_tiles_x = make_fastdiv(L.tiles_x);
+  L.fd_nmblk = make_fastdiv(pc.n_mblk);
+  int grid = conv_device_cus() * b_occ;
+  if (grid > L.items_total) grid = L.items_total;
+  L.items_per_wg = (L.items_total + grid - 1) / grid;
+  L.grid = (L.items_total + L.items_per_wg - 1) / L.items_per_wg;
+  conv_dbg_set_grid(L.grid);
+  if (pc.dtype == SCPOSE_DT_BF16) return conv_m32_dispatch_bf16(pc.mrep, pc.wm, b_nr, b_occ, L, lds, stream);
+  return conv_m32_dispatch_f16(pc.mrep, pc.wm, b_nr, b_occ, L, lds, stream);
+}
+
+}  // namespace scpose

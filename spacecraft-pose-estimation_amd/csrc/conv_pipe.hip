@@ -31,7 +31,17 @@ const void* conv_zero_page() {
   return g_zero_page[dev];
 }
 
-static int device_cus() {
+// development only: phase-cycle dump buffer of the LAST launch, printed by scpose_dbg_dump()
+unsigned long long* conv_dbg_buffer(hipStream_t stream) {
+  static unsigned long long* buf = nullptr;
+  if (!buf) (void)hipMalloc(&buf, 2048 * 8 * 6 * 8);
+  (void)hipMemsetAsync(buf, 0, 2048 * 8 * 6 * 8, stream);
+  g_dbg_buf = buf; g_dbg_grid = 0;
+  return buf;
+}
+void conv_dbg_set_grid(int grid) { g_dbg_grid = grid; }
+
+int conv_device_cus() {
   static int cus[16] = {0};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -67,14 +77,8 @@ int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, 
   L.items_total = ((L.tiles_total + nt * groups - 1) / (nt * groups)) * pc.n_mblk;
   { static const char* e = getenv("SCPOSE_DBG"); L.dbg = e ? atoi(e) : 0; }
   L.dbg_buf = nullptr;
-  if (L.dbg & 8) {   // development only: phase-cycle dump of the LAST launch, printed by scpose_dbg_dump()
-    static unsigned long long* buf = nullptr;
-    if (!buf) (void)hipMalloc(&buf, 2048 * 8 * 6 * 8);
-    (void)hipMemsetAsync(buf, 0, 2048 * 8 * 6 * 8, stream);
-    L.dbg_buf = buf;
-    g_dbg_buf = buf; g_dbg_grid = 0;
-  }
-  const int cus = device_cus();
+  if (L.dbg & 8) L.dbg_buf = conv_dbg_buffer(stream);
+  const int cus = conv_device_cus();
   int per_cu = (int)((160 * 1024) / lds);
   per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
   if (occ < 2 || groups > 1) per_cu = 1;   // the variant's register budget assumes one workgroup per CU

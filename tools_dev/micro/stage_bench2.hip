@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void k(const char* src, size_t src_bytes, int 
   for (int i = 0; i < NA; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
   bf16x8 a = *(const bf16x8*)(src + tid * 16), b = *(const bf16x8*)(src + 4096 + tid * 16);
   constexpr int V = VEC > 0 ? VEC : 1;
-  size_t base = ((size_t)blockIdx.x * 977 * 4096) % (src_bytes - (size_t)V * 4096 * 2);
+  size_t base = src_bytes < (1u << 20) ? 0 : ((size_t)blockIdx.x * 977 * 4096) % (src_bytes - (size_t)V * 4096 * 2);
   for (int it = 0; it < iters; ++it) {
     const char* s = src + (base + (size_t)it * V * 4096) % (src_bytes - (size_t)V * 4096 * 2);
     char* dst = smem + (it & 1) * V * 4096;
@@ -69,6 +69,11 @@ int main() {
   size_t big = 1ull << 30;
   char* d; hipMalloc(&d, big); hipMemset(d, 0x3c, big);
   float* sink; hipMalloc(&sink, 4);
+  // all workgroups stream the SAME small buffer (the weight-chunk pattern of the convolution)
+  run<0, 7, 0>("same-src", d, 172032 + 2 * 7 * 4096, sink, 1);
+  run<0, 7, 81>("same-src", d, 172032 + 2 * 7 * 4096, sink, 1);
+  run<0, 11, 0>("same-src", d, 172032 + 2 * 11 * 4096, sink, 1);
+  run<0, 11, 81>("same-src", d, 172032 + 2 * 11 * 4096, sink, 1);
   for (int pass = 0; pass < 2; ++pass) {
     size_t bytes = pass == 0 ? (size_t)2 << 20 : big;   // L2-resident (2 MB) vs HBM stream
     run<0, 0, 108>("mfma-only", d, bytes, sink, 1);
