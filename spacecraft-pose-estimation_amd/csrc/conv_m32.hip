@@ -9,12 +9,15 @@ namespace scpose {
 
 int32_t conv_m32_dispatch_bf16(int mr, int wm, int nr, int occ, const ConvLaunch& L, size_t lds, hipStream_t st);
 int32_t conv_m32_dispatch_f16(int mr, int wm, int nr, int occ, const ConvLaunch& L, size_t lds, hipStream_t st);
+int32_t conv_m32p_dispatch_bf16(int mr, int nr, const ConvLaunch& L, size_t lds, hipStream_t st);
+int32_t conv_m32p_dispatch_f16(int mr, int nr, const ConvLaunch& L, size_t lds, hipStream_t st);
 
-// kernel variants built (keep in step with m32_dispatch): occ = resident workgroups per CU
+// kernel variants built (keep in step with m32_dispatch / m32p_dispatch): occ = resident workgroups
+// per CU of the single-role kernel (1, 2), or 3 = the producer/consumer kernel (512 threads, one per CU)
 struct M32Variant { int mr, wm, nr, occ; };
 static const M32Variant kVariants[] = {
-  {3, 1, 3, 1}, {3, 1, 2, 2},
-  {2, 1, 2, 1}, {2, 1, 4, 1}, {2, 1, 3, 2},
+  {3, 1, 3, 1}, {3, 1, 2, 2}, {3, 1, 2, 3},
+  {2, 1, 2, 1}, {2, 1, 4, 1}, {2, 1, 3, 2}, {2, 1, 3, 3},
 };
 
 bool conv_m32_choose(int cin, int cout, int ks, int stride, int* mr, int* wm, int* cp) {
@@ -68,6 +71,12 @@ size_t pack_conv_weights_m32(const float* w, int cout, int cin, int ks, int mt, 
   return total * 2;
 }
 
+static size_t m32p_lds_bytes(const PackedConv& pc, int plane_stride, int nr) {
+  const size_t lds_w = (size_t)pc.ksteps_full * 2 * pc.mt * 16;
+  const size_t lds_bias = (((size_t)pc.n_mblk * pc.mt * 4) + 511) & ~(size_t)511;
+  return lds_bias + 2 * lds_w + 2 * (size_t)pc.cp * plane_stride + (size_t)(pc.mt / 8) * (4 * nr * 32) * 16;
+}
+
 static size_t m32_lds_bytes(const PackedConv& pc, int plane_stride) {
   const bool resident = pc.nchunks == 1 && pc.n_mblk == 1;
   const size_t lds_w = (size_t)pc.ksteps_full * 2 * pc.mt * 16;
@@ -89,8 +98,9 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
     if (v.mr != pc.mrep || v.wm != pc.wm || (occ_only && v.occ != occ_only)) continue;
     const int nr = v.nr;
     const int cap = wn * nr * 32;
-    const int halo_cap = v.occ == 1 ? 1024 : 512;
-    const size_t lds_cap = v.occ == 1 ? 160 * 1024 : 80 * 1024;
+    if (v.occ == 3 && (pc.nchunks < 3 || (pc.cin / 8) % pc.cp != 0)) continue;   // retire-buffer schedule needs >= 3 equal chunks
+    const int halo_cap = v.occ == 2 ? 512 : 1024;
+    const size_t lds_cap = v.occ == 2 ? 80 * 1024 : 160 * 1024;
     for (int ti = 0; ti < 8; ++ti) {
       const int tw = tw_cand[ti];
       if (tw > L.Wo || tw > cap || (ti > 0 && tw >= L.Wo)) continue;
@@ -99,10 +109,12 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
         for (int nseg = 1; nseg <= 4; ++nseg) {
           if (nseg * th * tw > cap || nseg * hh * hw > halo_cap) break;
           const int ps = (nseg * hh * hw * 16 + 255) & ~255;
-          if (m32_lds_bytes(pc, ps) > lds_cap) break;
+          if ((v.occ == 3 ? m32p_lds_bytes(pc, ps, nr) : m32_lds_bytes(pc, ps)) > lds_cap) break;
           const int tx = (L.Wo + tw - 1) / tw, ty = (L.Ho + th - 1) / th;
           const double eff = (double)L.Ho * L.Wo / ((double)tx * ty / nseg * cap);
-          const double score = eff * (v.occ == 2 ? 1.25 : 1.0) / (1.0 + 2.0 / (wn * nr)) - 0.02 * (double)(hh * hw) / (th * tw);
+          // measured preference: producer/consumer for 96-row blocks, two workgroups per CU for 64-row blocks
+          const double pref = v.occ == 3 ? (v.mr == 3 ? 1.5 : 1.1) : v.occ == 2 ? 1.25 : 1.0;
+          const double score = eff * pref / (1.0 + 2.0 / (wn * nr)) - 0.02 * (double)(hh * hw) / (th * tw);
           if (score > best) { best = score; b_th = th; b_tw = tw; b_nseg = nseg; b_nr = nr; b_ps = ps; b_occ = v.occ; }
         }
       }
@@ -122,7 +134,7 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   L.nbuf_w = (pc.nchunks == 1 && pc.n_mblk == 1) ? 1 : 2;
   L.nbuf_x = 2;
   L.groups = 1;
-  const size_t lds = m32_lds_bytes(pc, L.plane_stride);
+  const size_t lds = b_occ == 3 ? m32p_lds_bytes(pc, L.plane_stride, b_nr) : m32_lds_bytes(pc, L.plane_stride);
   L.zero16 = conv_zero_page();
   SCP_REQUIRE(L.zero16, "conv: cannot allocate the zero page");
   L.tiles_total = L.N * L.tiles_x * L.tiles_y;
@@ -138,11 +150,15 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   L.fd_hp = make_fastdiv(L.halo_h * L.halo_w); L.fd_halo_w = make_fastdiv(L.halo_w);
   L.fd_tiles_img = make_fastdiv(L.tiles_x * L.tiles_y); L.fd_tiles_x = make_fastdiv(L.tiles_x);
   L.fd_nmblk = make_fastdiv(pc.n_mblk);
-  int grid = conv_device_cus() * b_occ;
+  int grid = conv_device_cus() * (b_occ == 2 ? 2 : 1);
   if (grid > L.items_total) grid = L.items_total;
   L.items_per_wg = (L.items_total + grid - 1) / grid;
   L.grid = (L.items_total + L.items_per_wg - 1) / L.items_per_wg;
   conv_dbg_set_grid(L.grid);
+  if (b_occ == 3) {
+    if (pc.dtype == SCPOSE_DT_BF16) return conv_m32p_dispatch_bf16(pc.mrep, b_nr, L, lds, stream);
+    return conv_m32p_dispatch_f16(pc.mrep, b_nr, L, lds, stream);
+  }
   if (pc.dtype == SCPOSE_DT_BF16) return conv_m32_dispatch_bf16(pc.mrep, pc.wm, b_nr, b_occ, L, lds, stream);
   return conv_m32_dispatch_f16(pc.mrep, pc.wm, b_nr, b_occ, L, lds, stream);
 }

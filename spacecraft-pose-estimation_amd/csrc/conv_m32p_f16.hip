@@ -1,0 +1,10 @@
+// f16 instantiations of the producer/consumer 32x32x16-MFMA convolution kernel (conv_m32p_kernel.h).
+#include <type_traits>
+
+#include "conv_m32p_kernel.h"
+
+namespace scpose {
+int32_t conv_m32p_dispatch_f16(int mr, int nr, const ConvLaunch& L, size_t lds, hipStream_t st) {
+  return m32p_dispatch<1>(mr, nr, L, lds, st);
+}
+}  // namespace scpose

@@ -1,0 +1,415 @@
+// Producer/consumer form of the 32x32x16-MFMA 3x3 convolution (see conv_m32_kernel.h for the GEMM
+// view, fragment layouts and the reference lines it replaces).
+//
+// Measured on MI355X (tools_dev/micro): a wave that issues memory instructions -- LDS-DMA,
+// residual loads, output stores -- stalls in the issue of each one while the memory pipeline is
+// busy, and cannot issue MFMAs meanwhile; with one wave per SIMD that stall is matrix-pipe idle time
+// (the single-role kernel spends ~35 % of its cycles there).  Two resident waves per SIMD cap the
+// wave at 256 registers, so instead of two symmetric workgroups the 512-thread workgroup is split
+// by ROLE:
+//   * waves 0-3, one per SIMD: consumers.  They execute only LDS reads, MFMAs and the VALU epilogue;
+//     a 32x32x16 MFMA stream from one wave keeps its SIMD's matrix pipe full.
+//   * waves 4-7, one per SIMD: producers.  They execute every global-memory instruction: LDS-DMA of the
+//     next K-chunk (weights + halos), LDS-DMA of the tile's residual rows into an LDS "retire buffer",
+//     and the stores of the previous tile's results out of that buffer.
+// Retire buffer (RO): [Cout-block planes][tile pixels] x 16 B.  For tile i the producers store tile
+// i-1's results from RO during the first chunks, DMA tile i's residual into RO during the middle
+// chunks, and after the last chunk's MFMAs the consumers replace each residual slot by
+// ReLU(acc + bias + residual) in place.  Every stage ends in one workgroup barrier, which orders all
+// of this.  Needs >= 3 K-chunks per tile (host falls back to the single-role kernel otherwise).
+#pragma once
+#include "conv_m32_kernel.h"
+
+namespace scpose {
+
+template <int DT, int KS, int STRIDE, int MR, int NR>
+__global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename DtOf<DT>::type T;
+  typedef typename FragOf<T>::type frag_t;
+  constexpr int MT = 32 * MR;
+  constexpr int KK = KS * KS;
+  constexpr int MAXP = 4;
+  constexpr int PXCAP = 4 * NR * 32;           // pixel slots of a tile group
+  constexpr int ROPL = MT / 8;                 // planes of a Cout block
+  constexpr int NQ = (PXCAP + 255) / 256;      // retire-buffer pixels per producer thread and plane
+
+  // LDS: [bias][W x2][X x2][RO]
+  float* bias_l = reinterpret_cast<float*>(smem);
+  char* wl0 = smem + p.lds_bias;
+  char* xl0 = wl0 + 2 * p.lds_w;
+  char* ro = xl0 + 2 * p.lds_x;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
+  const bool producer = wave_all >= 4;
+  const int wave = wave_all & 3, ptid = tid & 255;
+  const int half = lane >> 5, r = lane & 31;
+  const int HW = p.H * p.W;
+  const int HP = p.halo_h * p.halo_w;
+  const int npix = p.th * p.tw;
+  const int nseg = p.nt;
+  const int P = nseg * npix;
+  const int ksteps_full = (p.cp >> 1) * KK;
+  const int cout_planes = (p.cout + 7) >> 3;
+  const size_t HoWo = (size_t)p.Ho * p.Wo;
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+  const size_t chunk_wbytes = (size_t)ksteps_full * (2 * MT * 16);
+
+  for (int i = tid; i < p.n_mblk * MT; i += 512) bias_l[i] = p.bias[i];
+
+  const int wg = xcd_remap(blockIdx.x, p.grid);
+  const int it_begin = wg * p.items_per_wg;
+  const int it_end = min(p.items_total, it_begin + p.items_per_wg);
+  const int crot = wg % p.nchunks;   // rotated chunk order (equal-sized chunks are a host-side requirement)
+
+  auto pixel_of = [&](int pidx, int& ps, int& py, int& px) {   // flattened pixel -> (segment, y, x); ps < 0 = none
+    if (pidx < P) {
+      ps = fdiv(pidx, p.fd_npix);
+      const int rem = pidx - ps * npix;
+      py = fdiv(rem, p.fd_tw); px = rem - py * p.tw;
+    } else {
+      ps = -1; py = px = 0;
+    }
+  };
+  auto decode_tile = [&](int it, int seg, int& img, int& oy0, int& ox0) {
+    const int t = fdiv(it, p.fd_nmblk) * nseg + seg;
+    if (seg < 0 || t >= p.tiles_total) { img = -1; oy0 = ox0 = 0; return; }
+    img = fdiv(t, p.fd_tiles_img);
+    const int rem = t - img * tiles_per_img;
+    const int ty = fdiv(rem, p.fd_tiles_x);
+    oy0 = ty * p.th; ox0 = (rem - ty * p.tiles_x) * p.tw;
+  };
+  // number of stages at the head of a tile in which the previous tile's results are stored
+  const int n_st = p.nchunks >= 6 ? 2 : 1;
+
+  if (producer) {
+    // =====================================================================================
+    // producers: all global-memory traffic
+    // =====================================================================================
+    int hs[MAXP], hy[MAXP], hx[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      const int hp = i * 256 + ptid;
+      if (hp < nseg * HP) {
+        hs[i] = fdiv(hp, p.fd_hp);
+        const int rem = hp - hs[i] * HP;
+        hy[i] = fdiv(rem, p.fd_halo_w); hx[i] = rem - hy[i] * p.halo_w;
+      } else {
+        hs[i] = -1; hy[i] = hx[i] = 0;
+      }
+    }
+    int qs[NQ], qy[NQ], qx[NQ];   // retire-buffer pixels of this thread
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) pixel_of(k * 256 + ptid < PXCAP ? k * 256 + ptid : P, qs[k], qy[k], qx[k]);
+
+    size_t xoff[MAXP];
+    auto locate_halo = [&](int it) {
+#pragma unroll
+      for (int i = 0; i < MAXP; ++i) {
+        int img, oy0, ox0;
+        decode_tile(it, hs[i], img, oy0, ox0);
+        const int iy = oy0 * STRIDE - (KS / 2) + hy[i], ix = ox0 * STRIDE - (KS / 2) + hx[i];
+        const bool ok = img >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        xoff[i] = ok ? ((size_t)img * p.cin_planes * HW + (size_t)(iy * p.W + ix)) * 16 : ~(size_t)0;
+      }
+    };
+    auto issue_x = [&](int cl, int xb) {
+      const int c = cl + crot < p.nchunks ? cl + crot : cl + crot - p.nchunks;
+      const char* inb = static_cast<const char*>(p.in) + (size_t)c * p.cp * HW * 16;
+      char* xl = xl0 + xb * p.lds_x;
+#pragma unroll
+      for (int i = 0; i < MAXP; ++i) {
+        if (hs[i] >= 0) {
+          const bool ok = xoff[i] != ~(size_t)0;
+          for (int pl = 0; pl < p.cp; ++pl) {
+            const char* src = ok ? inb + xoff[i] + (size_t)pl * HW * 16 : static_cast<const char*>(p.zero16);
+            dma16(src, xl + pl * p.plane_stride + (i * 256 + wave * 64) * 16);
+          }
+        }
+      }
+    };
+    auto issue_w = [&](int it, int cl, int wb) {
+      const int c = cl + crot < p.nchunks ? cl + crot : cl + crot - p.nchunks;
+      const int nbytes = ksteps_full * (2 * MT * 16);
+      const char* ws = static_cast<const char*>(p.wpk) + ((size_t)(it - fdiv(it, p.fd_nmblk) * p.n_mblk) * p.nchunks + c) * chunk_wbytes;
+      char* wl = wl0 + wb * p.lds_w;
+      for (int o = 0; o < nbytes; o += 4096) {
+        const int mine = o + ptid * 16;
+        if (mine < nbytes) dma16(ws + mine, wl + o + wave * 1024);
+      }
+    };
+    // byte offset of (image, plane 0, pixel) in out / res for this thread's retire-buffer pixels
+    auto locate_out = [&](int it, size_t* qb) {
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) {
+        int img, oy0, ox0;
+        decode_tile(it, qs[k], img, oy0, ox0);
+        const int oy = oy0 + qy[k], ox = ox0 + qx[k];
+        const bool ok = img >= 0 && oy < p.Ho && ox < p.Wo;
+        qb[k] = ok ? ((size_t)img * cout_planes * HoWo + (size_t)oy * p.Wo + ox) * 16 : ~(size_t)0;
+      }
+    };
+    // planes [pl0, pl1) of the retire buffer: residual rows of tile `it` -> RO (LDS-DMA)
+    auto load_residual = [&](int it, const size_t* qb, int pl0, int pl1) {
+      const int plane0 = (it - fdiv(it, p.fd_nmblk) * p.n_mblk) * ROPL;
+      for (int pl = pl0; pl < pl1; ++pl)
+#pragma unroll
+        for (int k = 0; k < NQ; ++k)
+          if (k * 256 + ptid < PXCAP) {
+            const bool ok = qb[k] != ~(size_t)0 && plane0 + pl < cout_planes;
+            const char* src = ok ? static_cast<const char*>(p.res) + qb[k] + (size_t)(plane0 + pl) * HoWo * 16
+                                 : static_cast<const char*>(p.zero16);
+            dma16(src, ro + ((pl * PXCAP) + k * 256 + wave * 64) * 16);
+          }
+    };
+    // planes [pl0, pl1) of the retire buffer: results of tile `it` -> global
+    auto store_results = [&](int it, const size_t* qb, int pl0, int pl1) {
+      const int plane0 = (it - fdiv(it, p.fd_nmblk) * p.n_mblk) * ROPL;
+      for (int pl = pl0; pl < pl1; ++pl)
+#pragma unroll
+        for (int k = 0; k < NQ; ++k)
+          if (k * 256 + ptid < PXCAP && qb[k] != ~(size_t)0 && plane0 + pl < cout_planes) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(ro + ((pl * PXCAP) + k * 256 + ptid) * 16);
+            *reinterpret_cast<u32x4*>(static_cast<char*>(p.out) + qb[k] + (size_t)(plane0 + pl) * HoWo * 16) = v;
+          }
+    };
+
+    size_t qb_cur[NQ], qb_prev[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) qb_cur[k] = qb_prev[k] = ~(size_t)0;
+    int wc = 0, xb = 0;
+    if (it_begin < it_end) {
+      locate_halo(it_begin);
+      issue_w(it_begin, 0, 0);
+      issue_x(0, 0);
+    }
+    __syncthreads();   // bias, stage 0 (compiler: vmcnt(0) + lgkmcnt(0) + barrier)
+
+    const int n_ld = p.nchunks - 1 - n_st;   // stages that load residual rows
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
+    auto now = [&]() -> unsigned long long { return (p.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull; };
+    for (int it = it_begin; it < it_end; ++it) {
+      locate_out(it, qb_cur);
+      for (int c = 0; c < p.nchunks; ++c, ++wc) {
+        const unsigned long long t0 = now();
+        const bool last = c == p.nchunks - 1;
+        const int nit = last ? it + 1 : it, nc = last ? 0 : c + 1;
+        unsigned long long t1 = t0;
+        if (nit < it_end) {   // DMA burst for the next stage
+          if (nc == 0) locate_halo(nit);
+          if (!(p.dbg & 4)) issue_x(nc, xb ^ 1);
+          t1 = now();
+          issue_w(nit, nc, (wc + 1) & 1);
+        }
+        const unsigned long long t2 = now();
+        if (c < n_st) {
+          if (it > it_begin && !(p.dbg & 2)) store_results(it - 1, qb_prev, ROPL * c / n_st, ROPL * (c + 1) / n_st);
+        } else if (!last && p.res && !(p.dbg & 2)) {
+          load_residual(it, qb_cur, ROPL * (c - n_st) / n_ld, ROPL * (c - n_st + 1) / n_ld);
+        }
+        const unsigned long long t3 = now();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long t4 = now();
+        __builtin_amdgcn_s_barrier();
+        if (p.dbg & 8) {   // producers: [X issue][W issue][retire-buffer traffic][wait][barrier]
+          const unsigned long long t5 = now();
+          tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; tph[3] += t4 - t3; tph[4] += t5 - t4;
+        }
+        xb ^= 1;
+      }
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) qb_prev[k] = qb_cur[k];
+    }
+    if (it_begin < it_end && !(p.dbg & 2)) store_results(it_end - 1, qb_prev, 0, ROPL);   // drain the last tile
+    if ((p.dbg & 8) && p.dbg_buf && lane == 0)
+      for (int k = 0; k < 6; ++k) p.dbg_buf[((size_t)blockIdx.x * 8 + wave_all) * 6 + k] = tph[k];
+  } else {
+    // =====================================================================================
+    // consumers: LDS reads, MFMAs, epilogue into the retire buffer
+    // =====================================================================================
+    int pixoff[NR];
+    bool pvalid[NR];
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+      int ps, py, px;
+      pixel_of((wave * NR + n) * 32 + r, ps, py, px);
+      pvalid[n] = ps >= 0;
+      pixoff[n] = ps >= 0 ? (ps * HP + (py * STRIDE) * p.halo_w + px * STRIDE) * 16 : 0;
+    }
+    f32x16 acc[MR][NR];
+    int wc = 0, xb = 0;
+    __syncthreads();   // matches the producers' prologue barrier
+
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
+    auto now = [&]() -> unsigned long long { return (p.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull; };
+    for (int it = it_begin; it < it_end; ++it) {
+      const int mb = it - fdiv(it, p.fd_nmblk) * p.n_mblk;
+      for (int c = 0; c < p.nchunks; ++c, ++wc) {
+        const unsigned long long t0 = now();
+        const bool last = c == p.nchunks - 1;
+        if (c == 0) {
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int n = 0; n < NR; ++n)
+#pragma unroll
+              for (int j = 0; j < 16; ++j) acc[m][n][j] = 0.f;
+        }
+        {  // MFMA loop: plane pairs x KK taps, taps unrolled so that every LDS offset is an immediate
+          const int npp = (p.dbg & 1) ? 0 : p.cp >> 1;
+          const uint32_t xl = (uint32_t)(size_t)(xl0 + xb * p.lds_x) + half * p.plane_stride;
+          uint32_t wa = (uint32_t)(size_t)(wl0 + (wc & 1) * p.lds_w) + (half * MT + r) * 16;
+          const int hw16 = p.halo_w * 16;
+          frag_t a0[MR], b0[NR], a1[MR], b1[NR];
+          uint32_t brow[NR];
+          auto set_row = [&](int pp, int ky) {
+#pragma unroll
+            for (int n = 0; n < NR; ++n) brow[n] = xl + pp * 2 * p.plane_stride + ky * hw16 + pixoff[n];
+          };
+          auto issue = [&](auto tapn, frag_t* a, frag_t* b) {
+            constexpr int TAPN = decltype(tapn)::value;
+            constexpr int AOFF = TAPN * (2 * MT * 16);
+            lds_read16<AOFF>(a[0], wa);
+            if constexpr (MR > 1) lds_read16<AOFF + 512>(a[1], wa);
+            if constexpr (MR > 2) lds_read16<AOFF + 1024>(a[2], wa);
+            if constexpr (MR > 3) lds_read16<AOFF + 1536>(a[3], wa);
+#pragma unroll
+            for (int n = 0; n < NR; ++n) lds_read16<((TAPN % KK) % KS) * 16>(b[n], brow[n]);
+          };
+          auto landed = [&](frag_t* a, frag_t* b) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int m = 0; m < MR; ++m) lds_landed(a[m]);
+#pragma unroll
+            for (int n = 0; n < NR; ++n) lds_landed(b[n]);
+          };
+          auto mfmas = [&](const frag_t* a, const frag_t* b, int n0, int n1) {
+#pragma unroll
+            for (int n = 0; n < NR; ++n)
+              if (n >= n0 && n < n1)
+#pragma unroll
+                for (int m = 0; m < MR; ++m) mfma32_acc<T, false>(acc[m][n], a[m], b[n]);
+          };
+          if (npp > 0) {
+            set_row(0, 0);
+            issue(std::integral_constant<int, 0>{}, a0, b0);
+            landed(a0, b0);
+          }
+          for (int pp = 0; pp < npp; ++pp) {
+            const bool more = pp + 1 < npp;
+            auto tap = [&](auto tapc) {
+              constexpr int TAP = decltype(tapc)::value;
+              frag_t* ca = (TAP & 1) ? a1 : a0; frag_t* cb = (TAP & 1) ? b1 : b0;
+              frag_t* na = (TAP & 1) ? a0 : a1; frag_t* nb = (TAP & 1) ? b0 : b1;
+              mfmas(ca, cb, 0, 1);
+              if constexpr (TAP + 1 < KK) {
+                if constexpr ((TAP + 1) % KS == 0) set_row(pp, (TAP + 1) / KS);
+                issue(std::integral_constant<int, TAP + 1>{}, na, nb);
+              } else if (more) {
+                set_row(pp + 1, 0);
+                issue(std::integral_constant<int, KK>{}, na, nb);
+              }
+              mfmas(ca, cb, 1, NR);
+              if (TAP + 1 < KK || more) landed(na, nb);
+            };
+            tap(std::integral_constant<int, 0>{});
+            if constexpr (KK > 1) {
+              tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
+              tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{});
+              tap(std::integral_constant<int, 5>{}); tap(std::integral_constant<int, 6>{});
+              tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
+            }
+            if (more) {
+              wa += KK * (2 * MT * 16);
+              if constexpr (KK & 1) {
+#pragma unroll
+                for (int m = 0; m < MR; ++m) a0[m] = a1[m];
+#pragma unroll
+                for (int n = 0; n < NR; ++n) b0[n] = b1[n];
+              }
+            }
+          }
+          asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA's result visible to the VALU
+        }
+        const unsigned long long t1 = now();
+        if (last) {  // retire: RO slot <- ReLU(acc + bias + residual), in place
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              const int pl = m * 4 + 2 * g + half;   // plane inside the Cout block
+              const float* bp = bias_l + mb * MT + pl * 8;
+              const float4 bs0 = *reinterpret_cast<const float4*>(bp);
+              const float4 bs1 = *reinterpret_cast<const float4*>(bp + 4);
+#pragma unroll
+              for (int n = 0; n < NR; ++n) {
+                u32x4* sp = reinterpret_cast<u32x4*>(ro + ((pl * PXCAP) + (wave * NR + n) * 32 + r) * 16);
+                u32x4 rv = u32x4{0u, 0u, 0u, 0u};
+                if (p.res) rv = *sp;
+                uint32_t a[4], b[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                  a[jj] = __float_as_uint(acc[m][n][8 * g + jj]);
+                  b[jj] = __float_as_uint(acc[m][n][8 * g + 4 + jj]);
+                  const auto sw = __builtin_amdgcn_permlane32_swap(a[jj], b[jj], false, false);
+                  a[jj] = sw[0]; b[jj] = sw[1];
+                }
+                float v[8];
+                v[0] = __uint_as_float(a[0]) + bs0.x; v[1] = __uint_as_float(a[1]) + bs0.y;
+                v[2] = __uint_as_float(a[2]) + bs0.z; v[3] = __uint_as_float(a[3]) + bs0.w;
+                v[4] = __uint_as_float(b[0]) + bs1.x; v[5] = __uint_as_float(b[1]) + bs1.y;
+                v[6] = __uint_as_float(b[2]) + bs1.z; v[7] = __uint_as_float(b[3]) + bs1.w;
+                v[0] += from_bits<T>(rv[0] & 0xffff); v[1] += from_bits<T>(rv[0] >> 16);
+                v[2] += from_bits<T>(rv[1] & 0xffff); v[3] += from_bits<T>(rv[1] >> 16);
+                v[4] += from_bits<T>(rv[2] & 0xffff); v[5] += from_bits<T>(rv[2] >> 16);
+                v[6] += from_bits<T>(rv[3] & 0xffff); v[7] += from_bits<T>(rv[3] >> 16);
+                if (p.relu) {
+#pragma unroll
+                  for (int jj = 0; jj < 8; ++jj) v[jj] = fmaxf(v[jj], 0.f);
+                }
+                u32x4 ov;
+                ov[0] = (uint32_t)to_bits<T>(v[0]) | ((uint32_t)to_bits<T>(v[1]) << 16);
+                ov[1] = (uint32_t)to_bits<T>(v[2]) | ((uint32_t)to_bits<T>(v[3]) << 16);
+                ov[2] = (uint32_t)to_bits<T>(v[4]) | ((uint32_t)to_bits<T>(v[5]) << 16);
+                ov[3] = (uint32_t)to_bits<T>(v[6]) | ((uint32_t)to_bits<T>(v[7]) << 16);
+                if (pvalid[n]) *sp = ov;
+              }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long t2 = now();
+        __builtin_amdgcn_s_barrier();
+        if (p.dbg & 8) {   // consumers: [zero + MFMA loop][epilogue][barrier]
+          const unsigned long long t3 = now();
+          tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2;
+        }
+        xb ^= 1;
+      }
+    }
+    if ((p.dbg & 8) && p.dbg_buf && lane == 0)
+      for (int k = 0; k < 6; ++k) p.dbg_buf[((size_t)blockIdx.x * 8 + wave_all) * 6 + k] = tph[k];
+  }
+}
+
+template <int DT, int MR, int NR>
+int32_t m32p_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
+  auto kern = conv_m32p_kernel<DT, 3, 1, MR, NR>;
+  static bool big_lds_enabled = false;
+  if (!big_lds_enabled) {
+    SCP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    big_lds_enabled = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(L.grid), dim3(512), lds, st, L);
+  SCP_CHECK_HIP(hipGetLastError());
+  return SCPOSE_OK;
+}
+
+template <int DT>
+int32_t m32p_dispatch(int mr, int nr, const ConvLaunch& L, size_t lds, hipStream_t st) {
+  if (mr == 3 && nr == 2) return m32p_launch_one<DT, 3, 2>(L, lds, st);
+  if (mr == 2 && nr == 3) return m32p_launch_one<DT, 2, 3>(L, lds, st);
+  set_error("conv m32p: variant mr=%d nr=%d not built", mr, nr);
+  return SCPOSE_E_INVALID;
+}
+
+}  // namespace scpose

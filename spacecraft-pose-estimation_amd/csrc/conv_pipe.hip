@@ -111,4 +111,11 @@ extern "C" void scpose_dbg_dump(void) {
   for (int i = 0; i < g_dbg_grid * 8; ++i) { double t = 0; for (int k = 0; k < 6; ++k) { sum[k] += (double)h[i * 6 + k]; t += (double)h[i * 6 + k]; } nw += t > 0; }
   for (int k = 0; k < 6; ++k) tot += sum[k];
   for (int k = 0; k < 6; ++k) printf("  %-26s %10.0f cycles/wave  %5.1f%%\n", names[k], sum[k] / (nw ? nw : 1), 100 * sum[k] / tot);
+  // role-split kernels: waves 0-3 and 4-7 of each workgroup separately (slot meaning differs per role)
+  for (int role = 0; role < 2; ++role) {
+    double rs[6] = {0}; int rn = 0;
+    for (int b = 0; b < g_dbg_grid; ++b)
+      for (int w = role * 4; w < role * 4 + 4; ++w) { double t = 0; for (int k = 0; k < 6; ++k) { rs[k] += (double)h[(b * 8 + w) * 6 + k]; t += (double)h[(b * 8 + w) * 6 + k]; } rn += t > 0; }
+    if (rn) { printf("  waves %d-%d:", role * 4, role * 4 + 3); for (int k = 0; k < 6; ++k) printf(" %9.0f", rs[k] / rn); printf("\n"); }
+  }
 }

@@ -1,0 +1,77 @@
+// Microbenchmark 6: LDS-DMA issued by dedicated producer waves (4-7) of a 512-thread workgroup while
+// waves 0-3 idle at the barrier or run an MFMA stream; same 28 KiB/stage weight-chunk pattern.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// MODE 0: 256 threads, every wave issues.  MODE 1: 512 threads, waves 4-7 issue, 0-3 barrier only.
+// MODE 2: as 1, waves 0-3 run NM MFMAs per stage.  LOOPED: issue through a runtime loop with an EXEC mask.
+template <int MODE, int VEC, int NM, int LOOPED>
+__global__ __launch_bounds__(MODE == 0 ? 256 : 512, MODE == 0 ? 1 : 2) void k(const char* src, int chunk_bytes, int nchunks, int iters, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, wave_all = tid >> 6, lane = tid & 63, wave = wave_all & 3, ptid = tid & 255;
+  const bool producer = MODE == 0 || wave_all >= 4;
+  f32x16 acc[6];
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  bf16x8 a = *(const bf16x8*)(src + tid * 16), b = *(const bf16x8*)(src + 8192 + tid * 16);
+  for (int it = 0; it < iters; ++it) {
+    if (producer) {
+      const char* s = src + (size_t)((it + blockIdx.x) % nchunks) * chunk_bytes;
+      char* dst = smem + (it & 1) * 32768;
+      if (LOOPED) {
+        for (int o = 0; o < chunk_bytes; o += 4096) {
+          const int mine = o + ptid * 16;
+          if (mine < chunk_bytes) __builtin_amdgcn_global_load_lds((gbl_void_t*)(s + mine), (lds_void_t*)(dst + o + wave * 1024), 16, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(s + (j * 4 + wave) * 1024 + lane * 16), (lds_void_t*)(dst + (j * 4 + wave) * 1024), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (MODE == 2) {
+#pragma unroll 1
+      for (int m = 0; m < NM / 6; ++m)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+  float t = 0;
+  for (int i = 0; i < 6; ++i) t += acc[i][0];
+  if (t == 123.456f) sink[0] = t;
+}
+
+template <int MODE, int VEC, int NM, int LOOPED>
+void run(const char* name, const char* d, int chunk_bytes, int nchunks, float* sink) {
+  const int iters = 600;
+  hipFuncSetAttribute((const void*)k<MODE, VEC, NM, LOOPED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  const int threads = MODE == 0 ? 256 : 512;
+  k<MODE, VEC, NM, LOOPED><<<256, threads, 128 * 1024>>>(d, chunk_bytes, nchunks, 10, sink);
+  hipEventRecord(a);
+  k<MODE, VEC, NM, LOOPED><<<256, threads, 128 * 1024>>>(d, chunk_bytes, nchunks, iters, sink);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  double us = ms * 1e3 / iters;
+  printf("%-46s %6.2f us/stage  %5.1f GB/s per CU\n", name, us, chunk_bytes / (us * 1e-6) / 1e9);
+}
+
+int main() {
+  char* d; hipMalloc(&d, 1 << 20);
+  unsigned short* h = (unsigned short*)malloc(1 << 20);
+  for (int i = 0; i < (1 << 19); ++i) h[i] = (unsigned short)(0x3c00 + (rand() & 0x3ff));
+  hipMemcpy(d, h, 1 << 20, hipMemcpyHostToDevice);
+  float* sink; hipMalloc(&sink, 4);
+  run<0, 7, 0, 0>("256 thr, all waves issue, unrolled, 28 KiB", d, 28672, 6, sink);
+  run<0, 7, 0, 1>("256 thr, all waves issue, looped, 27 KiB", d, 27648, 6, sink);
+  run<1, 7, 0, 0>("512 thr, waves 4-7 issue, unrolled", d, 28672, 6, sink);
+  run<1, 7, 0, 1>("512 thr, waves 4-7 issue, looped, 27 KiB", d, 27648, 6, sink);
+  run<2, 7, 54, 1>("512 thr, producers looped + 54 MFMA consumers", d, 27648, 6, sink);
+  run<2, 7, 54, 0>("512 thr, producers unrolled + 54 MFMA consumers", d, 28672, 6, sink);
+  return 0;
+}
