@@ -91,7 +91,8 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   const int occ_only = occ_env ? atoi(occ_env) : 0;
   // tile search over the built variants: maximise useful MFMA columns, prefer two workgroups per CU
   // (one computes while the other is stalled in its memory instructions), then pixels per weight chunk
-  double best = -1.0;
+  double best = -1e30;
+  bool found = false;
   int b_th = 0, b_tw = 0, b_nseg = 0, b_nr = 0, b_ps = 0, b_occ = 1;
   const int tw_cand[8] = {L.Wo, 64, 48, 32, 24, 16, 12, 8};
   for (const M32Variant& v : kVariants) {
@@ -115,12 +116,12 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
           // measured preference: producer/consumer for 96-row blocks, two workgroups per CU for 64-row blocks
           const double pref = v.occ == 3 ? (v.mr == 3 ? 1.5 : 1.1) : v.occ == 2 ? 1.25 : 1.0;
           const double score = eff * pref / (1.0 + 2.0 / (wn * nr)) - 0.02 * (double)(hh * hw) / (th * tw);
-          if (score > best) { best = score; b_th = th; b_tw = tw; b_nseg = nseg; b_nr = nr; b_ps = ps; b_occ = v.occ; }
+          if (score > best) { found = true; best = score; b_th = th; b_tw = tw; b_nseg = nseg; b_nr = nr; b_ps = ps; b_occ = v.occ; }
         }
       }
     }
   }
-  SCP_REQUIRE(best > 0, "conv m32: no tiling for %dx%d output", L.Ho, L.Wo);
+  SCP_REQUIRE(found, "conv m32: no tiling for %dx%d output", L.Ho, L.Wo);
   L.th = b_th; L.tw = b_tw; L.nt = b_nseg;
   L.tiles_x = (L.Wo + L.tw - 1) / L.tw;
   L.tiles_y = (L.Ho + L.th - 1) / L.th;

@@ -39,6 +39,14 @@ CASES = [
     (16, 32, 3, 2, 2, 2, 3, False, False),
     (128, 16, 1, 1, 2, 2, 1, False, False),
     (80, 80, 3, 1, 16, 16, 1, True, True),      # Cout not on a 48/64/96 grid (padded block)
+    # 32x32x16-MFMA kernels (conv_m32 / conv_m32p): ragged maps, several Cout blocks, segment groups
+    (96, 96, 3, 1, 20, 28, 3, True, True),
+    (96, 192, 3, 1, 24, 24, 3, True, False),
+    (192, 96, 3, 1, 10, 14, 5, False, True),
+    (64, 128, 3, 1, 17, 9, 2, True, True),
+    (32, 96, 3, 1, 12, 12, 7, True, True),      # 2 K-chunks only: single-role kernel, not producer/consumer
+    (384, 384, 3, 1, 5, 5, 9, True, True),
+    (96, 96, 3, 1, 1, 1, 4, True, True),
 ]
 
 
