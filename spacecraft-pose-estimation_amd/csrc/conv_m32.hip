@@ -16,7 +16,7 @@ int32_t conv_m32p_dispatch_f16(int mr, int nr, const ConvLaunch& L, size_t lds, 
 // per CU of the single-role kernel (1, 2), or 3 = the producer/consumer kernel (512 threads, one per CU)
 struct M32Variant { int mr, wm, nr, occ; };
 static const M32Variant kVariants[] = {
-  {3, 1, 3, 1}, {3, 1, 2, 2}, {3, 1, 2, 3},
+  {3, 1, 3, 1}, {3, 1, 2, 2}, {3, 1, 2, 3}, {3, 1, 3, 3},
   {2, 1, 2, 1}, {2, 1, 4, 1}, {2, 1, 3, 2}, {2, 1, 3, 3},
 };
 

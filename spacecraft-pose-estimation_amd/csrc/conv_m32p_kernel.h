@@ -174,6 +174,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
           }
     };
 
+    if (!(p.dbg & 128)) __builtin_amdgcn_s_setprio(3);   // memory instructions ahead of the consumers' MFMA stream
     size_t qb_cur[NQ], qb_prev[NQ];
 #pragma unroll
     for (int k = 0; k < NQ; ++k) qb_cur[k] = qb_prev[k] = ~(size_t)0;
@@ -194,24 +195,26 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
         const unsigned long long t0 = now();
         const bool last = c == p.nchunks - 1;
         const int nit = last ? it + 1 : it, nc = last ? 0 : c + 1;
-        unsigned long long t1 = t0;
-        if (nit < it_end) {   // DMA burst for the next stage
-          if (nc == 0) locate_halo(nit);
-          if (!(p.dbg & 4)) issue_x(nc, xb ^ 1);
-          t1 = now();
-          issue_w(nit, nc, (wc + 1) & 1);
-        }
-        const unsigned long long t2 = now();
+        // Issue order = expected latency, longest first: the retire-buffer traffic and the halos come from
+        // HBM, the weights from L2; everything is waited for once, at the end of the stage.
         if (c < n_st) {
           if (it > it_begin && !(p.dbg & 2)) store_results(it - 1, qb_prev, ROPL * c / n_st, ROPL * (c + 1) / n_st);
         } else if (!last && p.res && !(p.dbg & 2)) {
           load_residual(it, qb_cur, ROPL * (c - n_st) / n_ld, ROPL * (c - n_st + 1) / n_ld);
         }
+        const unsigned long long t1 = now();
+        unsigned long long t2 = t1;
+        if (nit < it_end) {   // DMA for the next stage
+          if (nc == 0) locate_halo(nit);
+          if (!(p.dbg & 4)) issue_x(nc, xb ^ 1);
+          t2 = now();
+          issue_w(nit, nc, (wc + 1) & 1);
+        }
         const unsigned long long t3 = now();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const unsigned long long t4 = now();
         __builtin_amdgcn_s_barrier();
-        if (p.dbg & 8) {   // producers: [X issue][W issue][retire-buffer traffic][wait][barrier]
+        if (p.dbg & 8) {   // producers: [retire-buffer traffic][locate + X issue][W issue][wait][barrier]
           const unsigned long long t5 = now();
           tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; tph[3] += t4 - t3; tph[4] += t5 - t4;
         }
@@ -247,13 +250,21 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
       for (int c = 0; c < p.nchunks; ++c, ++wc) {
         const unsigned long long t0 = now();
         const bool last = c == p.nchunks - 1;
-        if (c == 0) {
+        if (c == 0) {   // accumulators start at the bias of their rows: row(j) = 8*(j/4) + 4*half + j%4
 #pragma unroll
-          for (int m = 0; m < MR; ++m)
+          for (int m = 0; m < MR; ++m) {
+            const float* bp = bias_l + mb * MT + m * 32 + 4 * half;
+            float bv[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * q);
+              bv[4 * q] = b4.x; bv[4 * q + 1] = b4.y; bv[4 * q + 2] = b4.z; bv[4 * q + 3] = b4.w;
+            }
 #pragma unroll
             for (int n = 0; n < NR; ++n)
 #pragma unroll
-              for (int j = 0; j < 16; ++j) acc[m][n][j] = 0.f;
+              for (int j = 0; j < 16; ++j) acc[m][n][j] = bv[j];
+          }
         }
         {  // MFMA loop: plane pairs x KK taps, taps unrolled so that every LDS offset is an immediate
           const int npp = (p.dbg & 1) ? 0 : p.cp >> 1;
@@ -332,49 +343,53 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
           asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA's result visible to the VALU
         }
         const unsigned long long t1 = now();
-        if (last) {  // retire: RO slot <- ReLU(acc + bias + residual), in place
+        if (last) {  // retire: RO <- ReLU(acc + residual), in place.  Before any lane exchange a lane holds
+                     // channels [4*half, 4*half+4) of the two planes 2g and 2g+1 of its pixel: it reads and
+                     // writes those two 8-byte half-slots directly, so no permlane and no bias add are needed.
+          // residual half-slots are read one (m, g) batch ahead of the batch being finalised: the
+          // in-place writes would otherwise order every read behind the previous write
+          uint2 ra[2][NR], rb[2][NR];
+          auto slot_a = [&](int b, int n) -> char* {   // b = 2*m + g
+            return ro + ((((b >> 1) * 4 + 2 * (b & 1)) * PXCAP) + (wave * NR + n) * 32 + r) * 16 + 8 * half;
+          };
+          auto fetch = [&](int b, int buf) {
 #pragma unroll
-          for (int m = 0; m < MR; ++m)
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-              const int pl = m * 4 + 2 * g + half;   // plane inside the Cout block
-              const float* bp = bias_l + mb * MT + pl * 8;
-              const float4 bs0 = *reinterpret_cast<const float4*>(bp);
-              const float4 bs1 = *reinterpret_cast<const float4*>(bp + 4);
-#pragma unroll
-              for (int n = 0; n < NR; ++n) {
-                u32x4* sp = reinterpret_cast<u32x4*>(ro + ((pl * PXCAP) + (wave * NR + n) * 32 + r) * 16);
-                u32x4 rv = u32x4{0u, 0u, 0u, 0u};
-                if (p.res) rv = *sp;
-                uint32_t a[4], b[4];
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                  a[jj] = __float_as_uint(acc[m][n][8 * g + jj]);
-                  b[jj] = __float_as_uint(acc[m][n][8 * g + 4 + jj]);
-                  const auto sw = __builtin_amdgcn_permlane32_swap(a[jj], b[jj], false, false);
-                  a[jj] = sw[0]; b[jj] = sw[1];
-                }
-                float v[8];
-                v[0] = __uint_as_float(a[0]) + bs0.x; v[1] = __uint_as_float(a[1]) + bs0.y;
-                v[2] = __uint_as_float(a[2]) + bs0.z; v[3] = __uint_as_float(a[3]) + bs0.w;
-                v[4] = __uint_as_float(b[0]) + bs1.x; v[5] = __uint_as_float(b[1]) + bs1.y;
-                v[6] = __uint_as_float(b[2]) + bs1.z; v[7] = __uint_as_float(b[3]) + bs1.w;
-                v[0] += from_bits<T>(rv[0] & 0xffff); v[1] += from_bits<T>(rv[0] >> 16);
-                v[2] += from_bits<T>(rv[1] & 0xffff); v[3] += from_bits<T>(rv[1] >> 16);
-                v[4] += from_bits<T>(rv[2] & 0xffff); v[5] += from_bits<T>(rv[2] >> 16);
-                v[6] += from_bits<T>(rv[3] & 0xffff); v[7] += from_bits<T>(rv[3] >> 16);
-                if (p.relu) {
-#pragma unroll
-                  for (int jj = 0; jj < 8; ++jj) v[jj] = fmaxf(v[jj], 0.f);
-                }
-                u32x4 ov;
-                ov[0] = (uint32_t)to_bits<T>(v[0]) | ((uint32_t)to_bits<T>(v[1]) << 16);
-                ov[1] = (uint32_t)to_bits<T>(v[2]) | ((uint32_t)to_bits<T>(v[3]) << 16);
-                ov[2] = (uint32_t)to_bits<T>(v[4]) | ((uint32_t)to_bits<T>(v[5]) << 16);
-                ov[3] = (uint32_t)to_bits<T>(v[6]) | ((uint32_t)to_bits<T>(v[7]) << 16);
-                if (pvalid[n]) *sp = ov;
+            for (int n = 0; n < NR; ++n) {
+              ra[buf][n] = make_uint2(0u, 0u); rb[buf][n] = make_uint2(0u, 0u);
+              if (p.res) {
+                ra[buf][n] = *reinterpret_cast<const uint2*>(slot_a(b, n));
+                rb[buf][n] = *reinterpret_cast<const uint2*>(slot_a(b, n) + PXCAP * 16);
               }
             }
+          };
+          fetch(0, 0);
+#pragma unroll
+          for (int b = 0; b < 2 * MR; ++b) {
+            const int m = b >> 1, g = b & 1, buf = b & 1;
+            if (b + 1 < 2 * MR) fetch(b + 1, buf ^ 1);
+#pragma unroll
+            for (int n = 0; n < NR; ++n) {
+              const uint2 xa = ra[buf][n], xb2 = rb[buf][n];
+              float v[8];
+              v[0] = acc[m][n][8 * g + 0] + from_bits<T>(xa.x & 0xffff); v[1] = acc[m][n][8 * g + 1] + from_bits<T>(xa.x >> 16);
+              v[2] = acc[m][n][8 * g + 2] + from_bits<T>(xa.y & 0xffff); v[3] = acc[m][n][8 * g + 3] + from_bits<T>(xa.y >> 16);
+              v[4] = acc[m][n][8 * g + 4] + from_bits<T>(xb2.x & 0xffff); v[5] = acc[m][n][8 * g + 5] + from_bits<T>(xb2.x >> 16);
+              v[6] = acc[m][n][8 * g + 6] + from_bits<T>(xb2.y & 0xffff); v[7] = acc[m][n][8 * g + 7] + from_bits<T>(xb2.y >> 16);
+              if (p.relu) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v[jj] = fmaxf(v[jj], 0.f);
+              }
+              uint2 oa, ob;
+              oa.x = (uint32_t)to_bits<T>(v[0]) | ((uint32_t)to_bits<T>(v[1]) << 16);
+              oa.y = (uint32_t)to_bits<T>(v[2]) | ((uint32_t)to_bits<T>(v[3]) << 16);
+              ob.x = (uint32_t)to_bits<T>(v[4]) | ((uint32_t)to_bits<T>(v[5]) << 16);
+              ob.y = (uint32_t)to_bits<T>(v[6]) | ((uint32_t)to_bits<T>(v[7]) << 16);
+              if (pvalid[n]) {
+                *reinterpret_cast<uint2*>(slot_a(b, n)) = oa;
+                *reinterpret_cast<uint2*>(slot_a(b, n) + PXCAP * 16) = ob;
+              }
+            }
+          }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned long long t2 = now();
@@ -407,6 +422,7 @@ int32_t m32p_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
 template <int DT>
 int32_t m32p_dispatch(int mr, int nr, const ConvLaunch& L, size_t lds, hipStream_t st) {
   if (mr == 3 && nr == 2) return m32p_launch_one<DT, 3, 2>(L, lds, st);
+  if (mr == 3 && nr == 3) return m32p_launch_one<DT, 3, 3>(L, lds, st);
   if (mr == 2 && nr == 3) return m32p_launch_one<DT, 2, 3>(L, lds, st);
   set_error("conv m32p: variant mr=%d nr=%d not built", mr, nr);
   return SCPOSE_E_INVALID;

@@ -8,6 +8,7 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// MODE 3: as 2, and the consumers read 6 fragments (ds_read_b128) per 9 MFMAs like the convolution's tap loop.
 // MODE 0: 256 threads, every wave issues.  MODE 1: 512 threads, waves 4-7 issue, 0-3 barrier only.
 // MODE 2: as 1, waves 0-3 run NM MFMAs per stage.  LOOPED: issue through a runtime loop with an EXEC mask.
 template <int MODE, int VEC, int NM, int LOOPED>
@@ -33,6 +34,19 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 512, MODE == 0 ? 1 : 2) void k(co
           __builtin_amdgcn_global_load_lds((gbl_void_t*)(s + (j * 4 + wave) * 1024 + lane * 16), (lds_void_t*)(dst + (j * 4 + wave) * 1024), 16, 0, 0);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (MODE == 3) {
+      const uint32_t la = (uint32_t)(size_t)smem + 65536 + (tid & 255) * 16;
+#pragma unroll 1
+      for (int m = 0; m < NM / 9; ++m) {
+        bf16x8 f[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[i]) : "v"(la), "n"(0));
+#pragma unroll
+        for (int i = 0; i < 9; ++i) acc[i % 6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i % 6], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 6; ++i) asm volatile("" :: "v"(f[i]));
+      }
     } else if (MODE == 2) {
 #pragma unroll 1
       for (int m = 0; m < NM / 6; ++m)
@@ -73,5 +87,9 @@ int main() {
   run<1, 7, 0, 1>("512 thr, waves 4-7 issue, looped, 27 KiB", d, 27648, 6, sink);
   run<2, 7, 54, 1>("512 thr, producers looped + 54 MFMA consumers", d, 27648, 6, sink);
   run<2, 7, 54, 0>("512 thr, producers unrolled + 54 MFMA consumers", d, 28672, 6, sink);
+  run<3, 7, 54, 0>("512 thr, producers + 54 MFMA + LDS-read consumers", d, 28672, 6, sink);
+  run<3, 7, 81, 0>("512 thr, producers + 81 MFMA + LDS-read consumers", d, 28672, 6, sink);
+  run<3, 11, 81, 0>("512 thr, 44 KiB + 81 MFMA + LDS-read consumers", d, 45056, 3, sink);
+  run<2, 11, 81, 0>("512 thr, 44 KiB + 81 MFMA consumers (no reads)", d, 45056, 3, sink);
   return 0;
 }
