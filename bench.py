@@ -187,7 +187,7 @@ def main():
         key, (ms, calls, flops, byts) = max(prof_ms.items(), key=lambda kv: kv[1][0])
         kind, a, cin, cout = key
         kname = {0: "stem_conv1_kernel (3->64 3x3 s2, f32 VALU)", 2: "fuse_sum_kernel (%d terms, C=%d)" % (a, cin)}.get(
-            kind, "conv_igemm_kernel %dx%d s%d %d->%d" % (a // 10, a // 10, a % 10, cin, cout))
+            kind, "conv %dx%d s%d %d->%d (MFMA implicit-GEMM; variant names in profiles/*_kernel_stats.csv)" % (a // 10, a // 10, a % 10, cin, cout))
         ai = flops / byts if byts else float("inf")
         hbm_bound = ai < MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
         sec = ms / 1e3
@@ -196,7 +196,17 @@ def main():
         else:
             roof = {"bound": "mfma", "achieved": round(flops / sec / 1e12, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
         roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-        roof["traffic"] = None   # HBM bytes from PMC counters: collected by separate rocprofv3 --pmc passes (profiles/)
+        # HBM bytes per launch from the PMC counters: they need separate rocprofv3 --pmc passes, so the
+        # number is read from the committed summary of those passes (same command, same batch) or null
+        roof["traffic"] = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json"))).get("%d:%d:%d:%d" % key)
+            if tr and tr.get("batch") == B and args.dtype == "bf16" and image == 384:
+                roof["traffic"] = tr["fetch_bytes"] + tr["write_bytes"]
+                roof["traffic_unit"] = "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE), %s" % tr["kernel"]
+                roof["algorithmic_bytes_per_launch"] = byts / calls
+        except (OSError, ValueError):
+            pass
         roof.update({"kernel": kname, "launches": calls, "avg_launch_us": round(ms / calls * 1e3, 2),
                      "share_of_forward": round(ms / sum(v[0] for v in prof_ms.values()), 4),
                      "flop_per_byte": round(ai, 1),
