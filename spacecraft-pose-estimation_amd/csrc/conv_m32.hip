@@ -71,10 +71,17 @@ size_t pack_conv_weights_m32(const float* w, int cout, int cin, int ks, int mt, 
   return total * 2;
 }
 
+// producer/consumer kernel: weights stay resident (all chunks in LDS) when the layer has one Cout block and they fit
+static int m32p_wbufs(const PackedConv& pc, int plane_stride, int nr) {
+  const size_t lds_w = (size_t)pc.ksteps_full * 2 * pc.mt * 16;
+  const size_t lds_bias = (((size_t)pc.n_mblk * pc.mt * 4) + 511) & ~(size_t)511;
+  const size_t rest = lds_bias + 2 * (size_t)pc.cp * plane_stride + (size_t)(pc.mt / 8) * (4 * nr * 32) * 16;
+  return (pc.n_mblk == 1 && pc.nchunks > 2 && rest + pc.nchunks * lds_w <= 160 * 1024) ? pc.nchunks : 2;
+}
 static size_t m32p_lds_bytes(const PackedConv& pc, int plane_stride, int nr) {
   const size_t lds_w = (size_t)pc.ksteps_full * 2 * pc.mt * 16;
   const size_t lds_bias = (((size_t)pc.n_mblk * pc.mt * 4) + 511) & ~(size_t)511;
-  return lds_bias + 2 * lds_w + 2 * (size_t)pc.cp * plane_stride + (size_t)(pc.mt / 8) * (4 * nr * 32) * 16;
+  return lds_bias + m32p_wbufs(pc, plane_stride, nr) * lds_w + 2 * (size_t)pc.cp * plane_stride + (size_t)(pc.mt / 8) * (4 * nr * 32) * 16;
 }
 
 static size_t m32_lds_bytes(const PackedConv& pc, int plane_stride) {
@@ -132,7 +139,7 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   L.lds_w = pc.ksteps_full * 2 * pc.mt * 16;
   L.lds_x = pc.cp * L.plane_stride;
   L.lds_bias = ((pc.n_mblk * pc.mt * 4) + 511) & ~511;
-  L.nbuf_w = (pc.nchunks == 1 && pc.n_mblk == 1) ? 1 : 2;
+  L.nbuf_w = b_occ == 3 ? m32p_wbufs(pc, L.plane_stride, b_nr) : (pc.nchunks == 1 && pc.n_mblk == 1) ? 1 : 2;
   L.nbuf_x = 2;
   L.groups = 1;
   const size_t lds = b_occ == 3 ? m32p_lds_bytes(pc, L.plane_stride, b_nr) : m32_lds_bytes(pc, L.plane_stride);

@@ -34,10 +34,11 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
   constexpr int ROPL = MT / 8;                 // planes of a Cout block
   constexpr int NQ = (PXCAP + 255) / 256;      // retire-buffer pixels per producer thread and plane
 
-  // LDS: [bias][W x2][X x2][RO]
+  // LDS: [bias][W: 2 chunk buffers, or all chunks when the layer's weights stay resident][X x2][RO]
+  const bool w_resident = p.nbuf_w != 2;          // nbuf_w = nchunks: one Cout block whose whole K fits
   float* bias_l = reinterpret_cast<float*>(smem);
   char* wl0 = smem + p.lds_bias;
-  char* xl0 = wl0 + 2 * p.lds_w;
+  char* xl0 = wl0 + p.nbuf_w * p.lds_w;
   char* ro = xl0 + 2 * p.lds_x;
 
   const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
@@ -181,7 +182,15 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
     int wc = 0, xb = 0;
     if (it_begin < it_end) {
       locate_halo(it_begin);
-      issue_w(it_begin, 0, 0);
+      if (w_resident) {   // every chunk, in storage order, once per launch
+        const int nbytes = p.nchunks * ksteps_full * (2 * MT * 16);
+        for (int o = 0; o < nbytes; o += 4096) {
+          const int mine = o + ptid * 16;
+          if (mine < nbytes) dma16(static_cast<const char*>(p.wpk) + mine, wl0 + o + wave * 1024);
+        }
+      } else {
+        issue_w(it_begin, 0, 0);
+      }
       issue_x(0, 0);
     }
     __syncthreads();   // bias, stage 0 (compiler: vmcnt(0) + lgkmcnt(0) + barrier)
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
           if (nc == 0) locate_halo(nit);
           if (!(p.dbg & 4)) issue_x(nc, xb ^ 1);
           t2 = now();
-          issue_w(nit, nc, (wc + 1) & 1);
+          if (!w_resident) issue_w(nit, nc, (wc + 1) & 1);
         }
         const unsigned long long t3 = now();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -269,7 +278,8 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
         {  // MFMA loop: plane pairs x KK taps, taps unrolled so that every LDS offset is an immediate
           const int npp = (p.dbg & 1) ? 0 : p.cp >> 1;
           const uint32_t xl = (uint32_t)(size_t)(xl0 + xb * p.lds_x) + half * p.plane_stride;
-          uint32_t wa = (uint32_t)(size_t)(wl0 + (wc & 1) * p.lds_w) + (half * MT + r) * 16;
+          const int cidx = c + crot < p.nchunks ? c + crot : c + crot - p.nchunks;
+          uint32_t wa = (uint32_t)(size_t)(wl0 + (w_resident ? cidx : (wc & 1)) * p.lds_w) + (half * MT + r) * 16;
           const int hw16 = p.halo_w * 16;
           frag_t a0[MR], b0[NR], a1[MR], b1[NR];
           uint32_t brow[NR];

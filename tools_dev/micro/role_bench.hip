@@ -12,10 +12,11 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // MODE 0: 256 threads, every wave issues.  MODE 1: 512 threads, waves 4-7 issue, 0-3 barrier only.
 // MODE 2: as 1, waves 0-3 run NM MFMAs per stage.  LOOPED: issue through a runtime loop with an EXEC mask.
 template <int MODE, int VEC, int NM, int LOOPED>
-__global__ __launch_bounds__(MODE == 0 ? 256 : 512, MODE == 0 ? 1 : 2) void k(const char* src, int chunk_bytes, int nchunks, int iters, float* sink) {
+__global__ __launch_bounds__(MODE == 0 ? 256 : MODE == 5 ? 1024 : 512, MODE == 0 ? 1 : MODE == 5 ? 4 : 2) void k(const char* src, int chunk_bytes, int nchunks, int iters, float* sink) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, wave_all = tid >> 6, lane = tid & 63, wave = wave_all & 3, ptid = tid & 255;
-  const bool producer = MODE == 0 || wave_all >= 4;
+  const bool producer = MODE == 0 || MODE >= 4 || wave_all >= 4;
+  constexpr int NW = MODE == 4 ? 8 : MODE == 5 ? 16 : 4;   // waves sharing the stage's DMA
   f32x16 acc[6];
   for (int i = 0; i < 6; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
   bf16x8 a = *(const bf16x8*)(src + tid * 16), b = *(const bf16x8*)(src + 8192 + tid * 16);
@@ -30,8 +31,10 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 512, MODE == 0 ? 1 : 2) void k(co
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j)
-          __builtin_amdgcn_global_load_lds((gbl_void_t*)(s + (j * 4 + wave) * 1024 + lane * 16), (lds_void_t*)(dst + (j * 4 + wave) * 1024), 16, 0, 0);
+        for (int j = 0; j < VEC * 4 / NW; ++j) {
+          const int w = MODE >= 4 ? wave_all : wave;
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(s + (j * NW + w) * 1024 + lane * 16), (lds_void_t*)(dst + (j * NW + w) * 1024), 16, 0, 0);
+        }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else if (MODE == 3) {
@@ -65,7 +68,7 @@ void run(const char* name, const char* d, int chunk_bytes, int nchunks, float* s
   const int iters = 600;
   hipFuncSetAttribute((const void*)k<MODE, VEC, NM, LOOPED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  const int threads = MODE == 0 ? 256 : 512;
+  const int threads = MODE == 0 ? 256 : MODE == 5 ? 1024 : 512;
   k<MODE, VEC, NM, LOOPED><<<256, threads, 128 * 1024>>>(d, chunk_bytes, nchunks, 10, sink);
   hipEventRecord(a);
   k<MODE, VEC, NM, LOOPED><<<256, threads, 128 * 1024>>>(d, chunk_bytes, nchunks, iters, sink);
@@ -85,6 +88,9 @@ int main() {
   run<0, 7, 0, 1>("256 thr, all waves issue, looped, 27 KiB", d, 27648, 6, sink);
   run<1, 7, 0, 0>("512 thr, waves 4-7 issue, unrolled", d, 28672, 6, sink);
   run<1, 7, 0, 1>("512 thr, waves 4-7 issue, looped, 27 KiB", d, 27648, 6, sink);
+  run<0, 16, 0, 0>("256 thr,  4 waves issue 64 KiB", d, 65536, 3, sink);
+  run<4, 16, 0, 0>("512 thr,  8 waves issue 64 KiB", d, 65536, 3, sink);
+  run<5, 16, 0, 0>("1024 thr, 16 waves issue 64 KiB", d, 65536, 3, sink);
   run<2, 7, 54, 1>("512 thr, producers looped + 54 MFMA consumers", d, 27648, 6, sink);
   run<2, 7, 54, 0>("512 thr, producers unrolled + 54 MFMA consumers", d, 28672, 6, sink);
   run<3, 7, 54, 0>("512 thr, producers + 54 MFMA + LDS-read consumers", d, 28672, 6, sink);
