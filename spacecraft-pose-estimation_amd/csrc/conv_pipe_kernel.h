@@ -50,6 +50,11 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native vector: usable as an inline-asm operand
 
+// exact n / d for a launch-time constant d (common.h: FastDiv)
+__device__ __forceinline__ int pipe_fdiv(int n, const FastDiv& f) {
+  return (int)((__umulhi((uint32_t)n, f.mul) + (uint32_t)n * f.add) >> f.shift);
+}
+
 __device__ __forceinline__ void dma16(const void* g, void* l_wave_base) {
   __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)l_wave_base, 16, 0, 0);
 }
@@ -139,13 +144,13 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
   const size_t chunk_wbytes = (size_t)p.ksteps_full * (4 * MT * 16);
 
   // item -> (Cout block, first tile of the group); tile -> (image, tile origin); img < 0 = no tile
-  auto item_mb = [&](int it) { return it % p.n_mblk; };
+  auto item_mb = [&](int it) { return it - pipe_fdiv(it, p.fd_nmblk) * p.n_mblk; };
   auto decode_tile = [&](int it, int j, int& img, int& oy0, int& ox0) {
-    const int t = (it / p.n_mblk) * (NT * G) + j + grp * NT;
+    const int t = pipe_fdiv(it, p.fd_nmblk) * (NT * G) + j + grp * NT;
     if (t >= p.tiles_total) { img = -1; oy0 = ox0 = 0; return; }
-    img = t / tiles_per_img;
+    img = pipe_fdiv(t, p.fd_tiles_img);
     const int rem = t - img * tiles_per_img;
-    const int ty = rem / p.tiles_x;
+    const int ty = pipe_fdiv(rem, p.fd_tiles_x);
     oy0 = ty * p.th; ox0 = (rem - ty * p.tiles_x) * p.tw;
   };
 
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
 #pragma unroll
               for (int n = 0; n < NREP; ++n) acc[J][m][n] = mfma16<T>(a[m], b[n], acc[J][m][n]);
           };
-          if constexpr (OCC >= 2) {
+          if constexpr (OCC >= 2 && MREP * NREP > 8) {   // big tiles at two waves per SIMD: no room for a second fragment set
             for (int st = 0; st < ksteps; ++st) {
               load_frags(st, kt[st * 4], a0, b0);
               mfmas(a0, b0);
