@@ -127,6 +127,14 @@ int32_t scpose_decode(const float* heatmaps, int32_t n, int32_t j, int32_t h, in
 int32_t scpose_max_preds(const float* heatmaps, int32_t n, int32_t j, int32_t h, int32_t w,
                          float* coords, float* maxvals, void* stream);
 
+/* Flip test (cfg.TEST.FLIP_TEST, lib/core/function.py:347-366): out = (a + flip_back(b)) * 0.5 where b
+ * is the forward of the x-flipped input; flip_back (lib/utils/transforms.py:15-29) mirrors b in x and
+ * swaps the joints of each flip pair; shift != 0 applies the TEST.SHIFT_HEATMAP column shift (:361-363).
+ *   a, b, out  device f32 N x J x H x W (out may alias a)
+ *   perm       device i32 J: perm[j] = partner joint of j (j itself when unpaired) */
+int32_t scpose_flip_merge(const float* a, const float* b, const int32_t* perm, int32_t n, int32_t j,
+                          int32_t h, int32_t w, int32_t shift, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Batched PnP.  Replaces, per frame, the confidence filter + cv2.solvePnPRansac(...,
  * flags=SOLVEPNP_EPNP, iterationsCount, reprojectionError) + cv2.Rodrigues of

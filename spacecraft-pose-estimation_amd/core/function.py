@@ -15,8 +15,7 @@ import time
 import numpy as np
 import torch
 
-from .. import parallel
-from ..utils.transforms import flip_back
+from .. import ops, parallel
 from .evaluate import accuracy
 from .inference import get_final_preds_device
 
@@ -65,10 +64,8 @@ def validate(config, val_loader, val_dataset, model, criterion, output_dir, tb_l
             if config.TEST.FLIP_TEST:
                 out_f = model(input.flip(3))
                 out_f = out_f[-1] if isinstance(out_f, list) else out_f
-                out_f = torch.from_numpy(flip_back(out_f.cpu().numpy(), val_dataset.flip_pairs).copy()).to(dev)
-                if config.TEST.SHIFT_HEATMAP:
-                    out_f[:, :, :, 1:] = out_f.clone()[:, :, :, 0:-1]
-                output = (output + out_f) * 0.5
+                # flip_back + SHIFT_HEATMAP + average (:354-366) in one device kernel, no D2H round trip
+                output = ops.flip_merge(output, out_f, val_dataset.flip_pairs, config.TEST.SHIFT_HEATMAP)
             num_images = input.size(0)
             if log_metrics and criterion is not None:
                 target_d = target.to(dev, non_blocking=True)

@@ -19,6 +19,14 @@ extern "C" int32_t scpose_decode(const float* heatmaps, int32_t n, int32_t j, in
                        nullptr, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int32_t scpose_flip_merge(const float* a, const float* b, const int32_t* perm, int32_t n, int32_t j,
+                                     int32_t h, int32_t w, int32_t shift, float* out, void* stream) {
+  if (n == 0) return SCPOSE_OK;
+  SCP_REQUIRE(a && b && perm && out, "flip_merge: null argument");
+  SCP_REQUIRE(j > 0 && h > 0 && w > 0, "flip_merge: bad shape J=%d H=%d W=%d", j, h, w);
+  return flip_merge_launch(a, b, perm, n, j, h, w, shift, out, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int32_t scpose_max_preds(const float* heatmaps, int32_t n, int32_t j, int32_t h,
                                     int32_t w, float* coords, float* maxvals, void* stream) {
   if (n == 0) return SCPOSE_OK;

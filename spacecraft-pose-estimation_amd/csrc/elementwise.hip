@@ -125,6 +125,39 @@ __global__ void blocked_to_nchw_kernel(const void* __restrict__ src, int N, int 
   }
 }
 
+// ---- flip-test merge (TEST.FLIP_TEST): out = (a + flip_back(b)) * 0.5 -------------------------
+// landmark_regression/lib/core/function.py:347-366: b is the network output for the horizontally
+// flipped input; flip_back (lib/utils/transforms.py:15-29) mirrors it in x and swaps the joints of
+// each flip pair; with TEST.SHIFT_HEATMAP columns 1.. take the value of the column to their left
+// (column 0 keeps its own).  fp32, same operation order as the reference: (a + b') * 0.5.
+__global__ __launch_bounds__(256) void flip_merge_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         const int32_t* __restrict__ perm, int N, int J, int H, int W,
+                                                         int shift, float* __restrict__ out) {
+  const size_t total = (size_t)N * J * H * W;
+  for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (size_t)gridDim.x * 256) {
+    const int x = (int)(gid % W);
+    size_t t = gid / W;
+    const int y = (int)(t % H);
+    t /= H;
+    const int j = (int)(t % J);
+    const size_t n = t / J;
+    const int xs = (shift && x > 0) ? x - 1 : x;          // column of the flipped-back map that lands on x
+    const float bv = b[((n * J + perm[j]) * H + y) * W + (W - 1 - xs)];
+    out[gid] = (a[gid] + bv) * 0.5f;
+  }
+}
+
+int32_t flip_merge_launch(const float* a, const float* b, const int32_t* perm, int N, int J, int H, int W, int shift,
+                          float* out, hipStream_t stream) {
+  const size_t total = (size_t)N * J * H * W;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks == 0) return SCPOSE_OK;
+  hipLaunchKernelGGL(flip_merge_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, b, perm, N, J, H, W, shift, out);
+  SCP_CHECK_HIP(hipGetLastError());
+  return SCPOSE_OK;
+}
+
 static unsigned ew_grid(size_t total) {
   size_t b = (total + 255) / 256;
   return (unsigned)(b > 8192 ? 8192 : (b ? b : 1));

@@ -131,6 +131,22 @@ def max_preds(heatmaps):
     return coords, maxvals
 
 
+def flip_merge(out, out_flipped, flip_pairs, shift):
+    """(out + flip_back(out_flipped)) * 0.5 of the flip test (lib/core/function.py:347-366), on the device.
+    out / out_flipped: (N,J,H,W) f32 device heatmaps of the frame and of its x-flipped copy."""
+    _need_cuda(out, out_flipped)
+    a, b = out.contiguous().float(), out_flipped.contiguous().float()
+    n, j, h, w = a.shape
+    perm = list(range(j))
+    for p0, p1 in flip_pairs:
+        perm[p0], perm[p1] = p1, p0
+    perm_d = torch.tensor(perm, dtype=torch.int32, device=a.device)
+    res = torch.empty_like(a)
+    nat.check(nat.lib().scpose_flip_merge(_ptr(a), _ptr(b), _ptr(perm_d), n, j, h, w, int(bool(shift)), _ptr(res),
+                                          _stream()), "flip_merge")
+    return res
+
+
 # ------------------------------------------------------------------ PnP
 def pnp_epnp_ransac(kp_xyc, landmarks, K, dist, conf_thr0=0.95, min_pts=15, thr_decay=0.8, thr_iters=100,
                     max_iters=10000, reproj_err=15.0, confidence=0.99, want_rvec=False):

@@ -94,3 +94,23 @@ def test_decode_full_size_properties(gpu_ops):
 def test_decode_empty_batch(gpu_ops):
     out = gpu_ops.decode(torch.zeros(0, 11, 8, 8).cuda(), torch.zeros(0, 2).cuda(), torch.zeros(0, 2).cuda(), True)
     assert out.shape == (0, 11, 3)
+
+
+def test_flip_merge_matches_reference_semantics(gpu_ops):
+    """(out + flip_back(out_flipped)) * 0.5 with and without SHIFT_HEATMAP, against the NumPy restatement of
+    lib/core/function.py:347-366 + lib/utils/transforms.py:15-29 -- bit-exact (fp32, same operation order)."""
+    import numpy as np
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(3, 11, 24, 20, generator=g)
+    b = torch.randn(3, 11, 24, 20, generator=g)
+    pairs = [[1, 2], [3, 6], [9, 10]]
+    for shift in (False, True):
+        f = b.numpy()[:, :, :, ::-1].copy()
+        for p0, p1 in pairs:
+            tmp = f[:, p0].copy(); f[:, p0] = f[:, p1]; f[:, p1] = tmp
+        if shift:
+            f[:, :, :, 1:] = f.copy()[:, :, :, 0:-1]
+        ref = (a.numpy() + f) * np.float32(0.5)
+        got = gpu_ops.flip_merge(a.cuda(), b.cuda(), pairs, shift).cpu().numpy()
+        assert np.array_equal(got, ref)
+    assert gpu_ops.flip_merge(a[:0].cuda(), b[:0].cuda(), pairs, True).shape == (0, 11, 24, 20)
