@@ -127,6 +127,19 @@ int32_t scpose_decode(const float* heatmaps, int32_t n, int32_t j, int32_t h, in
 int32_t scpose_max_preds(const float* heatmaps, int32_t n, int32_t j, int32_t h, int32_t w,
                          float* coords, float* maxvals, void* stream);
 
+/* Crop pre-processing.  Replaces, per sample, cv2.warpAffine(frame, get_affine_transform(c, s, 0,
+ * IMAGE_SIZE), IMAGE_SIZE, flags=INTER_LINEAR) and the COLOR_RGB channel swap of
+ * landmark_regression/lib/dataset/JointsDataset.py:134-150, :191-195.
+ *   frames    device u8: the samples' full frames (H_i x W_i x 3, any sizes) packed back to back
+ *   offsets   device i64 N: byte offset of sample i's frame inside `frames`
+ *   frame_hw  device i32 N x 2: (H_i, W_i)
+ *   minv      device f64 N x 6: row-major 2x3 INVERSE of the reference's `trans` (crop pixel -> frame pixel)
+ *   crops     device u8 N x out_h x out_w x 3 = the SCPOSE_IN_U8_NHWC input of scpose_hrnet_forward
+ * swap_rb != 0 exchanges channels 0 and 2 (BGR frame -> RGB crop).  Border value 0, bilinear in f64. */
+int32_t scpose_crop_warp(const uint8_t* frames, const int64_t* offsets, const int32_t* frame_hw,
+                         const double* minv, int32_t n, int32_t out_h, int32_t out_w, int32_t swap_rb,
+                         uint8_t* crops, void* stream);
+
 /* Flip test (cfg.TEST.FLIP_TEST, lib/core/function.py:347-366): out = (a + flip_back(b)) * 0.5 where b
  * is the forward of the x-flipped input; flip_back (lib/utils/transforms.py:15-29) mirrors b in x and
  * swaps the joints of each flip pair; shift != 0 applies the TEST.SHIFT_HEATMAP column shift (:361-363).

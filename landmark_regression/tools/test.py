@@ -46,6 +46,8 @@ def parse_args():
     parser.add_argument("--logDir", help="log directory", type=str, default="")
     parser.add_argument("--dataDir", help="data directory", type=str, default="")
     parser.add_argument("--prevModelDir", help="prev Model directory", type=str, default="")
+    parser.add_argument("--device_crop", action="store_true",
+                        help="(extension) warp the crops on the GPU (scpose_crop_warp) instead of in the data loader")
     return parser.parse_args()
 
 
@@ -78,8 +80,10 @@ def main():
         transforms.Compose([transforms.ToTensor(), normalize]))
     lo, hi = parallel.shard_range(len(valid_dataset), rank, ws)
     subset = torch.utils.data.Subset(valid_dataset, range(lo, hi)) if ws > 1 else valid_dataset
+    valid_dataset.device_crop = bool(args.device_crop)
     valid_loader = torch.utils.data.DataLoader(subset, batch_size=cfg.TEST.BATCH_SIZE_PER_GPU * len(cfg.GPUS),
-                                               shuffle=False, num_workers=cfg.WORKERS, pin_memory=True)
+                                               shuffle=False, num_workers=cfg.WORKERS, pin_memory=not args.device_crop,
+                                               collate_fn=valid_dataset.collate_device_crop if args.device_crop else None)
     validate(cfg, valid_loader, valid_dataset, model, criterion, final_output_dir, tb_log_dir, pred_file_name="pred_test")
 
 

@@ -51,6 +51,8 @@ SYMBOLS = {
                                 c_void_p, c_void_p]),
     "scpose_max_preds": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                    c_void_p]),
+    "scpose_crop_warp": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                   c_void_p]),
     "scpose_flip_merge": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                     c_void_p]),
     "scpose_pnp_epnp_ransac": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_double,

@@ -58,11 +58,15 @@ def validate(config, val_loader, val_dataset, model, criterion, output_dir, tb_l
     with torch.no_grad():
         end = time.time()
         for i, (input, target, target_weight, meta) in enumerate(val_loader):
-            input = input.to(dev, non_blocking=True)
+            if isinstance(input, (list, tuple)):   # dataset.device_crop: whole frames -> uint8 NHWC crops on the GPU
+                size = config.MODEL.IMAGE_SIZE
+                input = ops.crop_warp(input, meta["trans"].numpy(), (int(size[0]), int(size[1])), device=dev)
+            else:
+                input = input.to(dev, non_blocking=True)
             outputs = model(input)
             output = outputs[-1] if isinstance(outputs, list) else outputs
             if config.TEST.FLIP_TEST:
-                out_f = model(input.flip(3))
+                out_f = model(input.flip(2) if input.dtype == torch.uint8 else input.flip(3))   # x axis: NHWC crops / NCHW tensors
                 out_f = out_f[-1] if isinstance(out_f, list) else out_f
                 # flip_back + SHIFT_HEATMAP + average (:354-366) in one device kernel, no D2H round trip
                 output = ops.flip_merge(output, out_f, val_dataset.flip_pairs, config.TEST.SHIFT_HEATMAP)

@@ -4,9 +4,11 @@ __getitem__ returns the reference's tuple (input, target, target_weight, meta) f
 image read -> optional BGR/RGB handling -> get_affine_transform(c, s, 0, IMAGE_SIZE) -> bilinear
 warp to the crop -> transform (ToTensor + Normalize) -> gaussian target.  Training-time
 augmentation (flip / scale / rotation / half-body, :158-177) is out of scope and rejected.
-Image decoding uses PIL (cv2 is not available on this image); the crop warp is a NumPy
-restatement of cv2.warpAffine(INTER_LINEAR) (utils/transforms.py) -- SURVEY.md section 8(f) rank 1
-lists the GPU crop kernel as the next component.
+Image decoding uses PIL (cv2 is not available on this image).  The crop warp is either the NumPy
+restatement of cv2.warpAffine(INTER_LINEAR) (utils/transforms.py; default, the reference's data flow)
+or, with ``device_crop = True``, the HIP kernel scpose_crop_warp: then
+__getitem__ returns the whole frame and its affine, ``collate_device_crop`` keeps the frames of a batch
+as a list, and ``validate`` warps + normalises the batch on the GPU (bit-identical crops).
 """
 import copy
 import logging
@@ -53,6 +55,7 @@ class JointsDataset(Dataset):
         self.joints_weight = 1
         self.transform = transform
         self.numpy_transform = numpy_transform
+        self.device_crop = False   # True: hand whole frames to the GPU crop kernel instead of warping here
         self.db = []
 
     def _get_db(self):
@@ -83,16 +86,29 @@ class JointsDataset(Dataset):
         if self.numpy_transform:
             data_numpy = self.numpy_transform(data_numpy)
         trans = get_affine_transform(c, s, r, self.image_size)
-        input = warp_affine_bilinear(np.ascontiguousarray(data_numpy), trans, (int(self.image_size[0]), int(self.image_size[1])))
-        if self.transform:
-            input = self.transform(input)
+        if self.device_crop:
+            input = torch.from_numpy(np.ascontiguousarray(data_numpy))   # H x W x 3 uint8, final channel order
+        else:
+            input = warp_affine_bilinear(np.ascontiguousarray(data_numpy), trans, (int(self.image_size[0]), int(self.image_size[1])))
+            if self.transform:
+                input = self.transform(input)
         for i in range(self.num_joints):
             if joints_vis[i, 0] > 0.0:
                 joints[i, 0:2] = affine_transform(joints[i, 0:2], trans)
         target, target_weight = self.generate_target(joints, joints_vis)
         meta = {"image": image_file, "filename": db_rec.get("filename", ""), "imgnum": db_rec.get("imgnum", ""),
                 "joints": joints, "joints_vis": joints_vis, "center": c, "scale": s, "rotation": r, "score": score}
+        if self.device_crop:
+            meta["trans"] = np.asarray(trans, dtype=np.float64)
         return input, torch.from_numpy(target), torch.from_numpy(target_weight), meta
+
+    @staticmethod
+    def collate_device_crop(batch):
+        """DataLoader collate_fn for device_crop: frames stay a list (sizes differ), the rest is default-collated."""
+        from torch.utils.data import default_collate
+        frames = [b[0] for b in batch]
+        rest = default_collate([(b[1], b[2], b[3]) for b in batch])
+        return frames, rest[0], rest[1], rest[2]
 
     def generate_target(self, joints, joints_vis):
         """Gaussian heatmaps, peak 1.0 at the integer centre (JointsDataset.py:264-332)."""

@@ -131,6 +131,36 @@ def max_preds(heatmaps):
     return coords, maxvals
 
 
+def crop_warp(frames, trans, out_wh, swap_rb=False, device=None):
+    """Batched cv2.warpAffine(frame_i, trans_i, (W, H), INTER_LINEAR) on the device.
+    frames: list of HxWx3 uint8 arrays/tensors (any sizes); trans: (N,2,3) forward affines as returned by
+    get_affine_transform (frame -> crop).  Returns uint8 (N, H, W, 3) device crops."""
+    import numpy as np
+    dev = device or torch.device("cuda", torch.cuda.current_device())
+    n = len(frames)
+    w, h = int(out_wh[0]), int(out_wh[1])
+    out = torch.empty((n, h, w, 3), dtype=torch.uint8, device=dev)
+    if n == 0:
+        return out
+    flat, offs, hw, o = [], [], [], 0
+    for f in frames:
+        t = f if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(f))
+        if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
+            raise ValueError("crop_warp: frames must be HxWx3 uint8")
+        flat.append(t.reshape(-1)); offs.append(o); hw.append((t.shape[0], t.shape[1])); o += t.numel()
+    buf = torch.cat(flat).to(dev, non_blocking=True)
+    minv = np.zeros((n, 6), dtype=np.float64)
+    for i in range(n):
+        m = np.vstack([np.asarray(trans[i], dtype=np.float64), [0, 0, 1]])
+        minv[i] = np.linalg.inv(m)[:2].reshape(-1)      # same inverse as the NumPy restatement
+    offs_d = torch.tensor(offs, dtype=torch.int64, device=dev)
+    hw_d = torch.tensor(hw, dtype=torch.int32, device=dev)
+    minv_d = torch.from_numpy(minv).to(dev)
+    nat.check(nat.lib().scpose_crop_warp(_ptr(buf), _ptr(offs_d), _ptr(hw_d), _ptr(minv_d), n, h, w, int(bool(swap_rb)),
+                                         _ptr(out), _stream()), "crop_warp")
+    return out
+
+
 def flip_merge(out, out_flipped, flip_pairs, shift):
     """(out + flip_back(out_flipped)) * 0.5 of the flip test (lib/core/function.py:347-366), on the device.
     out / out_flipped: (N,J,H,W) f32 device heatmaps of the frame and of its x-flipped copy."""

@@ -152,6 +152,15 @@ def test_cli_tools_test_and_pose_export(pk, tmp_path):
     rel = np.abs(preds[:, :, 2] - ref[:, :, 2]).max() / np.abs(ref[:, :, 2]).max()
     assert rel < 5e-2, "maxvals of the CLI run deviate %.3g from the fp32 oracle" % rel
 
+    # the same run with the crops warped on the GPU (scpose_crop_warp): identical crops -> identical predictions
+    out2 = tmp_path / "out_dc"
+    cmd2 = cmd[:2] + ["--device_crop"] + cmd[2:]
+    cmd2[cmd2.index("OUTPUT_DIR") + 1] = str(out2)
+    r = subprocess.run(cmd2, cwd=os.path.join(ROOT, "landmark_regression"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    preds_dc = loadmat(out2 / "EventsDataset" / "pose_hrnet" / "w32_256" / "pred_test.mat")["preds"]
+    assert np.array_equal(preds_dc, preds)
+
     # stage 3 on known-answer keypoints written in the same .mat format
     kp, Rs, ts = P.synth_keypoints(6, np.random.default_rng(4), 0.5, 0.0)
     from scipy.io import savemat
