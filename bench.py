@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--model", default="w48", choices=["w48", "w32"])
     ap.add_argument("--image", type=int, default=None)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
-    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--chained", action="store_true",
                     help="feed the PnP stage with the decoded (random-weight) keypoints instead of synthetic ones")
     return ap.parse_args()
