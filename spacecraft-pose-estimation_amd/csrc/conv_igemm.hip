@@ -250,6 +250,10 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
     if (conv_pipe_lds_bytes(pc, L.plane_stride, 2) > 160 * 1024 || pc.mrep * nrep > 24) groups = 1;
     if (groups == 1 && 2 * pc.mrep * nrep * 4 <= 224) nt = 2;
   }
+  if (!resident && pc.ks == 3 && pc.stride == 2 && pc.mrep >= 4 && nrep <= 2) {
+    static const char* e = getenv("SCPOSE_S2_NT");
+    nt = e ? atoi(e) : 2;   // weight chunk shared by 2 sequential pixel tiles (measured: 3 is no better than 1)
+  }
   if (resident && 2 * conv_pipe_lds_bytes(pc, L.plane_stride, 1) <= 160 * 1024) occ = 2;
   L.cp = pc.cp; L.nchunks = pc.nchunks; L.ksteps_full = pc.ksteps_full;
   L.n_mblk = pc.n_mblk;

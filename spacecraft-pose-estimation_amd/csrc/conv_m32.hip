@@ -9,21 +9,25 @@ namespace scpose {
 
 int32_t conv_m32_dispatch_bf16(int mr, int wm, int nr, int occ, const ConvLaunch& L, size_t lds, hipStream_t st);
 int32_t conv_m32_dispatch_f16(int mr, int wm, int nr, int occ, const ConvLaunch& L, size_t lds, hipStream_t st);
-int32_t conv_m32p_dispatch_bf16(int mr, int nr, const ConvLaunch& L, size_t lds, hipStream_t st);
-int32_t conv_m32p_dispatch_f16(int mr, int nr, const ConvLaunch& L, size_t lds, hipStream_t st);
+int32_t conv_m32p_dispatch_bf16(int stride, int mr, int nr, const ConvLaunch& L, size_t lds, hipStream_t st);
+int32_t conv_m32p_dispatch_f16(int stride, int mr, int nr, const ConvLaunch& L, size_t lds, hipStream_t st);
 
 // kernel variants built (keep in step with m32_dispatch / m32p_dispatch): occ = resident workgroups
 // per CU of the single-role kernel (1, 2), or 3 = the producer/consumer kernel (512 threads, one per CU)
 struct M32Variant { int mr, wm, nr, occ; };
 static const M32Variant kVariants[] = {
-  {3, 1, 3, 1}, {3, 1, 2, 2}, {3, 1, 2, 3}, {3, 1, 3, 3},
+  {3, 1, 3, 1}, {3, 1, 2, 2}, {3, 1, 1, 3}, {3, 1, 2, 3}, {3, 1, 3, 3},
   {2, 1, 2, 1}, {2, 1, 4, 1}, {2, 1, 3, 2}, {2, 1, 3, 3},
 };
 
 bool conv_m32_choose(int cin, int cout, int ks, int stride, int* mr, int* wm, int* cp) {
   static const char* e = getenv("SCPOSE_M32");
   if (e && atoi(e) == 0) return false;
-  if (ks != 3 || stride != 1 || cin % 16 != 0) return false;
+  static const char* e2 = getenv("SCPOSE_M32_S2");
+  if (ks != 3 || cin % 16 != 0) return false;
+  // stride 2 (fuse down paths, transition): producer/consumer kernel only, which needs >= 3 K-chunks;
+  // measured 1.4-1.7x faster than the 16x16x32 kernel on these input-heavy layers (SCPOSE_M32_S2=0 disables)
+  if (stride != 1 && !(stride == 2 && cout % 96 == 0 && cin / 16 >= 3 && !(e2 && atoi(e2) == 0))) return false;
   int m = 0, w = 1;
   if (cout % 96 == 0) m = 3;          // Cout blocks of 96 (HRNet-W48: 96, 192, 384)
   else if (cout % 64 == 0) m = 2;     // Cout blocks of 64 (HRNet-W32: 64, 128, 256; layer1)
@@ -107,6 +111,7 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
     const int nr = v.nr;
     const int cap = wn * nr * 32;
     if (v.occ == 3 && (pc.nchunks < 3 || (pc.cin / 8) % pc.cp != 0)) continue;   // retire-buffer schedule needs >= 3 equal chunks
+    if (pc.stride == 2 && v.occ != 3) continue;
     const int halo_cap = v.occ == 2 ? 512 : 1024;
     const size_t lds_cap = v.occ == 2 ? 80 * 1024 : 160 * 1024;
     for (int ti = 0; ti < 8; ++ti) {
@@ -164,8 +169,8 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   L.grid = (L.items_total + L.items_per_wg - 1) / L.items_per_wg;
   conv_dbg_set_grid(L.grid);
   if (b_occ == 3) {
-    if (pc.dtype == SCPOSE_DT_BF16) return conv_m32p_dispatch_bf16(pc.mrep, b_nr, L, lds, stream);
-    return conv_m32p_dispatch_f16(pc.mrep, b_nr, L, lds, stream);
+    if (pc.dtype == SCPOSE_DT_BF16) return conv_m32p_dispatch_bf16(pc.stride, pc.mrep, b_nr, L, lds, stream);
+    return conv_m32p_dispatch_f16(pc.stride, pc.mrep, b_nr, L, lds, stream);
   }
   if (pc.dtype == SCPOSE_DT_BF16) return conv_m32_dispatch_bf16(pc.mrep, pc.wm, b_nr, b_occ, L, lds, stream);
   return conv_m32_dispatch_f16(pc.mrep, pc.wm, b_nr, b_occ, L, lds, stream);

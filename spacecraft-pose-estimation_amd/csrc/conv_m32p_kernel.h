@@ -416,9 +416,9 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
   }
 }
 
-template <int DT, int MR, int NR>
+template <int DT, int STRIDE, int MR, int NR>
 int32_t m32p_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
-  auto kern = conv_m32p_kernel<DT, 3, 1, MR, NR>;
+  auto kern = conv_m32p_kernel<DT, 3, STRIDE, MR, NR>;
   static bool big_lds_enabled = false;
   if (!big_lds_enabled) {
     SCP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -430,10 +430,17 @@ int32_t m32p_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
 }
 
 template <int DT>
-int32_t m32p_dispatch(int mr, int nr, const ConvLaunch& L, size_t lds, hipStream_t st) {
-  if (mr == 3 && nr == 2) return m32p_launch_one<DT, 3, 2>(L, lds, st);
-  if (mr == 3 && nr == 3) return m32p_launch_one<DT, 3, 3>(L, lds, st);
-  if (mr == 2 && nr == 3) return m32p_launch_one<DT, 2, 3>(L, lds, st);
+int32_t m32p_dispatch(int stride, int mr, int nr, const ConvLaunch& L, size_t lds, hipStream_t st) {
+  if (stride == 2) {
+    if (mr == 3 && nr == 1) return m32p_launch_one<DT, 2, 3, 1>(L, lds, st);
+    if (mr == 3 && nr == 2) return m32p_launch_one<DT, 2, 3, 2>(L, lds, st);
+    set_error("conv m32p: stride-2 variant mr=%d nr=%d not built", mr, nr);
+    return SCPOSE_E_INVALID;
+  }
+  if (mr == 3 && nr == 1) return m32p_launch_one<DT, 1, 3, 1>(L, lds, st);
+  if (mr == 3 && nr == 2) return m32p_launch_one<DT, 1, 3, 2>(L, lds, st);
+  if (mr == 3 && nr == 3) return m32p_launch_one<DT, 1, 3, 3>(L, lds, st);
+  if (mr == 2 && nr == 3) return m32p_launch_one<DT, 1, 2, 3>(L, lds, st);
   set_error("conv m32p: variant mr=%d nr=%d not built", mr, nr);
   return SCPOSE_E_INVALID;
 }

@@ -426,6 +426,10 @@ int32_t pipe_nt(int nt, int occ, const ConvLaunch& L, size_t lds, hipStream_t st
     if (nt == 2) return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 2, 1>(L, lds, st);
     if (nt == 3 && MREP * NREP * 12 <= 224) return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 3, 1>(L, lds, st);
   }
+  if constexpr (KS == 3 && STRIDE == 2 && MREP >= 4 && NREP <= 2) {   // stride 2: a staged weight chunk serves 3 (or 2) pixel tiles
+    if (nt == 3) return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 3, 1>(L, lds, st);
+    if (nt == 2) return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 2, 1>(L, lds, st);
+  }
   if (nt != 1) { set_error("conv: tile group %d unsupported for this variant", nt); return SCPOSE_E_INVALID; }
   if (occ == 2 && MREP * NREP * 4 <= 128) return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 1, 2>(L, lds, st);
   return pipe_launch_one<DT, KS, STRIDE, MREP, NREP, 1, 1>(L, lds, st);
