@@ -17,7 +17,7 @@ int32_t conv_m32p_dispatch_f16(int stride, int mr, int nr, const ConvLaunch& L, 
 struct M32Variant { int mr, wm, nr, occ; };
 static const M32Variant kVariants[] = {
   {3, 1, 3, 1}, {3, 1, 2, 2}, {3, 1, 1, 3}, {3, 1, 2, 3}, {3, 1, 3, 3},
-  {2, 1, 2, 1}, {2, 1, 4, 1}, {2, 1, 3, 2}, {2, 1, 3, 3},
+  {2, 1, 2, 1}, {2, 1, 4, 1}, {2, 1, 3, 2}, {2, 1, 1, 3}, {2, 1, 2, 3}, {2, 1, 3, 3},
 };
 
 bool conv_m32_choose(int cin, int cout, int ks, int stride, int* mr, int* wm, int* cp) {
@@ -27,10 +27,11 @@ bool conv_m32_choose(int cin, int cout, int ks, int stride, int* mr, int* wm, in
   if (ks != 3 || cin % 16 != 0) return false;
   // stride 2 (fuse down paths, transition): producer/consumer kernel only, which needs >= 3 K-chunks;
   // measured 1.4-1.7x faster than the 16x16x32 kernel on these input-heavy layers (SCPOSE_M32_S2=0 disables)
-  if (stride != 1 && !(stride == 2 && cout % 96 == 0 && cin / 16 >= 3 && !(e2 && atoi(e2) == 0))) return false;
+  if (stride != 1 && !(stride == 2 && (cout % 96 == 0 || cout == 48) && cin / 16 >= 3 && !(e2 && atoi(e2) == 0))) return false;
   int m = 0, w = 1;
   if (cout % 96 == 0) m = 3;          // Cout blocks of 96 (HRNet-W48: 96, 192, 384)
   else if (cout % 64 == 0) m = 2;     // Cout blocks of 64 (HRNet-W32: 64, 128, 256; layer1)
+  else if (cout == 48 && stride == 2) m = 2;   // input-bound: one 64-row block with 16 rows of padding
   else return false;
   *mr = m; *wm = w;
   const int planes = cin / 8;

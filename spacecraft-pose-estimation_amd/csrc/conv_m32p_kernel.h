@@ -434,12 +434,16 @@ int32_t m32p_dispatch(int stride, int mr, int nr, const ConvLaunch& L, size_t ld
   if (stride == 2) {
     if (mr == 3 && nr == 1) return m32p_launch_one<DT, 2, 3, 1>(L, lds, st);
     if (mr == 3 && nr == 2) return m32p_launch_one<DT, 2, 3, 2>(L, lds, st);
+    if (mr == 2 && nr == 1) return m32p_launch_one<DT, 2, 2, 1>(L, lds, st);
+    if (mr == 2 && nr == 2) return m32p_launch_one<DT, 2, 2, 2>(L, lds, st);
     set_error("conv m32p: stride-2 variant mr=%d nr=%d not built", mr, nr);
     return SCPOSE_E_INVALID;
   }
   if (mr == 3 && nr == 1) return m32p_launch_one<DT, 1, 3, 1>(L, lds, st);
   if (mr == 3 && nr == 2) return m32p_launch_one<DT, 1, 3, 2>(L, lds, st);
   if (mr == 3 && nr == 3) return m32p_launch_one<DT, 1, 3, 3>(L, lds, st);
+  if (mr == 2 && nr == 1) return m32p_launch_one<DT, 1, 2, 1>(L, lds, st);
+  if (mr == 2 && nr == 2) return m32p_launch_one<DT, 1, 2, 2>(L, lds, st);
   if (mr == 2 && nr == 3) return m32p_launch_one<DT, 1, 2, 3>(L, lds, st);
   set_error("conv m32p: variant mr=%d nr=%d not built", mr, nr);
   return SCPOSE_E_INVALID;
