@@ -103,12 +103,15 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   const int occ_only = occ_env ? atoi(occ_env) : 0;
   // tile search over the built variants: maximise useful MFMA columns, prefer two workgroups per CU
   // (one computes while the other is stalled in its memory instructions), then pixels per weight chunk
-  double best = -1e30;
-  bool found = false;
+  double best = -1e30, best_p = 1e30;
+  bool found = false, found_p = false;
   int b_th = 0, b_tw = 0, b_nseg = 0, b_nr = 0, b_ps = 0, b_occ = 1;
+  int p_th = 0, p_tw = 0, p_nseg = 0, p_nr = 0, p_ps = 0;   // best producer/consumer candidate (cost model)
+  const int cus = conv_device_cus();
   const int tw_cand[8] = {L.Wo, 64, 48, 32, 24, 16, 12, 8};
   for (const M32Variant& v : kVariants) {
-    if (v.mr != pc.mrep || v.wm != pc.wm || (occ_only && v.occ != occ_only)) continue;
+    static const char* nr_env = getenv("SCPOSE_M32_NR");   // development: restrict the search to one column count
+    if (v.mr != pc.mrep || v.wm != pc.wm || (occ_only && v.occ != occ_only) || (nr_env && v.nr != atoi(nr_env))) continue;
     const int nr = v.nr;
     const int cap = wn * nr * 32;
     if (v.occ == 3 && (pc.nchunks < 3 || (pc.cin / 8) % pc.cp != 0)) continue;   // retire-buffer schedule needs >= 3 equal chunks
@@ -128,11 +131,29 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
           const double eff = (double)L.Ho * L.Wo / ((double)tx * ty / nseg * cap);
           // measured preference: producer/consumer for 96-row blocks, two workgroups per CU for 64-row blocks
           const double pref = v.occ == 3 ? (v.mr == 3 ? 1.5 : 1.1) : v.occ == 2 ? 1.25 : 1.0;
+          if (v.occ == 3) {
+            // producer/consumer candidates are ranked by a cycle model fitted to the phase stamps:
+            // stage = max(consumer MFMAs, producer bytes at ~13 B/clk) + barrier; items are quantised per CU
+            const long items = (((long)L.N * tx * ty + nseg - 1) / nseg) * pc.n_mblk;
+            const double per_cu = (double)((items + cus - 1) / cus);
+            const double mfma = (double)v.mr * nr * (pc.cp / 2) * pc.ks * pc.ks * 32.0 * 1.35;
+            const bool res_w = m32p_wbufs(pc, ps, nr) > 2;
+            const double bytes = (res_w ? 0.0 : (double)pc.ksteps_full * 2 * pc.mt * 16) + (double)pc.cp * ps +
+                                 2.0 * pc.mt * (nseg * th * tw) * 2 / pc.nchunks;
+            const double stage = (mfma > bytes / 13.0 ? mfma : bytes / 13.0) + 700.0;
+            const double cost = per_cu * (pc.nchunks * stage + (double)v.mr * nr * 16 * 25.0);
+            if (cost < best_p) { found_p = true; best_p = cost; p_th = th; p_tw = tw; p_nseg = nseg; p_nr = nr; p_ps = ps; }
+            continue;
+          }
           const double score = eff * pref / (1.0 + 2.0 / (wn * nr)) - 0.02 * (double)(hh * hw) / (th * tw);
           if (score > best) { found = true; best = score; b_th = th; b_tw = tw; b_nseg = nseg; b_nr = nr; b_ps = ps; b_occ = v.occ; }
         }
       }
     }
+  }
+  // measured preference: producer/consumer for 96-row blocks and for stride 2, two workgroups per CU for 64-row blocks
+  if (found_p && (!found || pc.mrep == 3 || pc.stride == 2)) {
+    found = true; b_th = p_th; b_tw = p_tw; b_nseg = p_nseg; b_nr = p_nr; b_ps = p_ps; b_occ = 3;
   }
   SCP_REQUIRE(found, "conv m32: no tiling for %dx%d output", L.Ho, L.Wo);
   L.th = b_th; L.tw = b_tw; L.nt = b_nseg;
