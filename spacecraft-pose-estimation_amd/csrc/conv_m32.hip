@@ -31,7 +31,8 @@ bool conv_m32_choose(int cin, int cout, int ks, int stride, int* mr, int* wm, in
   int m = 0, w = 1;
   if (cout % 96 == 0) m = 3;          // Cout blocks of 96 (HRNet-W48: 96, 192, 384)
   else if (cout % 64 == 0) m = 2;     // Cout blocks of 64 (HRNet-W32: 64, 128, 256; layer1)
-  else if (cout == 48 && stride == 2) m = 2;   // input-bound: one 64-row block with 16 rows of padding
+  else if (cout == 48 && (stride == 2 || cin >= 96)) m = 2;   // one 64-row block with 16 rows of padding: input-bound
+                                                               // stride-2 layers and the deep-K transition conv
   else return false;
   *mr = m; *wm = w;
   const int planes = cin / 8;
@@ -152,7 +153,7 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
     }
   }
   // measured preference: producer/consumer for 96-row blocks and for stride 2, two workgroups per CU for 64-row blocks
-  if (found_p && (!found || pc.mrep == 3 || pc.stride == 2)) {
+  if (found_p && (!found || pc.mrep == 3 || pc.stride == 2 || pc.cout == 48)) {
     found = true; b_th = p_th; b_tw = p_tw; b_nseg = p_nseg; b_nr = p_nr; b_ps = p_ps; b_occ = 3;
   }
   SCP_REQUIRE(found, "conv m32: no tiling for %dx%d output", L.Ho, L.Wo);
