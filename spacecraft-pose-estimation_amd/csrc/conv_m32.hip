@@ -27,7 +27,7 @@ bool conv_m32_choose(int cin, int cout, int ks, int stride, int* mr, int* wm, in
   if (ks != 3 || cin % 16 != 0) return false;
   // stride 2 (fuse down paths, transition): producer/consumer kernel only, which needs >= 3 K-chunks;
   // measured 1.4-1.7x faster than the 16x16x32 kernel on these input-heavy layers (SCPOSE_M32_S2=0 disables)
-  if (stride != 1 && !(stride == 2 && (cout % 96 == 0 || cout == 48) && cin / 16 >= 3 && !(e2 && atoi(e2) == 0))) return false;
+  if (stride != 1 && !(stride == 2 && (cout % 96 == 0 || cout % 64 == 0 || cout == 48) && cin / 16 >= 3 && !(e2 && atoi(e2) == 0))) return false;
   int m = 0, w = 1;
   if (cout % 96 == 0) m = 3;          // Cout blocks of 96 (HRNet-W48: 96, 192, 384)
   else if (cout % 64 == 0) m = 2;     // Cout blocks of 64 (HRNet-W32: 64, 128, 256; layer1)
