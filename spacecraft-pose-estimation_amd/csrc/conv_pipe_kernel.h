@@ -257,8 +257,12 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
           }
         }
         // (2) DMA for the next stage: its input tile, plus this sub-stage's slice of the next weight chunk
+        // single-chunk layers with several Cout blocks (1x1 64->256): consecutive items are the Cout
+        // blocks of ONE pixel tile, whose staged input is reused instead of being fetched again
+        const bool same_x = NT == 1 && G == 1 && p.nchunks == 1 && have_next_chunk &&
+                            pipe_fdiv(nit, p.fd_nmblk) == pipe_fdiv(it, p.fd_nmblk);
         if (J + 1 < NT) issue_x(it, J + 1, c, xb ^ 1);
-        else if (have_next_chunk) issue_x(nit, 0, nc, xb ^ 1);
+        else if (have_next_chunk && !same_x) issue_x(nit, 0, nc, xb ^ 1);
         if (have_next_chunk && !w_resident) issue_w(nit, nc, (wc + 1) & 1, J, NT);
 
         const unsigned long long t1 = now();
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
           const unsigned long long t6 = now();
           tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; tph[3] += t4 - t3; tph[4] += t5 - t4; tph[5] += t6 - t5;
         }
-        xb ^= 1;
+        if (!same_x) xb ^= 1;
       };
 
       stage(std::integral_constant<int, 0>{});
