@@ -135,31 +135,50 @@ def main():
     lm = torch.from_numpy(syn.TANGO_LANDMARKS).to(dev)
     Kc = torch.from_numpy(syn.SPEEDPLUS_K).to(dev)
     dc = torch.from_numpy(syn.SPEEDPLUS_DIST).to(dev)
-    heat = torch.empty((B, JOINTS, hh, hh), dtype=torch.float32, device=dev)
-    block = torch.empty((B, 13), dtype=torch.float64, device=dev)
-    gathered = torch.empty((world * B, 13), dtype=torch.float64, device=dev) if world > 1 else None
+    # Steps are software-pipelined over two streams: decode + PnP + all-gather + D2H of step i run on a side
+    # stream while the forward of step i+1 runs on the main stream (double-buffered heatmaps / result blocks /
+    # pinned host buffers).  Every step's results are on the host before the closing barrier + synchronize.
+    heat = [torch.empty((B, JOINTS, hh, hh), dtype=torch.float32, device=dev) for _ in range(2)]
+    block = [torch.empty((B, 13), dtype=torch.float64, device=dev) for _ in range(2)]
+    gathered = [torch.empty((world * B, 13), dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    host_buf = [torch.empty((world * B, 13), dtype=torch.float64).pin_memory() for _ in range(2)] if rank == 0 else None
+    side = torch.cuda.Stream(device=dev)
+    done = [None, None]
+    counter = [0]
 
     prof_ms = {}
 
     def step(profile):
-        eng.forward(frames, out=heat, profile=profile)
-        kp = ops.decode(heat, center, scale, True)
-        rot, tv, st = ops.pnp_epnp_ransac(kp if args.chained else kp_syn, lm, Kc, dc)
-        block[:, 0:9] = rot.view(B, 9)
-        block[:, 9:12] = tv
-        block[:, 12] = st.double()
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, block)
-            out = gathered
-        else:
-            out = block
-        host = out.cpu() if rank == 0 else None     # (R, t, status) of every frame on rank 0's host
-        if profile:
+        k = counter[0] & 1
+        counter[0] += 1
+        main = torch.cuda.current_stream()
+        if done[k] is not None:
+            main.wait_event(done[k])              # buffers k were last read by the side stream two steps ago
+        eng.forward(frames, out=heat[k], profile=profile)
+        fwd_done = torch.cuda.Event()
+        fwd_done.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(fwd_done)
+            kp = ops.decode(heat[k], center, scale, True)
+            rot, tv, st = ops.pnp_epnp_ransac(kp if args.chained else kp_syn, lm, Kc, dc)
+            block[k][:, 0:9] = rot.view(B, 9)
+            block[k][:, 9:12] = tv
+            block[k][:, 12] = st.double()
+            if world > 1:
+                dist.all_gather_into_tensor(gathered[k], block[k])
+                out = gathered[k]
+            else:
+                out = block[k]
+            if rank == 0:
+                host_buf[k].copy_(out, non_blocking=True)   # (R, t, status) of every frame on rank 0's host
+            done[k] = torch.cuda.Event()
+            done[k].record(side)
+        if profile:   # per-launch HIP events of this forward (blocks the host until the forward has finished)
             for rec in eng.profile_read():
                 key = (rec["kind"], rec["a"], rec["cin"], rec["cout"])
                 e = prof_ms.setdefault(key, [0.0, 0, 0.0, 0.0])
                 e[0] += rec["ms"]; e[1] += 1; e[2] += rec["flops_per_frame"] * B; e[3] += rec["bytes_per_frame"] * B
-        return host
+        return host_buf[k] if rank == 0 else None
 
     def barrier():
         if world > 1:
@@ -225,7 +244,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "HRNet-%s %dx%d %d joints, batch %d per GPU + batched EPnP-RANSAC HIP kernel%s" % (
                            args.model.upper(), image, image, JOINTS, B, " (PnP chained to decoded keypoints)" if args.chained else ""),
-                       "frames_per_step": world * B, "parallelism": "frame-sharded x%d, all-gather of (R,t,status)" % world,
+                       "frames_per_step": world * B, "parallelism": "frame-sharded x%d, all-gather of (R,t,status); PnP/gather/D2H of step i overlap the forward of step i+1" % world,
                        "pnp_input": "decoded" if args.chained else "synthetic projected landmarks, 1 px noise, 10% outliers",
                        "launches_per_forward": st["launches"], "gflop_per_frame": round(st["flops_per_frame"] / 1e9, 3),
                        "act_mbytes_per_frame": round(st["act_bytes_per_frame"] / 1e6, 2)},
