@@ -192,6 +192,9 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   L.grid = (L.items_total + L.items_per_wg - 1) / L.items_per_wg;
   conv_dbg_set_grid(L.grid);
   if (b_occ == 3) {
+    // L.groups doubles as "K-chunks of weights held in producer registers" for the producer/consumer kernel
+    static const char* wr_env = getenv("SCPOSE_M32_WREG");
+    L.groups = (pc.n_mblk == 1 && pc.nchunks == 6 && pc.stride == 1 && pc.mrep == 3 && b_nr == 3 && !(wr_env && atoi(wr_env) == 0)) ? 6 : 1;
     if (pc.dtype == SCPOSE_DT_BF16) return conv_m32p_dispatch_bf16(pc.stride, pc.mrep, b_nr, L, lds, stream);
     return conv_m32p_dispatch_f16(pc.stride, pc.mrep, b_nr, L, lds, stream);
   }

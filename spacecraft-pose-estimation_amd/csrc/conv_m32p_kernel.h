@@ -22,7 +22,10 @@
 
 namespace scpose {
 
-template <int DT, int KS, int STRIDE, int MR, int NR>
+// WREG > 0: the layer has ONE Cout block of WREG K-chunks and the producers keep all of its packed weights in
+// their (otherwise idle) registers -- 7 x 16 B per thread and chunk -- and refill the LDS chunk buffers with
+// ds_write_b128 instead of LDS-DMA: 7 of the ~16 memory instructions a producer wave issues per stage disappear.
+template <int DT, int KS, int STRIDE, int MR, int NR, int WREG = 0>
 __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename DtOf<DT>::type T;
@@ -129,9 +132,42 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
         }
       }
     };
+    constexpr int WSLOTS = (KK * 2 * MT * 16 + 4095) / 4096;   // 16-byte slots per thread of a 2-plane chunk
+    u32x4 wreg[WREG > 0 ? WREG : 1][WSLOTS];
+    if constexpr (WREG > 0) {
+      const int nbytes = ksteps_full * (2 * MT * 16);
+#pragma unroll
+      for (int c = 0; c < WREG; ++c)
+#pragma unroll
+        for (int j = 0; j < WSLOTS; ++j) {
+          const int mine = j * 4096 + ptid * 16;
+          wreg[c][j] = mine < nbytes ? *reinterpret_cast<const u32x4*>(static_cast<const char*>(p.wpk) + (size_t)c * chunk_wbytes + mine)
+                                     : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
     auto issue_w = [&](int it, int cl, int wb) {
       const int c = cl + crot < p.nchunks ? cl + crot : cl + crot - p.nchunks;
       const int nbytes = ksteps_full * (2 * MT * 16);
+      if constexpr (WREG > 0) {   // registers -> LDS (same image as the DMA would write)
+        char* wl = wl0 + wb * p.lds_w + ptid * 16;
+        auto put = [&](auto cc) {
+          constexpr int C = decltype(cc)::value;
+          if constexpr (C < WREG) {
+#pragma unroll
+            for (int j = 0; j < WSLOTS; ++j)
+              if (j * 4096 + ptid * 16 < nbytes) *reinterpret_cast<u32x4*>(wl + j * 4096) = wreg[C][j];
+          }
+        };
+        switch (c) {
+          case 0: put(std::integral_constant<int, 0>{}); break;
+          case 1: put(std::integral_constant<int, 1>{}); break;
+          case 2: put(std::integral_constant<int, 2>{}); break;
+          case 3: put(std::integral_constant<int, 3>{}); break;
+          case 4: put(std::integral_constant<int, 4>{}); break;
+          default: put(std::integral_constant<int, 5>{}); break;
+        }
+        return;
+      }
       const char* ws = static_cast<const char*>(p.wpk) + ((size_t)(it - fdiv(it, p.fd_nmblk) * p.n_mblk) * p.nchunks + c) * chunk_wbytes;
       char* wl = wl0 + wb * p.lds_w;
       for (int o = 0; o < nbytes; o += 4096) {
@@ -416,9 +452,9 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
   }
 }
 
-template <int DT, int STRIDE, int MR, int NR>
+template <int DT, int STRIDE, int MR, int NR, int WREG = 0>
 int32_t m32p_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
-  auto kern = conv_m32p_kernel<DT, 3, STRIDE, MR, NR>;
+  auto kern = conv_m32p_kernel<DT, 3, STRIDE, MR, NR, WREG>;
   static bool big_lds_enabled = false;
   if (!big_lds_enabled) {
     SCP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -441,6 +477,7 @@ int32_t m32p_dispatch(int stride, int mr, int nr, const ConvLaunch& L, size_t ld
   }
   if (mr == 3 && nr == 1) return m32p_launch_one<DT, 1, 3, 1>(L, lds, st);
   if (mr == 3 && nr == 2) return m32p_launch_one<DT, 1, 3, 2>(L, lds, st);
+  if (mr == 3 && nr == 3 && L.groups == 6) return m32p_launch_one<DT, 1, 3, 3, 6>(L, lds, st);   // weights in producer registers
   if (mr == 3 && nr == 3) return m32p_launch_one<DT, 1, 3, 3>(L, lds, st);
   if (mr == 2 && nr == 1) return m32p_launch_one<DT, 1, 2, 1>(L, lds, st);
   if (mr == 2 && nr == 2) return m32p_launch_one<DT, 1, 2, 2>(L, lds, st);
