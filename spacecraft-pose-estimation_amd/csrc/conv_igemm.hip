@@ -18,6 +18,7 @@
 //     2*pp + (q&1) at tap pt = 2*s + (q>>1).  The two k-groups that share a ds_read_b128
 //     lane group (q = 0,1 and q = 2,3) therefore differ by one whole LDS plane, whose stride
 //     is padded so both land on disjoint banks.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -234,6 +235,13 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
     L.th /= 2;
     set_geometry();
     if (2 * conv_pipe_lds_bytes(pc, L.plane_stride, 1) > 160 * 1024) { L.th = th0; set_geometry(); }
+  }
+  {   // development: SCPOSE_TILE="th,tw" overrides the tile of weight-resident 3x3 stride-1 layers
+    static const char* e = getenv("SCPOSE_TILE");
+    int eth = 0, etw = 0;
+    if (e && resident && pc.ks == 3 && pc.stride == 1 && sscanf(e, "%d,%d", &eth, &etw) == 2 && eth > 0 && etw > 0) {
+      L.th = eth; L.tw = etw; set_geometry();
+    }
   }
   // Weight-streaming 3x3 layers.  Measured on MI355X: a CU's LDS-DMA path moves ~16 B/clk and the
   // issuing wave stalls for it.  So (a) the bytes staged per MFMA must be small: one staged weight
