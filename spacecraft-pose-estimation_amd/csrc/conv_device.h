@@ -29,6 +29,23 @@ template <typename T> __device__ __forceinline__ float from_bits(uint16_t v) {
   return (float)__builtin_bit_cast(T, v);
 }
 
+// two fp32 -> one dword of two 16-bit values (a in the low half), one v_cvt_pk_* instruction, RNE like the scalar cast
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(2))) short i16x2_t;
+template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b) {
+  const f32x2 v = {a, b};
+  if constexpr (__is_same(T, __bf16)) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+  else return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+// ReLU on a packed pair of bf16/f16 (sign-magnitude formats): signed 16-bit max against `floor2`, which is 0 for
+// ReLU and 0x80008000 (no-op) otherwise -- one v_pk_max_i16, no branch.  (-0 and negative NaNs become +0.)
+__device__ __forceinline__ uint32_t relu2_16(uint32_t x, uint32_t floor2) {
+  const i16x2_t r = __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, x), __builtin_bit_cast(i16x2_t, floor2));
+  return __builtin_bit_cast(uint32_t, r);
+}
+
 // Blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous range of
 // logical ids so that neighbouring tiles / Cout blocks of one tile hit the same L2.
 __device__ __forceinline__ int xcd_remap(int b, int nb) {

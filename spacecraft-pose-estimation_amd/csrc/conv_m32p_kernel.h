@@ -394,6 +394,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
                      // writes those two 8-byte half-slots directly, so no permlane and no bias add are needed.
           // residual half-slots are read one (m, g) batch ahead of the batch being finalised: the
           // in-place writes would otherwise order every read behind the previous write
+          const uint32_t relu_floor = p.relu ? 0u : 0x80008000u;
           uint2 ra[2][NR], rb[2][NR];
           auto slot_a = [&](int b, int n) -> char* {   // b = 2*m + g
             return ro + ((((b >> 1) * 4 + 2 * (b & 1)) * PXCAP) + (wave * NR + n) * 32 + r) * 16 + 8 * half;
@@ -421,15 +422,9 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
               v[2] = acc[m][n][8 * g + 2] + from_bits<T>(xa.y & 0xffff); v[3] = acc[m][n][8 * g + 3] + from_bits<T>(xa.y >> 16);
               v[4] = acc[m][n][8 * g + 4] + from_bits<T>(xb2.x & 0xffff); v[5] = acc[m][n][8 * g + 5] + from_bits<T>(xb2.x >> 16);
               v[6] = acc[m][n][8 * g + 6] + from_bits<T>(xb2.y & 0xffff); v[7] = acc[m][n][8 * g + 7] + from_bits<T>(xb2.y >> 16);
-              if (p.relu) {
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) v[jj] = fmaxf(v[jj], 0.f);
-              }
               uint2 oa, ob;
-              oa.x = (uint32_t)to_bits<T>(v[0]) | ((uint32_t)to_bits<T>(v[1]) << 16);
-              oa.y = (uint32_t)to_bits<T>(v[2]) | ((uint32_t)to_bits<T>(v[3]) << 16);
-              ob.x = (uint32_t)to_bits<T>(v[4]) | ((uint32_t)to_bits<T>(v[5]) << 16);
-              ob.y = (uint32_t)to_bits<T>(v[6]) | ((uint32_t)to_bits<T>(v[7]) << 16);
+              oa.x = relu2_16(pack2<T>(v[0], v[1]), relu_floor); oa.y = relu2_16(pack2<T>(v[2], v[3]), relu_floor);
+              ob.x = relu2_16(pack2<T>(v[4], v[5]), relu_floor); ob.y = relu2_16(pack2<T>(v[6], v[7]), relu_floor);
               if (pvalid[n]) {
                 *reinterpret_cast<uint2*>(slot_a(b, n)) = oa;
                 *reinterpret_cast<uint2*>(slot_a(b, n) + PXCAP * 16) = ob;

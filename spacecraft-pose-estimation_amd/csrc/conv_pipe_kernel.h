@@ -345,15 +345,10 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
               v[2] += from_bits<T>(rv[1] & 0xffff); v[3] += from_bits<T>(rv[1] >> 16);
               v[4] += from_bits<T>(rv[2] & 0xffff); v[5] += from_bits<T>(rv[2] >> 16);
               v[6] += from_bits<T>(rv[3] & 0xffff); v[7] += from_bits<T>(rv[3] >> 16);
-              if (p.relu) {
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) v[jj] = fmaxf(v[jj], 0.f);
-              }
+              const uint32_t relu_floor = p.relu ? 0u : 0x80008000u;   // packed ReLU: signed 16-bit max (conv_device.h)
               u32x4 ov;
-              ov[0] = (uint32_t)to_bits<T>(v[0]) | ((uint32_t)to_bits<T>(v[1]) << 16);
-              ov[1] = (uint32_t)to_bits<T>(v[2]) | ((uint32_t)to_bits<T>(v[3]) << 16);
-              ov[2] = (uint32_t)to_bits<T>(v[4]) | ((uint32_t)to_bits<T>(v[5]) << 16);
-              ov[3] = (uint32_t)to_bits<T>(v[6]) | ((uint32_t)to_bits<T>(v[7]) << 16);
+              ov[0] = relu2_16(pack2<T>(v[0], v[1]), relu_floor); ov[1] = relu2_16(pack2<T>(v[2], v[3]), relu_floor);
+              ov[2] = relu2_16(pack2<T>(v[4], v[5]), relu_floor); ov[3] = relu2_16(pack2<T>(v[6], v[7]), relu_floor);
               slot[m][np] = ov;
             }
           }
