@@ -1,47 +1,51 @@
-"""PCK accuracy logged by validate() (landmark_regression/lib/core/evaluate.py:16-71).  The two
-argmax passes (output and target) run on the HIP decode kernel; the tiny per-joint distance
-statistics stay on the host, as in the reference."""
+"""PCK accuracy that validate() logs (semantics of landmark_regression/lib/core/evaluate.py:16-71).
+
+Vectorised restatement: both argmax passes (prediction and target heat-maps) run on the HIP decode
+kernel; the per-joint distance statistics are a handful of NumPy array operations on the host.
+Rules kept from the reference: a joint takes part only when BOTH target coordinates are > 1; distances
+are Euclidean after dividing by (H, W) / 10; a joint's score is the fraction of its participating
+samples closer than `thr`; joints without participants score -1 and are left out of the average;
+slot 0 of the returned vector holds that average.
+"""
 import numpy as np
 
 from .inference import get_max_preds
 
 
+def _normalised_distances(pred, gt, scale):
+    """(J, N) float64 distances, -1 where the ground-truth joint is not usable."""
+    p = pred.astype(np.float32) / scale[:, None, :]
+    g = gt.astype(np.float32) / scale[:, None, :]
+    d = np.sqrt(((p - g) ** 2).sum(axis=2)).astype(np.float64)
+    usable = (gt[..., 0] > 1) & (gt[..., 1] > 1)
+    return np.where(usable, d, -1.0).T
+
+
 def calc_dists(preds, target, normalize):
-    preds = preds.astype(np.float32)
-    target = target.astype(np.float32)
-    dists = np.zeros((preds.shape[1], preds.shape[0]))
-    for n in range(preds.shape[0]):
-        for c in range(preds.shape[1]):
-            if target[n, c, 0] > 1 and target[n, c, 1] > 1:
-                dists[c, n] = np.linalg.norm(preds[n, c, :] / normalize[n] - target[n, c, :] / normalize[n])
-            else:
-                dists[c, n] = -1
-    return dists
+    normalize = np.broadcast_to(np.asarray(normalize, dtype=np.float64), (preds.shape[0], 2))
+    return _normalised_distances(preds, target, normalize)
 
 
 def dist_acc(dists, thr=0.5):
-    dist_cal = np.not_equal(dists, -1)
-    num = dist_cal.sum()
-    return np.less(dists[dist_cal], thr).sum() * 1.0 / num if num > 0 else -1
+    valid = dists != -1
+    n = int(valid.sum())
+    return float((dists[valid] < thr).sum()) / n if n else -1
 
 
 def accuracy(output, target, hm_type="gaussian", thr=0.5):
-    idx = list(range(output.shape[1]))
-    norm = 1.0
-    if hm_type == "gaussian":
-        pred, _ = get_max_preds(output)
-        target, _ = get_max_preds(target)
-        h, w = output.shape[2], output.shape[3]
-        norm = np.ones((pred.shape[0], 2)) * np.array([h, w]) / 10
-    dists = calc_dists(pred, target, norm)
-    acc = np.zeros((len(idx) + 1))
-    avg_acc, cnt = 0, 0
-    for i in range(len(idx)):
-        acc[i + 1] = dist_acc(dists[idx[i]])
-        if acc[i + 1] >= 0:
-            avg_acc += acc[i + 1]
-            cnt += 1
-    avg_acc = avg_acc / cnt if cnt != 0 else 0
-    if cnt != 0:
-        acc[0] = avg_acc
-    return acc, avg_acc, cnt, pred
+    if hm_type != "gaussian":
+        raise ValueError("accuracy: only gaussian heat-maps are supported")
+    pred, _ = get_max_preds(output)
+    gt, _ = get_max_preds(target)
+    n, j, h, w = output.shape
+    scale = np.tile(np.array([h, w], dtype=np.float64) / 10.0, (n, 1))
+    dists = _normalised_distances(pred, gt, scale)
+    per_joint = np.array([dist_acc(dists[k], thr) for k in range(j)], dtype=np.float64)
+    scored = per_joint >= 0
+    cnt = int(scored.sum())
+    avg = float(per_joint[scored].mean()) if cnt else 0
+    acc = np.zeros(j + 1)
+    acc[1:] = per_joint
+    if cnt:
+        acc[0] = avg
+    return acc, avg, cnt, pred
