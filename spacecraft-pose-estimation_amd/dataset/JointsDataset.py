@@ -111,33 +111,29 @@ class JointsDataset(Dataset):
         return frames, rest[0], rest[1], rest[2]
 
     def generate_target(self, joints, joints_vis):
-        """Gaussian heatmaps, peak 1.0 at the integer centre (JointsDataset.py:264-332)."""
-        target_weight = np.ones((self.num_joints, 1), dtype=np.float32)
-        target_weight[:, 0] = joints_vis[:, 0]
+        """Gaussian heat-maps (JointsDataset.py:264-332): value exp(-d^2 / 2 sigma^2) inside the (6 sigma + 1)^2
+        window centred on the rounded joint position, 0 elsewhere; a joint whose window misses the map
+        entirely gets weight 0 and an empty map.  Evaluated on the whole grid at once in float32."""
         assert self.target_type == "gaussian", "Only support gaussian map now!"
-        hw, hh = int(self.heatmap_size[0]), int(self.heatmap_size[1])
-        target = np.zeros((self.num_joints, hh, hw), dtype=np.float32)
-        tmp_size = self.sigma * 3
-        size = 2 * tmp_size + 1
-        x = np.arange(0, size, 1, np.float32)
-        y = x[:, np.newaxis]
-        x0 = y0 = size // 2
-        g = np.exp(-((x - x0) ** 2 + (y - y0) ** 2) / (2 * self.sigma ** 2))
-        feat_stride = self.image_size / self.heatmap_size
-        for j in range(self.num_joints):
-            mu_x = int(joints[j][0] / feat_stride[0] + 0.5)
-            mu_y = int(joints[j][1] / feat_stride[1] + 0.5)
-            ul = [int(mu_x - tmp_size), int(mu_y - tmp_size)]
-            br = [int(mu_x + tmp_size + 1), int(mu_y + tmp_size + 1)]
-            if ul[0] >= hw or ul[1] >= hh or br[0] < 0 or br[1] < 0:
-                target_weight[j] = 0
+        wmap, hmap = int(self.heatmap_size[0]), int(self.heatmap_size[1])
+        weight = np.ones((self.num_joints, 1), dtype=np.float32)
+        weight[:, 0] = joints_vis[:, 0]
+        target = np.zeros((self.num_joints, hmap, wmap), dtype=np.float32)
+        reach = self.sigma * 3
+        stride = self.image_size / self.heatmap_size
+        gx = np.arange(wmap, dtype=np.float32)[None, :]
+        gy = np.arange(hmap, dtype=np.float32)[:, None]
+        denom = np.float32(2 * self.sigma ** 2)
+        for k in range(self.num_joints):
+            cx = int(joints[k][0] / stride[0] + 0.5)
+            cy = int(joints[k][1] / stride[1] + 0.5)
+            if cx - reach >= wmap or cy - reach >= hmap or cx + reach + 1 < 0 or cy + reach + 1 < 0:
+                weight[k] = 0
                 continue
-            g_x = max(0, -ul[0]), min(br[0], hw) - ul[0]
-            g_y = max(0, -ul[1]), min(br[1], hh) - ul[1]
-            img_x = max(0, ul[0]), min(br[0], hw)
-            img_y = max(0, ul[1]), min(br[1], hh)
-            if target_weight[j] > 0.5:
-                target[j][img_y[0]:img_y[1], img_x[0]:img_x[1]] = g[g_y[0]:g_y[1], g_x[0]:g_x[1]]
+            if weight[k] > 0.5:
+                dx, dy = gx - np.float32(cx), gy - np.float32(cy)
+                inside = (np.abs(dx) <= reach) & (np.abs(dy) <= reach)
+                target[k] = np.where(inside, np.exp(-(dx ** 2 + dy ** 2) / denom), np.float32(0))
         if self.use_different_joints_weight:
-            target_weight = np.multiply(target_weight, self.joints_weight)
-        return target, target_weight
+            weight = np.multiply(weight, self.joints_weight)
+        return target, weight

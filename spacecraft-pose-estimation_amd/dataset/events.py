@@ -46,34 +46,33 @@ class EventsDataset(JointsDataset):
         return primary
 
     def _get_db(self):
-        with open(self.annotation_file()) as anno_file:
-            anno = json.load(anno_file)
-        gt_db = []
-        image_annots = {im["id"]: im for im in anno["images"]}
-        for a in anno["annotations"]:
-            image_name = image_annots[a["image_id"]]["file_name"]
-            box = np.array(a["bbox"]).flatten()
-            c, s = self._box2cs(box)
-            joints_3d = np.zeros((self.num_joints, 3), dtype=np.float64)
-            joints_3d_vis = np.zeros((self.num_joints, 3), dtype=np.float64)
-            jr = np.array(a["keypoints"]).reshape((-1, 3))
-            joints_3d[:, 0:2] = jr[:, 0:2]
-            joints_3d_vis[:, 0] = jr[:, -1] - 1      # detectron visibility -> mpii
-            joints_3d_vis[:, 1] = jr[:, -1] - 1
-            x, y, w, h = box[:4]
-            gt_db.append({"image": os.path.join(self.DATA_DIR, image_name), "center": c, "scale": s, "box_w": w,
-                          "box_h": h, "joints_3d": joints_3d, "joints_3d_vis": joints_3d_vis, "filename": "", "imgnum": 0})
-        return gt_db
+        """One record per entry of annotations[] (that order is the row order of preds)."""
+        with open(self.annotation_file()) as fh:
+            coco = json.load(fh)
+        file_of = {im["id"]: im["file_name"] for im in coco["images"]}
+        records = []
+        for ann in coco["annotations"]:
+            bbox = np.asarray(ann["bbox"], dtype=np.float64).reshape(-1)
+            center, scale = self._box2cs(bbox)
+            kp = np.asarray(ann["keypoints"], dtype=np.float64).reshape(-1, 3)
+            xy = np.zeros((self.num_joints, 3), dtype=np.float64)
+            vis = np.zeros((self.num_joints, 3), dtype=np.float64)
+            xy[:, :2] = kp[:, :2]
+            vis[:, :2] = (kp[:, 2] - 1)[:, None]          # COCO visibility {1, 2} -> {0, 1} on both axes
+            records.append({"image": os.path.join(self.DATA_DIR, file_of[ann["image_id"]]), "center": center,
+                            "scale": scale, "box_w": bbox[2], "box_h": bbox[3], "joints_3d": xy,
+                            "joints_3d_vis": vis, "filename": "", "imgnum": 0})
+        return records
 
     def _box2cs(self, box):
-        x, y, w, h = box[:4]
-        return self._xywh2cs(x, y, w, h)
+        return self._xywh2cs(*box[:4])
 
     def _xywh2cs(self, x, y, w, h):
-        center = np.zeros((2), dtype=np.float32)
-        center[0] = x + w * 0.5
-        center[1] = y + h * 0.5
-        scale = np.array([w * 1.0 / self.pixel_std, h * 1.0 / self.pixel_std], dtype=np.float32)
+        """bbox -> (center, scale): centre of the box in float32; scale = box size / 200, enlarged 1.5x
+        (the aspect-ratio fix of the COCO loader is disabled in the reference, events.py:103-106)."""
+        center = np.array([x + 0.5 * w, y + 0.5 * h], dtype=np.float32)
+        scale = np.array([w, h], dtype=np.float64) / self.pixel_std
+        scale = scale.astype(np.float32)
         if center[0] != -1:
             scale = scale * 1.5
         return center, scale
