@@ -29,6 +29,20 @@ template <typename T> __device__ __forceinline__ float from_bits(uint16_t v) {
   return (float)__builtin_bit_cast(T, v);
 }
 
+// single-instruction asm pieces of the hand-scheduled MFMA loops (the compiler neither reorders them nor
+// inserts waits for them; the loops wait explicitly)
+template <int OFF, typename F>
+__device__ __forceinline__ void lds_read16(F& d, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <typename F>
+__device__ __forceinline__ void lds_landed(F& d) { asm volatile("" : "+v"(d)); }
+template <typename T>
+__device__ __forceinline__ void mfma16_acc(f32x4& c, const typename FragOf<T>::type& a, const typename FragOf<T>::type& b) {
+  if constexpr (__is_same(T, __bf16)) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
 // two fp32 -> one dword of two 16-bit values (a in the low half), one v_cvt_pk_* instruction, RNE like the scalar cast
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;

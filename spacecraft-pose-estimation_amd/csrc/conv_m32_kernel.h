@@ -64,13 +64,6 @@ __device__ __forceinline__ void mfma32_acc(f32x16& c, const typename FragOf<T>::
     else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
   }
 }
-template <int OFF, typename F>
-__device__ __forceinline__ void lds_read16(F& d, uint32_t addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
-}
-template <typename F>
-__device__ __forceinline__ void lds_landed(F& d) { asm volatile("" : "+v"(d)); }
-
 __device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
   return (int)((__umulhi((uint32_t)n, f.mul) + (uint32_t)n * f.add) >> f.shift);
 }

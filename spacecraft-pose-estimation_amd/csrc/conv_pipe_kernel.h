@@ -190,6 +190,11 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
     }
   };
 
+  // weight-resident single-chunk 3x3 layers (the HBM-bound high-resolution branch): the k-step offsets are
+  // tile-invariant, so they live in registers and the k-loop below is fully unrolled, hand-scheduled asm
+  constexpr bool ASM_LOOP = KS == 3 && STRIDE == 1 && NT == 1 && G == 1 && MREP * NREP <= 8 && MT <= 64;
+  constexpr int ASM_STEPS = 14;
+  int koffv[ASM_LOOP ? ASM_STEPS : 1];
   float4 bsv[MREP];   // bias of the (single) Cout block stays in registers; several blocks: re-read per item
 #pragma unroll
   for (int m = 0; m < MREP; ++m) bsv[m] = *reinterpret_cast<const float4*>(p.bias + m * 16 + q * 4);
@@ -205,6 +210,10 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
     issue_x(it_begin, 0, 0, 0);
   }
   __syncthreads();            // tables, bias, stage 0 (vmcnt(0) + barrier)
+  if constexpr (ASM_LOOP) {
+#pragma unroll
+    for (int s2 = 0; s2 < ASM_STEPS; ++s2) koffv[s2] = koff[s2 * 4 + q];   // single chunk: table 0 (zero padded to 16 steps)
+  }
 
   int xb = 0;                 // X buffer of the stage being computed
   // development instrumentation (dbg & 8): cycles spent per phase, summed over the launch
@@ -287,7 +296,64 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
 #pragma unroll
               for (int n = 0; n < NREP; ++n) acc[J][m][n] = mfma16<T>(a[m], b[n], acc[J][m][n]);
           };
-          if constexpr (OCC >= 2 && MREP * NREP > 8) {   // big tiles at two waves per SIMD: no room for a second fragment set
+          bool done_asm = false;
+          if constexpr (ASM_LOOP) {
+            if (w_resident && p.nchunks == 1 && ksteps <= ASM_STEPS && ksteps > 0) {
+              done_asm = true;
+              const uint32_t wa = (uint32_t)(size_t)wq;
+              const uint32_t xa = (uint32_t)(size_t)xl;
+              auto issue = [&](auto sc, frag_t* a, frag_t* b) {
+                constexpr int S = decltype(sc)::value;
+                lds_read16<S * (4 * MT * 16)>(a[0], wa);
+                if constexpr (MREP > 1) lds_read16<S * (4 * MT * 16) + 256>(a[1], wa);
+                if constexpr (MREP > 2) lds_read16<S * (4 * MT * 16) + 512>(a[2], wa);
+                if constexpr (MREP > 3) lds_read16<S * (4 * MT * 16) + 768>(a[3], wa);
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) lds_read16<0>(b[n], xa + koffv[S] + pixoff[n]);
+              };
+              auto landed = [&](frag_t* a, frag_t* b) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int m = 0; m < MREP; ++m) lds_landed(a[m]);
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) lds_landed(b[n]);
+              };
+              auto mfma_cols = [&](const frag_t* a, const frag_t* b, int n0, int n1) {
+#pragma unroll
+                for (int n = 0; n < NREP; ++n)
+                  if (n >= n0 && n < n1)
+#pragma unroll
+                    for (int m = 0; m < MREP; ++m) mfma16_acc<T>(acc[J][m][n], a[m], b[n]);
+              };
+              issue(std::integral_constant<int, 0>{}, a0, b0);
+              landed(a0, b0);
+              auto step = [&](auto sc) {
+                constexpr int S = decltype(sc)::value;
+                if (S < ksteps) {
+                  frag_t* ca = (S & 1) ? a1 : a0; frag_t* cb = (S & 1) ? b1 : b0;
+                  frag_t* na = (S & 1) ? a0 : a1; frag_t* nb = (S & 1) ? b0 : b1;
+                  mfma_cols(ca, cb, 0, 1);
+                  if constexpr (S + 1 < ASM_STEPS) {
+                    if (S + 1 < ksteps) issue(std::integral_constant<int, S + 1>{}, na, nb);
+                  }
+                  mfma_cols(ca, cb, 1, NREP);
+                  if constexpr (S + 1 < ASM_STEPS) {
+                    if (S + 1 < ksteps) landed(na, nb);
+                  }
+                }
+              };
+              step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+              step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+              step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+              step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+              step(std::integral_constant<int, 8>{}); step(std::integral_constant<int, 9>{});
+              step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+              step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{});
+              asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // last MFMA's result visible to the VALU
+            }
+          }
+          if (done_asm) {
+          } else if constexpr (OCC >= 2 && MREP * NREP > 8) {   // big tiles at two waves per SIMD: no room for a second fragment set
             for (int st = 0; st < ksteps; ++st) {
               load_frags(st, kt[st * 4], a0, b0);
               mfmas(a0, b0);
