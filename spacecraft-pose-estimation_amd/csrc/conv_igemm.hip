@@ -263,6 +263,17 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
     nt = e ? atoi(e) : 2;   // weight chunk shared by 2 sequential pixel tiles (measured: 3 is no better than 1)
   }
   if (resident && 2 * conv_pipe_lds_bytes(pc, L.plane_stride, 1) <= 160 * 1024) occ = 2;
+  // 1x1 layers are bound by their memory instructions (K is tiny): two workgroups per CU double the waves that
+  // keep loads and stores in flight; halve the pixel tile until two of them fit the LDS and the register budget
+  static const char* e11 = getenv("SCPOSE_K1_OCC");
+  if (pc.ks == 1 && !out_nchw_f32 && !(e11 && atoi(e11) == 1)) {
+    while (L.th % 2 == 0 && L.th * L.tw > 64 &&
+           (2 * conv_pipe_lds_bytes(pc, L.plane_stride, 1) > 160 * 1024 || pc.mrep * nrep * 4 > 128)) {
+      L.th /= 2;
+      set_geometry();
+    }
+    if (2 * conv_pipe_lds_bytes(pc, L.plane_stride, 1) <= 160 * 1024 && pc.mrep * nrep * 4 <= 128) occ = 2;
+  }
   L.cp = pc.cp; L.nchunks = pc.nchunks; L.ksteps_full = pc.ksteps_full;
   L.n_mblk = pc.n_mblk;
   L.relu = relu; L.out_nchw_f32 = out_nchw_f32;
