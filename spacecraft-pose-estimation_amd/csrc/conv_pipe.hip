@@ -82,7 +82,7 @@ int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, 
   if (L.dbg & 8) L.dbg_buf = conv_dbg_buffer(stream);
   const int cus = conv_device_cus();
   int per_cu = (int)((160 * 1024) / lds);
-  per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+  { static const char* e = getenv("SCPOSE_K1_WGS"); const int cap = (pc.ks == 1 && e) ? atoi(e) : 2; per_cu = per_cu < 1 ? 1 : (per_cu > cap ? cap : per_cu); }
   if (occ < 2 || groups > 1) per_cu = 1;   // the variant's register budget assumes one workgroup per CU
   int grid = cus * per_cu;
   if (grid > L.items_total) grid = L.items_total;
