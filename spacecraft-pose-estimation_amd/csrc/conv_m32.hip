@@ -174,7 +174,8 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   L.zero16 = conv_zero_page();
   SCP_REQUIRE(L.zero16, "conv: cannot allocate the zero page");
   L.tiles_total = L.N * L.tiles_x * L.tiles_y;
-  L.total_blocks = L.tiles_total * pc.n_mblk;
+  { static const char* e = getenv("SCPOSE_NST"); const int v = e ? atoi(e) : 0;   // producer/consumer kernel: stages that store the previous tile
+    L.total_blocks = (b_occ == 3 && v > 0 && v <= pc.nchunks - 2) ? v : 0; }
   L.items_total = ((L.tiles_total + L.nt - 1) / L.nt) * pc.n_mblk;
   { static const char* e = getenv("SCPOSE_DBG"); L.dbg = e ? atoi(e) : 0; }
   L.dbg_buf = nullptr;

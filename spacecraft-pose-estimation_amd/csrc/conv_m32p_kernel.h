@@ -84,7 +84,8 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
     oy0 = ty * p.th; ox0 = (rem - ty * p.tiles_x) * p.tw;
   };
   // number of stages at the head of a tile in which the previous tile's results are stored
-  const int n_st = p.nchunks >= 6 ? 2 : 1;
+  // (total_blocks doubles as a host-side override of the store-stage count for this kernel)
+  const int n_st = p.total_blocks > 0 ? p.total_blocks : (p.nchunks >= 6 ? 2 : 1);
 
   if (producer) {
     // =====================================================================================
