@@ -12,7 +12,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // MODE 0: 256 threads, every wave issues.  MODE 1: 512 threads, waves 4-7 issue, 0-3 barrier only.
 // MODE 2: as 1, waves 0-3 run NM MFMAs per stage.  LOOPED: issue through a runtime loop with an EXEC mask.
 template <int MODE, int VEC, int NM, int LOOPED>
-__global__ __launch_bounds__(MODE == 0 ? 256 : MODE == 5 ? 1024 : 512, MODE == 0 ? 1 : MODE == 5 ? 4 : 2) void k(const char* src, int chunk_bytes, int nchunks, int iters, float* sink) {
+__global__ __launch_bounds__(MODE == 0 ? 256 : MODE == 5 ? 1024 : 512, MODE == 0 ? 1 : MODE == 5 ? 4 : 2) void k(const char* src, int chunk_bytes, int nchunks, int iters, float* sink, unsigned long long* cyc) {
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, wave_all = tid >> 6, lane = tid & 63, wave = wave_all & 3, ptid = tid & 255;
   const bool producer = MODE == 0 || MODE >= 4 || wave_all >= 4;
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : MODE == 5 ? 1024 : 512, MODE == 0
   float t = 0;
   for (int i = 0; i < 6; ++i) t += acc[i][0];
   if (t == 123.456f) sink[0] = t;
+  if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = __builtin_amdgcn_s_memtime() - t_begin;
 }
 
 template <int MODE, int VEC, int NM, int LOOPED>
@@ -69,13 +71,16 @@ void run(const char* name, const char* d, int chunk_bytes, int nchunks, float* s
   hipFuncSetAttribute((const void*)k<MODE, VEC, NM, LOOPED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   const int threads = MODE == 0 ? 256 : MODE == 5 ? 1024 : 512;
-  k<MODE, VEC, NM, LOOPED><<<256, threads, 128 * 1024>>>(d, chunk_bytes, nchunks, 10, sink);
+  static unsigned long long* cyc = nullptr; if (!cyc) hipMalloc(&cyc, 8);
+  k<MODE, VEC, NM, LOOPED><<<256, threads, 128 * 1024>>>(d, chunk_bytes, nchunks, 10, sink, cyc);
   hipEventRecord(a);
-  k<MODE, VEC, NM, LOOPED><<<256, threads, 128 * 1024>>>(d, chunk_bytes, nchunks, iters, sink);
+  k<MODE, VEC, NM, LOOPED><<<256, threads, 128 * 1024>>>(d, chunk_bytes, nchunks, iters, sink, cyc);
   hipEventRecord(b); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b);
   double us = ms * 1e3 / iters;
-  printf("%-46s %6.2f us/stage  %5.1f GB/s per CU\n", name, us, chunk_bytes / (us * 1e-6) / 1e9);
+  unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+  printf("%-46s %6.2f us/stage  %5.1f GB/s per CU  %6.0f ticks/stage  shader clock %.2f GHz\n", name, us, chunk_bytes / (us * 1e-6) / 1e9,
+         (double)c / iters, (double)c / iters / (us * 1e3));
 }
 
 int main() {
@@ -91,6 +96,7 @@ int main() {
   run<0, 16, 0, 0>("256 thr,  4 waves issue 64 KiB", d, 65536, 3, sink);
   run<4, 16, 0, 0>("512 thr,  8 waves issue 64 KiB", d, 65536, 3, sink);
   run<5, 16, 0, 0>("1024 thr, 16 waves issue 64 KiB", d, 65536, 3, sink);
+  run<2, 0, 54, 0>("512 thr, 54 MFMA consumers, idle producers", d, 28672, 6, sink);
   run<2, 7, 54, 1>("512 thr, producers looped + 54 MFMA consumers", d, 27648, 6, sink);
   run<2, 7, 54, 0>("512 thr, producers unrolled + 54 MFMA consumers", d, 28672, 6, sink);
   run<3, 7, 54, 0>("512 thr, producers + 54 MFMA + LDS-read consumers", d, 28672, 6, sink);
