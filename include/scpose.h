@@ -182,6 +182,11 @@ int32_t scpose_conv_destroy(scpose_conv_t c);
 int32_t scpose_conv_forward(scpose_conv_t c, const void* in, int32_t n, int32_t h, int32_t w,
                             const void* residual, int32_t relu, int32_t out_nchw_f32, void* out,
                             void* stream);
+/* Fused BasicBlock (pose_hrnet.py:41-57): out = relu(conv2(relu(conv1(x))) + x) in one kernel, for two 3x3 /
+ * stride-1 / C -> C convolutions created with scpose_conv_create (C = 32 or 48).  in/out blocked C x h x w.
+ * Returns SCPOSE_E_INVALID when the pair is not fusable (then run the two scpose_conv_forward calls). */
+int32_t scpose_basic_block_forward(scpose_conv_t conv1, scpose_conv_t conv2, const void* in, int32_t n,
+                                   int32_t h, int32_t w, void* out, void* stream);
 /* out = relu(sum_t upsample_nearest(term_t, 2^shift_t)); all blocked, out is c x h x w. */
 int32_t scpose_fuse_sum(const void* const* terms, const int32_t* shifts, int32_t nterms,
                         int32_t n, int32_t c, int32_t h, int32_t w, int32_t dtype, void* out,

@@ -63,6 +63,7 @@ SYMBOLS = {
     "scpose_conv_destroy": (c_int32, [c_void_p]),
     "scpose_conv_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32,
                                       c_int32, c_void_p, c_void_p]),
+    "scpose_basic_block_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "scpose_fuse_sum": (c_int32, [POINTER(c_void_p), POINTER(c_int32), c_int32, c_int32, c_int32, c_int32,
                                   c_int32, c_int32, c_void_p, c_void_p]),
     "scpose_nchw_f32_to_blocked": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,

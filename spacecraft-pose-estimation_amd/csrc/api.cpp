@@ -85,6 +85,13 @@ extern "C" int32_t scpose_conv_forward(scpose_conv_t c, const void* in, int32_t 
                      static_cast<hipStream_t>(stream));
 }
 
+extern "C" int32_t scpose_basic_block_forward(scpose_conv_t conv1, scpose_conv_t conv2, const void* in, int32_t n,
+                                              int32_t h, int32_t w, void* out, void* stream) {
+  SCP_REQUIRE(conv1 && conv2 && in && out, "basic_block_forward: null argument");
+  SCP_REQUIRE(block_fusable(conv1->pc, conv2->pc), "basic_block_forward: not a fusable pair (3x3 stride-1 C->C->C, C = 32 or 48)");
+  return block_launch(conv1->pc, conv2->pc, in, n, h, w, out, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int32_t scpose_fuse_sum(const void* const* terms, const int32_t* shifts, int32_t nterms,
                                    int32_t n, int32_t c, int32_t h, int32_t w, int32_t dtype,
                                    void* out, void* stream) {

@@ -127,6 +127,10 @@ int plane_stride_for(int stride, int halo_h, int halo_w);
 int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, int occ, int groups, hipStream_t stream);
 size_t conv_pipe_lds_bytes(const PackedConv& pc, int plane_stride, int groups);
 const void* conv_zero_page();   // lazily allocated 256 zero bytes on the current device
+// fused BasicBlock (conv_block_kernel.h): out = relu(conv2(relu(conv1(x))) + x) for C -> C -> C 3x3 layers
+bool block_fusable(const PackedConv& c1, const PackedConv& c2);
+int32_t block_launch(const PackedConv& c1, const PackedConv& c2, const void* in, int N, int H, int W, void* out,
+                     hipStream_t stream);
 int conv_device_cus();
 unsigned long long* conv_dbg_buffer(hipStream_t stream);   // development instrumentation
 void conv_dbg_set_grid(int grid);

@@ -1,0 +1,307 @@
+// Fused BasicBlock for the high-resolution branch:  out = ReLU(conv2(ReLU(conv1(x))) + x),
+// both 3x3 / stride 1 / C -> C with folded BatchNorm, C = 16*MREP <= 64
+// (landmark_regression/lib/models/pose_hrnet.py:41-57; branch 0 of every HighResolutionModule :139-185).
+//
+// Why: at C = 48 the two convolutions are HBM-bound (172.8 flop/B) and, run separately, move five
+// activation tensors per block (conv1 in+out, conv2 in+residual+out).  Fused, the block reads x once
+// (with a 2-pixel halo) and writes its output once: 2.3x fewer bytes and memory instructions, for 27 %
+// more MFMAs (conv1 is evaluated on the 18x18 halo of each 16x16 output tile).
+//
+// One 512-thread workgroup per CU (two waves per SIMD, which a 16x16x32 MFMA stream needs to fill the
+// matrix pipe), persistent over 16x16 output tiles.  LDS (157.7 KB at C = 48): both layers' packed weights
+// resident (2 x 42 KB), the 20x20 input tile (6 planes, 38.4 KB), the 18x18 intermediate tile (32 KB).
+// Per tile:
+//   A. conv1 on the 18x18 intermediate pixels (21 MFMA columns over 8 waves), bias + ReLU + 16-bit rounding
+//      -- the same rounding the unfused path applies when it stores conv1's output -- written to the
+//      intermediate tile in LDS as 8-byte half-slots (no lane exchange needed); pixels outside the image
+//      are written as zeros (they are conv2's zero padding, not conv1 outputs);
+//   B. every lane copies the residual slots it will need (the centre of the input tile) into registers,
+//      then the input tile is dead and the LDS-DMA of the NEXT tile's input is issued into it;
+//   C. conv2 on the 16x16 output pixels from the intermediate tile, bias + residual + ReLU, 16-byte stores.
+// Three workgroup barriers per tile.  Both k-loops are fully unrolled, hand-scheduled asm (fragment reads
+// one step ahead, tap offsets in registers, weight offsets immediates), as in conv_pipe_kernel.h.
+#pragma once
+#include "common.h"
+#include "conv_device.h"
+#include "conv_pipe_kernel.h"   // dma16, u32x4, pipe_fdiv
+
+namespace scpose {
+
+struct BlockLaunch {
+  const void* in;        // blocked N x C x H x W
+  const void* w1;        // packed weights of conv1 / conv2 (pack_conv_weights, mt = C, one chunk)
+  const void* w2;
+  const float* b1;       // folded biases in packed row order
+  const float* b2;
+  void* out;             // blocked N x C x H x W
+  const void* zero16;
+  int32_t N, H, W;
+  int32_t tiles_x, tiles_y, tiles_total, tiles_per_wg, grid;
+  FastDiv fd_tiles_img, fd_tiles_x;
+};
+
+template <int S, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (S < E) {
+    f(std::integral_constant<int, S>{});
+    static_for<S + 1, E>(f);
+  }
+}
+
+constexpr int kBlockTile = 16;                                   // output tile edge
+constexpr int block_ksteps(int mrep) { return (mrep * 9 + 1) / 2; }
+constexpr int block_xs() { return 20 * 20 * 16; }               // bytes of one input-tile plane
+constexpr int block_ms() { return (18 * 18 * 16 + 255) & ~255; } // bytes of one intermediate-tile plane
+constexpr size_t block_lds_bytes(int mrep) {
+  return 1024 + 2 * (size_t)block_ksteps(mrep) * 4 * (16 * mrep) * 16 + 2 * mrep * (size_t)(block_xs() + block_ms());
+}
+
+template <int DT, int MREP>
+__global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename DtOf<DT>::type T;
+  typedef typename FragOf<T>::type frag_t;
+  constexpr int MT = 16 * MREP, PLANES = 2 * MREP, KSTEPS = block_ksteps(MREP), NPT = MREP * 9;
+  constexpr int XS = block_xs(), MS = block_ms();
+  constexpr int WBYTES = KSTEPS * 4 * MT * 16;
+
+  int* koffA = reinterpret_cast<int*>(smem);            // [16 steps][4 k-groups] offsets into the input tile
+  int* koffB = koffA + 64;                              // ... into the intermediate tile
+  float* bias1 = reinterpret_cast<float*>(smem + 512);
+  float* bias2 = bias1 + 64;
+  char* w1l = smem + 1024;
+  char* w2l = w1l + WBYTES;
+  char* xl = w2l + WBYTES;
+  char* ml = xl + PLANES * XS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, r = lane & 15, half = lane >> 5, psel = q & 1;
+  const int HW = p.H * p.W;
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+
+  if (tid < 128) {   // tap offsets of MFMA k-step st, k-group qq (plane 2pp + (qq&1), tap pt = 2 st + (qq>>1))
+    const int tbl = tid >> 6, e = tid & 63;
+    const int st = e >> 2, qq = e & 3;
+    const int pt = 2 * st + (qq >> 1);
+    const int pp = pt / 9, tap = pt - pp * 9;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int v = tbl == 0 ? (2 * pp + (qq & 1)) * XS + (ky * 20 + kx) * 16 : (2 * pp + (qq & 1)) * MS + (ky * 18 + kx) * 16;
+    (tbl == 0 ? koffA : koffB)[e] = pt < NPT ? v : 0;
+  }
+  if (tid < MT) { bias1[tid] = p.b1[tid]; bias2[tid] = p.b2[tid]; }
+
+  const int wg = xcd_remap(blockIdx.x, p.grid);
+  const int t_begin = wg * p.tiles_per_wg;
+  const int t_end = min(p.tiles_total, t_begin + p.tiles_per_wg);
+
+  auto decode = [&](int t, int& img, int& oy0, int& ox0) {
+    img = pipe_fdiv(t, p.fd_tiles_img);
+    const int rem = t - img * tiles_per_img;
+    const int ty = pipe_fdiv(rem, p.fd_tiles_x);
+    oy0 = ty * kBlockTile; ox0 = (rem - ty * p.tiles_x) * kBlockTile;
+  };
+  // input tile (20 x 20 halo of the 16 x 16 outputs): one pixel per thread, all planes
+  const int hy = tid / 20, hx = tid - hy * 20;
+  auto issue_x = [&](int t) {
+    if (tid < 400) {
+      int img, oy0, ox0;
+      decode(t, img, oy0, ox0);
+      const int iy = oy0 - 2 + hy, ix = ox0 - 2 + hx;
+      const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const char* src0 = static_cast<const char*>(p.in) + ((size_t)img * PLANES * HW + (size_t)(ok ? iy * p.W + ix : 0)) * 16;
+#pragma unroll
+      for (int pl = 0; pl < PLANES; ++pl) {
+        const char* src = ok ? src0 + (size_t)pl * HW * 16 : static_cast<const char*>(p.zero16);
+        dma16(src, xl + pl * XS + wave * 1024);
+      }
+    }
+  };
+
+  // prologue: both weight sets, the first input tile
+  for (int o = 0; o < WBYTES; o += 8192) {
+    const int mine = o + tid * 16;
+    if (mine < WBYTES) {
+      dma16(static_cast<const char*>(p.w1) + mine, w1l + o + wave * 1024);
+      dma16(static_cast<const char*>(p.w2) + mine, w2l + o + wave * 1024);
+    }
+  }
+  if (t_begin < t_end) issue_x(t_begin);
+  __syncthreads();
+
+  int kA[KSTEPS], kB[KSTEPS];
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) { kA[s] = koffA[s * 4 + q]; kB[s] = koffB[s * 4 + q]; }
+
+  // phase A columns of this wave: intermediate pixels (n*8 + wave)*16 + r, n = 0..2 (21 columns of 16 over 324 pixels)
+  int offA[3], myA[3], mxA[3];
+  bool okA[3];
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    const int pidx = (n * 8 + wave) * 16 + r;
+    okA[n] = pidx < 18 * 18;
+    myA[n] = okA[n] ? pidx / 18 : 0;
+    mxA[n] = okA[n] ? pidx - myA[n] * 18 : 0;
+    offA[n] = (myA[n] * 20 + mxA[n]) * 16;
+  }
+  // phase C columns: output pixels (n*8 + wave)*16 + r, n = 0..1; after the lane exchange the lower half-wave
+  // owns column 0's pixel, the upper half-wave column 1's
+  int offB[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int pidx = (n * 8 + wave) * 16 + r;
+    offB[n] = ((pidx >> 4) * 18 + (pidx & 15)) * 16;
+  }
+  const int opix = (half * 8 + wave) * 16 + r;       // the output pixel whose 16-byte slots this lane stores
+  const int opy = opix >> 4, opx = opix & 15;
+
+  // fully unrolled k-loop: NCOL columns, fragments one step ahead
+  auto kloop = [&](auto ncol_c, const char* wl, const char* bl, const int* kv, const int* off, f32x4 (*acc)[3]) {
+    constexpr int NCOL = decltype(ncol_c)::value;
+    const uint32_t wa = (uint32_t)(size_t)wl + (q * MT + r) * 16;
+    const uint32_t ba = (uint32_t)(size_t)bl;
+    frag_t a0[MREP], b0[NCOL], a1[MREP], b1[NCOL];
+    auto issue = [&](auto sc, frag_t* a, frag_t* b) {
+      constexpr int S = decltype(sc)::value;
+      lds_read16<S * (4 * MT * 16)>(a[0], wa);
+      if constexpr (MREP > 1) lds_read16<S * (4 * MT * 16) + 256>(a[1], wa);
+      if constexpr (MREP > 2) lds_read16<S * (4 * MT * 16) + 512>(a[2], wa);
+      if constexpr (MREP > 3) lds_read16<S * (4 * MT * 16) + 768>(a[3], wa);
+#pragma unroll
+      for (int n = 0; n < NCOL; ++n) lds_read16<0>(b[n], ba + kv[S] + off[n]);
+    };
+    auto landed = [&](frag_t* a, frag_t* b) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int m = 0; m < MREP; ++m) lds_landed(a[m]);
+#pragma unroll
+      for (int n = 0; n < NCOL; ++n) lds_landed(b[n]);
+    };
+    auto cols = [&](const frag_t* a, const frag_t* b, int n0, int n1) {
+#pragma unroll
+      for (int n = 0; n < NCOL; ++n)
+        if (n >= n0 && n < n1)
+#pragma unroll
+          for (int m = 0; m < MREP; ++m) mfma16_acc<T>(acc[m][n], a[m], b[n]);
+    };
+#pragma unroll
+    for (int m = 0; m < MREP; ++m)
+#pragma unroll
+      for (int n = 0; n < NCOL; ++n) mfma_input_fence<false>(acc[m][n]);
+    issue(std::integral_constant<int, 0>{}, a0, b0);
+    landed(a0, b0);
+    static_for<0, KSTEPS>([&](auto sc) {
+      constexpr int S = decltype(sc)::value;
+      frag_t* ca = (S & 1) ? a1 : a0; frag_t* cb = (S & 1) ? b1 : b0;
+      frag_t* na = (S & 1) ? a0 : a1; frag_t* nb = (S & 1) ? b0 : b1;
+#ifdef SCPOSE_BLOCK_NO_OVERLAP
+      cols(ca, cb, 0, NCOL);
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+      if constexpr (S + 1 < KSTEPS) issue(std::integral_constant<int, S + 1>{}, na, nb);
+#else
+      cols(ca, cb, 0, 1);
+      if constexpr (S + 1 < KSTEPS) issue(std::integral_constant<int, S + 1>{}, na, nb);
+      cols(ca, cb, 1, NCOL);
+#endif
+      if constexpr (S + 1 < KSTEPS) landed(na, nb);
+    });
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // last MFMA's result visible to the VALU
+#pragma unroll
+    for (int m = 0; m < MREP; ++m)
+#pragma unroll
+      for (int n = 0; n < NCOL; ++n) mfma_result_fence<false>(acc[m][n]);
+  };
+
+  for (int t = t_begin; t < t_end; ++t) {
+    int img, oy0, ox0;
+    decode(t, img, oy0, ox0);
+    f32x4 acc[MREP][3];
+
+    // ---- A: conv1 -> intermediate tile ----
+#pragma unroll
+    for (int m = 0; m < MREP; ++m)
+#pragma unroll
+      for (int n = 0; n < 3; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    kloop(std::integral_constant<int, 3>{}, w1l, xl, kA, offA, acc);
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      const int gy = oy0 - 1 + myA[n], gx = ox0 - 1 + mxA[n];
+      const bool inimg = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+#pragma unroll
+      for (int m = 0; m < MREP; ++m) {
+        const float4 bs = *reinterpret_cast<const float4*>(bias1 + m * 16 + q * 4);
+        uint2 o;
+        o.x = relu2_16(pack2<T>(acc[m][n][0] + bs.x, acc[m][n][1] + bs.y), 0u);
+        o.y = relu2_16(pack2<T>(acc[m][n][2] + bs.z, acc[m][n][3] + bs.w), 0u);
+        if (!inimg) o = make_uint2(0u, 0u);              // conv2's zero padding
+        if (okA[n])
+          *reinterpret_cast<uint2*>(ml + (2 * m + psel) * MS + ((n * 8 + wave) * 16 + r) * 16 + 8 * (q >> 1)) = o;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // intermediate tile complete, input tile no longer read by conv1
+
+    // ---- B: residual slots of this lane's output pixel, then the next input tile may overwrite the buffer ----
+    u32x4 resv[MREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m)
+      resv[m] = *reinterpret_cast<const u32x4*>(xl + (2 * m + psel) * XS + ((opy + 2) * 20 + opx + 2) * 16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) asm volatile("" : "+v"(resv[m]));
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < t_end) issue_x(t + 1);
+
+    // ---- C: conv2 -> output ----
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) { acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    kloop(std::integral_constant<int, 2>{}, w2l, ml, kB, offB, acc);
+    const int oy = oy0 + opy, ox = ox0 + opx;
+    const bool store_ok = oy < p.H && ox < p.W;
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+      const float4 bs = *reinterpret_cast<const float4*>(bias2 + m * 16 + q * 4);
+      uint32_t a[4], b[4];
+      a[0] = __float_as_uint(acc[m][0][0] + bs.x); a[1] = __float_as_uint(acc[m][0][1] + bs.y);
+      a[2] = __float_as_uint(acc[m][0][2] + bs.z); a[3] = __float_as_uint(acc[m][0][3] + bs.w);
+      b[0] = __float_as_uint(acc[m][1][0] + bs.x); b[1] = __float_as_uint(acc[m][1][1] + bs.y);
+      b[2] = __float_as_uint(acc[m][1][2] + bs.z); b[3] = __float_as_uint(acc[m][1][3] + bs.w);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(a[jj], b[jj], false, false);
+        a[jj] = sw[0]; b[jj] = sw[1];
+      }
+      // lower half-wave: a = own (column 0, channels 0-3), b = partner's (column 0, channels 4-7);
+      // upper half-wave: a = partner's (column 1, channels 0-3), b = own (column 1, channels 4-7)
+      float v[8];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) { v[jj] = __uint_as_float(a[jj]); v[4 + jj] = __uint_as_float(b[jj]); }
+      const u32x4 rv = resv[m];
+      v[0] += from_bits<T>(rv[0] & 0xffff); v[1] += from_bits<T>(rv[0] >> 16);
+      v[2] += from_bits<T>(rv[1] & 0xffff); v[3] += from_bits<T>(rv[1] >> 16);
+      v[4] += from_bits<T>(rv[2] & 0xffff); v[5] += from_bits<T>(rv[2] >> 16);
+      v[6] += from_bits<T>(rv[3] & 0xffff); v[7] += from_bits<T>(rv[3] >> 16);
+      u32x4 ov;
+      ov[0] = relu2_16(pack2<T>(v[0], v[1]), 0u); ov[1] = relu2_16(pack2<T>(v[2], v[3]), 0u);
+      ov[2] = relu2_16(pack2<T>(v[4], v[5]), 0u); ov[3] = relu2_16(pack2<T>(v[6], v[7]), 0u);
+      if (store_ok)
+        *reinterpret_cast<u32x4*>(static_cast<char*>(p.out) + (((size_t)img * PLANES + 2 * m + psel) * HW + (size_t)oy * p.W + ox) * 16) = ov;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // next input tile landed (this wave's share)
+    __builtin_amdgcn_s_barrier();                                   // ... and the intermediate tile is free again
+  }
+}
+
+template <int DT, int MREP>
+int32_t block_launch_one(const BlockLaunch& L, hipStream_t st) {
+  auto kern = conv_block_kernel<DT, MREP>;
+  static bool big_lds_enabled = false;
+  if (!big_lds_enabled) {
+    SCP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    big_lds_enabled = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(L.grid), dim3(512), block_lds_bytes(MREP), st, L);
+  SCP_CHECK_HIP(hipGetLastError());
+  return SCPOSE_OK;
+}
+
+}  // namespace scpose

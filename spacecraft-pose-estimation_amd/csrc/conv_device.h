@@ -43,6 +43,24 @@ __device__ __forceinline__ void mfma16_acc(f32x4& c, const typename FragOf<T>::t
   else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
+// After a hand-scheduled MFMA loop: the trailing s_nop covers the MFMA -> VALU read latency, and every accumulator is
+// passed through an (empty) asm so that the compiler cannot hoist their consumers above that s_nop.
+template <bool AGPR, typename V>
+__device__ __forceinline__ void mfma_result_fence(V& c) {
+  if constexpr (AGPR) asm volatile("" : "+a"(c));
+  else asm volatile("" : "+v"(c));
+}
+
+// Before a hand-scheduled MFMA loop: the hazard recogniser does not see inline-asm MFMAs, so a VALU write of an
+// accumulator (its zero / bias initialisation, which the scheduler likes to sink right in front of the first
+// MFMA) could be followed by the MFMA's SrcC read without the required wait states.  Passing the accumulator
+// through this asm orders the initialisation before two wait states.
+template <bool AGPR, typename V>
+__device__ __forceinline__ void mfma_input_fence(V& c) {
+  if constexpr (AGPR) asm volatile("s_nop 1" : "+a"(c));
+  else asm volatile("s_nop 1" : "+v"(c));
+}
+
 // two fp32 -> one dword of two 16-bit values (a in the low half), one v_cvt_pk_* instruction, RNE like the scalar cast
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;

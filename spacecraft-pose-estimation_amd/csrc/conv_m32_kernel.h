@@ -313,6 +313,10 @@ __global__ __launch_bounds__(256, OCC) void conv_m32_kernel(const ConvLaunch p) 
               for (int m = 0; m < MR; ++m) mfma32_acc<T, OCC == 1>(acc[m][n], a[m], b[n]);
         };
         if (npp > 0) {
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int n = 0; n < NR; ++n) mfma_input_fence<OCC == 1>(acc[m][n]);
           set_row(0, 0);
           issue(std::integral_constant<int, 0>{}, a0, b0);
           landed(a0, b0);
@@ -351,6 +355,10 @@ __global__ __launch_bounds__(256, OCC) void conv_m32_kernel(const ConvLaunch p) 
             }
           }
           asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA's result visible to the VALU
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int n = 0; n < NR; ++n) mfma_result_fence<OCC == 1>(acc[m][n]);
         }
       }
       const unsigned long long t2 = now();

@@ -325,6 +325,10 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
 #pragma unroll
                     for (int m = 0; m < MREP; ++m) mfma16_acc<T>(acc[J][m][n], a[m], b[n]);
               };
+#pragma unroll
+              for (int m = 0; m < MREP; ++m)
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) mfma_input_fence<false>(acc[J][m][n]);
               issue(std::integral_constant<int, 0>{}, a0, b0);
               landed(a0, b0);
               auto step = [&](auto sc) {
@@ -350,6 +354,10 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
               step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
               step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{});
               asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // last MFMA's result visible to the VALU
+#pragma unroll
+              for (int m = 0; m < MREP; ++m)
+#pragma unroll
+                for (int n = 0; n < NREP; ++n) mfma_result_fence<false>(acc[J][m][n]);
             }
           }
           if (done_asm) {

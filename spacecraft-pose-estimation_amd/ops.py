@@ -161,6 +161,16 @@ def crop_warp(frames, trans, out_wh, swap_rb=False, device=None):
     return out
 
 
+def basic_block(conv1, conv2, xb):
+    """Fused BasicBlock relu(conv2(relu(conv1(x))) + x) on a blocked tensor (two Conv objects, 3x3 stride 1, C -> C)."""
+    _need_cuda(xb)
+    n, planes, h, w, _ = xb.shape
+    out = torch.empty_like(xb)
+    nat.check(nat.lib().scpose_basic_block_forward(conv1._h, conv2._h, _ptr(xb), n, h, w, _ptr(out), _stream()),
+              "basic_block_forward")
+    return out
+
+
 def flip_merge(out, out_flipped, flip_pairs, shift):
     """(out + flip_back(out_flipped)) * 0.5 of the flip test (lib/core/function.py:347-366), on the device.
     out / out_flipped: (N,J,H,W) f32 device heatmaps of the frame and of its x-flipped copy."""

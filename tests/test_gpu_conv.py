@@ -122,3 +122,30 @@ def test_bad_arguments_report_errors(gpu_ops):
         gpu_ops.Conv(torch.zeros(8, 12, 3, 3))
     with pytest.raises(gpu_ops.nat.NativeError, match="kernel size"):
         gpu_ops.Conv(torch.zeros(16, 16, 5, 5))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(48, 96, 96, 2), (48, 24, 40, 3), (32, 64, 64, 2), (48, 7, 5, 4), (32, 16, 16, 1)],
+                         ids=lambda s: "c%d_%dx%d_n%d" % s)
+def test_fused_basic_block_matches_two_convs(gpu_ops, shape, dtype):
+    """scpose_basic_block_forward (one kernel, intermediate tile in LDS) against the CPU float32 composition
+    relu(conv2(round16(relu(conv1(x)))) + x) -- the intermediate is rounded to 16 bits exactly where the unfused
+    path stores it -- and against the two unfused HIP launches."""
+    C, H, W, N = shape
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    g = torch.Generator().manual_seed(7 * C + H)
+    x = _rnd(torch.randn(N, C, H, W, generator=g), tdt)
+    w1 = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    w2 = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    b1 = torch.randn(C, generator=g) * 0.1
+    b2 = torch.randn(C, generator=g) * 0.1
+    mid = _rnd(F.relu(F.conv2d(x, _rnd(w1, tdt), b1, 1, 1)), tdt)
+    ref = F.relu(F.conv2d(mid, _rnd(w2, tdt), b2, 1, 1) + x)
+    c1 = gpu_ops.Conv(w1, b1, dtype=dtype)
+    c2 = gpu_ops.Conv(w2, b2, dtype=dtype)
+    xb = gpu_ops.to_blocked(x.cuda(), dtype)
+    got = gpu_ops.from_blocked(gpu_ops.basic_block(c1, c2, xb)).cpu()
+    two = gpu_ops.from_blocked(c2(c1(xb, relu=True), residual=xb, relu=True)).cpu()
+    tol = 1.5e-2 * ref.abs() + 1.5e-2 * ref.pow(2).mean().sqrt()
+    assert not ((got - ref).abs() > tol).any(), "fused vs CPU: max |d| %.4g" % (got - ref).abs().max()
+    assert not ((got - two).abs() > tol).any(), "fused vs unfused HIP: max |d| %.4g" % (got - two).abs().max()

@@ -1,0 +1,44 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch.nn.functional as F
+import scpose
+from importlib import import_module
+ops = import_module("spacecraft-pose-estimation_amd.ops")
+def rnd(t, dt): return t.to(dt).to(torch.float32)
+C,H,W,N = 48,16,16,1
+tdt=torch.bfloat16
+def run(name, w1, w2, b1, b2, x):
+    mid=rnd(F.relu(F.conv2d(x,rnd(w1,tdt),b1,1,1)),tdt)
+    ref=F.relu(F.conv2d(mid,rnd(w2,tdt),b2,1,1)+x)
+    c1=ops.Conv(w1,b1,dtype="bf16"); c2=ops.Conv(w2,b2,dtype="bf16")
+    xb=ops.to_blocked(x.cuda(),"bf16")
+    got=ops.from_blocked(ops.basic_block(c1,c2,xb)).cpu()
+    d=(got-ref).abs()
+    bad=d>1e-2*ref.abs()+1e-2
+    idx=bad.nonzero()
+    print("%-28s max %.4f bad %.4f  chans %s rows %s" % (name, d.max().item(), bad.float().mean().item(),
+          sorted(set(idx[:,1].tolist()))[:16], sorted(set(idx[:,2].tolist()))))
+    if len(idx):
+        n,c,y,xx = idx[0].tolist()
+        print("   first bad (c=%d,y=%d,x=%d): got %.5f ref %.5f x %.5f" % (c,y,xx,got[n,c,y,xx],ref[n,c,y,xx],x[n,c,y,xx]))
+g=torch.Generator().manual_seed(1)
+x=rnd(torch.randn(N,C,H,W,generator=g),tdt)
+w1=torch.randn(C,C,3,3,generator=g)/(C*9)**0.5; w2=torch.randn(C,C,3,3,generator=g)/(C*9)**0.5
+b1=torch.randn(C,generator=g)*0.1; b2=torch.randn(C,generator=g)*0.1
+z=torch.zeros_like(w1); zb=torch.zeros(C)
+run("all zero weights (relu x)", z, z, zb, zb, x)
+run("w2=0: relu(b2+x)", w1, z, b1, b2, x)
+run("w1=0: mid=relu(b1)", z, w2, b1, b2, x)
+run("x>=0 only center tap w2", w1, torch.cat([torch.zeros(C,C,3,3)[:, :, :1, :]]*3, 2), b1, zb, x.abs())
+run("full", w1, w2, b1, b2, x)
+xz=torch.zeros_like(x)
+run("x=0 full", w1, w2, b1, b2, xz)
+print("---- identity conv2 ----")
+eye=torch.zeros(C,C,3,3); 
+for c in range(C): eye[c,c,1,1]=1.0
+run("x=0, w2=I: out=mid", w1, eye, b1, zb, xz)
+run("x=0, w1=0,b1=c, w2=I", z, eye, b1.abs()+0.5, zb, xz)
+run("x=0, w1=0,b1=c, w2 rand", z, w2, b1.abs()+0.5, zb, xz)
+eye_s=torch.zeros(C,C,3,3)
+for c in range(C): eye_s[c,c,0,0]=1.0
+run("x=0, w1=0,b1=c, w2=shift(0,0)", z, eye_s, b1.abs()+0.5, zb, xz)
