@@ -210,7 +210,8 @@ def main():
         # ---- roofline of the dominant kernel class (largest summed time over the timed steps) ----
         key, (ms, calls, flops, byts) = max(prof_ms.items(), key=lambda kv: kv[1][0])
         kind, a, cin, cout = key
-        kname = {0: "stem_conv1_kernel (3->64 3x3 s2, f32 VALU)", 2: "fuse_sum_kernel (%d terms, C=%d)" % (a, cin)}.get(
+        kname = {0: "stem_conv1_kernel (3->64 3x3 s2, f32 VALU)", 2: "fuse_sum_kernel (%d terms, C=%d)" % (a, cin),
+                 3: "fused BasicBlock 2 x (3x3 s1 %d->%d) (conv_block_kernel; algorithmic bytes = the unfused 5 tensors)" % (cin, cout)}.get(
             kind, "conv %dx%d s%d %d->%d (MFMA implicit-GEMM; variant names in profiles/*_kernel_stats.csv)" % (a // 10, a // 10, a % 10, cin, cout))
         ai = flops / byts if byts else float("inf")
         hbm_bound = ai < MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)

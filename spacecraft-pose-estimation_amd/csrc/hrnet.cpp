@@ -68,7 +68,7 @@ static bool fold(Weights& W, const std::string& conv, const std::string& bn, int
   return true;
 }
 
-enum OpKind { OP_STEM = 0, OP_CONV = 1, OP_FUSE = 2 };
+enum OpKind { OP_STEM = 0, OP_CONV = 1, OP_FUSE = 2, OP_BLOCK = 3 };   // OP_BLOCK: fused BasicBlock (conv_block_kernel.h)
 
 struct TensorDesc {
   int C, ds;       // channels, log2 spatial downscale w.r.t. the network input
@@ -80,6 +80,7 @@ struct Op {
   int kind;
   int in, out, res;  // tensor ids (-1 none; in == -2: network input; out == -2: heatmaps)
   int conv;          // index into convs
+  int conv2;         // OP_BLOCK: second convolution of the block
   int relu, out_f32;
   int nterms, term[4], shift[4];
 };
@@ -132,6 +133,22 @@ struct Builder {
     op.out = to_heatmaps ? -2 : new_tensor(cout, ds);
     net->ops.push_back(op);
     return op.out;
+  }
+  // BasicBlock relu(conv2(relu(conv1(x))) + x): one fused launch when the pair qualifies, else two convolutions
+  int basic_block(int x, const std::string& p, int C) {
+    if (status != SCPOSE_OK) return -1;
+    const size_t first = net->convs.size(), first_op = net->ops.size();
+    const int u = conv(x, p + ".conv1", p + ".bn1", C, 3, 1, true);
+    const int t = conv(u, p + ".conv2", p + ".bn2", C, 3, 1, true, x);
+    if (status != SCPOSE_OK || net->tensors[x].C != C) return t;
+    if (!block_fusable(net->convs[first], net->convs[first + 1])) return t;
+    // replace the two ops by one; the intermediate tensor u stays unused (never planned: last_use < 0)
+    net->ops.resize(first_op);
+    Op op{};
+    op.kind = OP_BLOCK; op.in = x; op.res = -1; op.conv = (int)first; op.conv2 = (int)first + 1; op.relu = 1;
+    op.out = t;
+    net->ops.push_back(op);
+    return t;
   }
   int fuse(const std::vector<int>& terms, const std::vector<int>& shifts, int C, int ds) {
     if (status != SCPOSE_OK) return -1;
@@ -213,8 +230,7 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
         int t = xs[b];
         for (int k = 0; k < d.num_blocks[si][b]; ++k) {
           const std::string p = fmt("%s.branches.%d.%d", mp.c_str(), b, k);
-          const int u = B.conv(t, p + ".conv1", p + ".bn1", cur[b], 3, 1, true);
-          t = B.conv(u, p + ".conv2", p + ".bn2", cur[b], 3, 1, true, t);
+          t = B.basic_block(t, p, cur[b]);
         }
         xs[b] = t;
       }
@@ -361,6 +377,9 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
       void* out = op.out == -2 ? static_cast<void*>(heatmaps) : ptr(op.out);
       rc = conv_launch(net->convs[op.conv], ptr(op.in), n, h >> ti.ds, w >> ti.ds, ptr(op.res),
                        op.relu, op.out_f32, out, st);
+    } else if (op.kind == OP_BLOCK) {
+      const TensorDesc& ti = net->tensors[op.in];
+      rc = block_launch(net->convs[op.conv], net->convs[op.conv2], ptr(op.in), n, h >> ti.ds, w >> ti.ds, ptr(op.out), st);
     } else {
       const TensorDesc& to = net->tensors[op.out];
       const void* terms[4];
@@ -393,6 +412,15 @@ static void op_work(const scpose_hrnet* net, const Op& op, int h, int w, double*
     *f = 2.0 * pc.cin * pc.cout * pc.ks * pc.ks * ho * wo;
     *by = pc.cin * hi * wi * 2 + pc.cout * ho * wo * (op.out_f32 ? 4 : 2) + (op.res >= 0 ? pc.cout * ho * wo * 2 : 0);
     sig[1] = pc.ks * 10 + pc.stride; sig[2] = pc.cin; sig[3] = pc.cout;
+  } else if (op.kind == OP_BLOCK) {
+    // algorithmic work of the two convolutions as SURVEY.md 8(d) counts it (conv1 in + out, conv2 in + residual + out),
+    // so that the figures stay comparable with the unfused path; the fused kernel itself moves 2 of those 5 tensors
+    const PackedConv& pc = net->convs[op.conv];
+    const TensorDesc& ti = net->tensors[op.in];
+    const double hi = h >> ti.ds, wi = w >> ti.ds;
+    *f = 2.0 * 2.0 * pc.cin * pc.cout * 9 * hi * wi;
+    *by = 5.0 * pc.cin * hi * wi * 2;
+    sig[1] = 31; sig[2] = pc.cin; sig[3] = pc.cout;
   } else {
     const TensorDesc& to = net->tensors[op.out];
     const double ho = h >> to.ds, wo = w >> to.ds;
