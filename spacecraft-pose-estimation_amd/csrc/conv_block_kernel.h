@@ -15,10 +15,11 @@
 //      -- the same rounding the unfused path applies when it stores conv1's output -- written to the
 //      intermediate tile in LDS as 8-byte half-slots (no lane exchange needed); pixels outside the image
 //      are written as zeros (they are conv2's zero padding, not conv1 outputs);
-//   B. every lane copies the residual slots it will need (the centre of the input tile) into registers,
-//      then the input tile is dead and the LDS-DMA of the NEXT tile's input is issued into it;
+//      before that, every lane copies the residual slots it will need (the centre of the input tile) into
+//      registers, so that after the barrier that ends this phase the input tile is dead;
+//   B. the LDS-DMA of the NEXT tile's input is issued into it and streams in under phase C;
 //   C. conv2 on the 16x16 output pixels from the intermediate tile, bias + residual + ReLU, 16-byte stores.
-// Three workgroup barriers per tile.  Both k-loops are fully unrolled, hand-scheduled asm (fragment reads
+// Two workgroup barriers per tile.  Both k-loops are fully unrolled, hand-scheduled asm (fragment reads
 // one step ahead, tap offsets in registers, weight offsets immediates), as in conv_pipe_kernel.h.
 #pragma once
 #include "common.h"
@@ -211,6 +212,13 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
       for (int n = 0; n < NCOL; ++n) mfma_result_fence<false>(acc[m][n]);
   };
 
+  float4 bs1[MREP], bs2[MREP];   // this lane's bias values (rows 4q..4q+3 of every 16-row tile), tile-invariant
+#pragma unroll
+  for (int m = 0; m < MREP; ++m) {
+    bs1[m] = *reinterpret_cast<const float4*>(bias1 + m * 16 + q * 4);
+    bs2[m] = *reinterpret_cast<const float4*>(bias2 + m * 16 + q * 4);
+  }
+
   for (int t = t_begin; t < t_end; ++t) {
     int img, oy0, ox0;
     decode(t, img, oy0, ox0);
@@ -222,13 +230,18 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
 #pragma unroll
       for (int n = 0; n < 3; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     kloop(std::integral_constant<int, 3>{}, w1l, xl, kA, offA, acc);
+    // residual slots of this lane's output pixel (the centre of the input tile), kept in registers until the end
+    u32x4 resv[MREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m)
+      resv[m] = *reinterpret_cast<const u32x4*>(xl + (2 * m + psel) * XS + ((opy + 2) * 20 + opx + 2) * 16);
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
       const int gy = oy0 - 1 + myA[n], gx = ox0 - 1 + mxA[n];
       const bool inimg = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
 #pragma unroll
       for (int m = 0; m < MREP; ++m) {
-        const float4 bs = *reinterpret_cast<const float4*>(bias1 + m * 16 + q * 4);
+        const float4 bs = bs1[m];
         uint2 o;
         o.x = relu2_16(pack2<T>(acc[m][n][0] + bs.x, acc[m][n][1] + bs.y), 0u);
         o.y = relu2_16(pack2<T>(acc[m][n][2] + bs.z, acc[m][n][3] + bs.w), 0u);
@@ -238,18 +251,8 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                        // intermediate tile complete, input tile no longer read by conv1
-
-    // ---- B: residual slots of this lane's output pixel, then the next input tile may overwrite the buffer ----
-    u32x4 resv[MREP];
-#pragma unroll
-    for (int m = 0; m < MREP; ++m)
-      resv[m] = *reinterpret_cast<const u32x4*>(xl + (2 * m + psel) * XS + ((opy + 2) * 20 + opx + 2) * 16);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int m = 0; m < MREP; ++m) asm volatile("" : "+v"(resv[m]));
-    __builtin_amdgcn_s_barrier();
-    if (t + 1 < t_end) issue_x(t + 1);
+    __builtin_amdgcn_s_barrier();                        // intermediate tile complete; nobody reads the input tile any more
+    if (t + 1 < t_end) issue_x(t + 1);                   // ... so the next tile's input streams in under conv2
 
     // ---- C: conv2 -> output ----
 #pragma unroll
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
     const bool store_ok = oy < p.H && ox < p.W;
 #pragma unroll
     for (int m = 0; m < MREP; ++m) {
-      const float4 bs = *reinterpret_cast<const float4*>(bias2 + m * 16 + q * 4);
+      const float4 bs = bs2[m];
       uint32_t a[4], b[4];
       a[0] = __float_as_uint(acc[m][0][0] + bs.x); a[1] = __float_as_uint(acc[m][0][1] + bs.y);
       a[2] = __float_as_uint(acc[m][0][2] + bs.z); a[3] = __float_as_uint(acc[m][0][3] + bs.w);
