@@ -34,6 +34,9 @@ int32_t block_launch(const PackedConv& c1, const PackedConv& c2, const void* in,
   if (grid > L.tiles_total) grid = L.tiles_total;
   L.tiles_per_wg = (L.tiles_total + grid - 1) / grid;
   L.grid = (L.tiles_total + L.tiles_per_wg - 1) / L.tiles_per_wg;
+  { static const char* e = getenv("SCPOSE_DBG"); const int dbg = e ? atoi(e) : 0;
+    L.dbg_buf = (dbg & 8) ? conv_dbg_buffer(stream) : nullptr;
+    if (dbg & 8) conv_dbg_set_grid(L.grid); }
   const int mrep = c1.cin / 16;
   if (c1.dtype == SCPOSE_DT_BF16) {
     if (mrep == 3) return block_launch_one<0, 3>(L, stream);

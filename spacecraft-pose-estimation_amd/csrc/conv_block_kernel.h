@@ -39,6 +39,7 @@ struct BlockLaunch {
   int32_t N, H, W;
   int32_t tiles_x, tiles_y, tiles_total, tiles_per_wg, grid;
   FastDiv fd_tiles_img, fd_tiles_x;
+  unsigned long long* dbg_buf;   // development: per-wave phase cycle sums (SCPOSE_DBG & 8), else null
 };
 
 template <int S, int E, typename F>
@@ -219,7 +220,10 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
     bs2[m] = *reinterpret_cast<const float4*>(bias2 + m * 16 + q * 4);
   }
 
+  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
+  auto now = [&]() -> unsigned long long { return p.dbg_buf ? __builtin_amdgcn_s_memtime() : 0ull; };
   for (int t = t_begin; t < t_end; ++t) {
+    const unsigned long long t0 = now();
     int img, oy0, ox0;
     decode(t, img, oy0, ox0);
     f32x4 acc[MREP][3];
@@ -230,6 +234,7 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
 #pragma unroll
       for (int n = 0; n < 3; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     kloop(std::integral_constant<int, 3>{}, w1l, xl, kA, offA, acc);
+    const unsigned long long t1 = now();
     // residual slots of this lane's output pixel (the centre of the input tile), kept in registers until the end
     u32x4 resv[MREP];
 #pragma unroll
@@ -251,13 +256,17 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long t2 = now();
     __builtin_amdgcn_s_barrier();                        // intermediate tile complete; nobody reads the input tile any more
+    const unsigned long long t3 = now();
     if (t + 1 < t_end) issue_x(t + 1);                   // ... so the next tile's input streams in under conv2
 
     // ---- C: conv2 -> output ----
 #pragma unroll
     for (int m = 0; m < MREP; ++m) { acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const unsigned long long t4 = now();
     kloop(std::integral_constant<int, 2>{}, w2l, ml, kB, offB, acc);
+    const unsigned long long t5 = now();
     const int oy = oy0 + opy, ox = ox0 + opx;
     const bool store_ok = oy < p.H && ox < p.W;
 #pragma unroll
@@ -289,9 +298,17 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
       if (store_ok)
         *reinterpret_cast<u32x4*>(static_cast<char*>(p.out) + (((size_t)img * PLANES + 2 * m + psel) * HW + (size_t)oy * p.W + ox) * 16) = ov;
     }
+    const unsigned long long t6 = now();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // next input tile landed (this wave's share)
     __builtin_amdgcn_s_barrier();                                   // ... and the intermediate tile is free again
+    if (p.dbg_buf) {   // [conv1 loop][conv1 epilogue][barrier][DMA issue][conv2 loop][conv2 epilogue + end wait/barrier]
+      const unsigned long long t7 = now();
+      tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; tph[3] += t4 - t3; tph[4] += t5 - t4; tph[5] += t7 - t5;
+      (void)t6;
+    }
   }
+  if (p.dbg_buf && lane == 0)
+    for (int k = 0; k < 6; ++k) p.dbg_buf[((size_t)blockIdx.x * 8 + wave) * 6 + k] = tph[k];
 }
 
 template <int DT, int MREP>
