@@ -51,6 +51,8 @@ inline FastDiv make_fastdiv(uint32_t d) {
 // [N][C/8][H][W][8] 16-bit elements.
 struct ConvLaunch {
   const void* in;      // blocked input  N x Cin x H x W
+  const void* in2;     // optional second input tensor supplying the planes >= split_planes (K-concatenated 1x1 conv), else null
+  int32_t split_planes;
   const void* wpk;     // packed weights (see pack_conv_weights)
   const float* bias;   // f32 [n_mblk*MT] (zero padded)
   const void* res;     // optional blocked residual, shape of out
@@ -120,7 +122,8 @@ int32_t conv_upload(const float* w, const float* bias, int cout, int cin, int ks
                     int dtype, PackedConv* pc);
 void conv_free(PackedConv* pc);
 int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, const void* res,
-                    int relu, int out_nchw_f32, void* out, hipStream_t stream);
+                    int relu, int out_nchw_f32, void* out, hipStream_t stream,
+                    const void* in2 = nullptr, int split_planes = 0);
 size_t conv_lds_bytes(const PackedConv& pc, int nrep, int th, int tw);
 int plane_stride_for(int stride, int halo_h, int halo_w);
 // software-pipelined persistent kernel (conv_pipe_kernel.h); nt = pixel tiles per work item

@@ -200,11 +200,13 @@ size_t conv_lds_bytes(const PackedConv& pc, int nrep, int th, int tw) {
 }
 
 int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, const void* res,
-                    int relu, int out_nchw_f32, void* out, hipStream_t stream) {
+                    int relu, int out_nchw_f32, void* out, hipStream_t stream, const void* in2, int split_planes) {
+  SCP_REQUIRE(!in2 || (pc.variant == 0 && pc.ks == 1 && split_planes > 0 && split_planes % pc.cp == 0 && split_planes < pc.cin / 8),
+              "conv: a second input tensor needs a 1x1 layer whose K-chunks do not straddle the split (split=%d planes, cp=%d)", split_planes, pc.cp);
   SCP_REQUIRE(N > 0 && H > 0 && W > 0, "conv: bad shape N=%d H=%d W=%d", N, H, W);
   SCP_REQUIRE(out_nchw_f32 || pc.cout % 8 == 0, "conv: blocked output needs Cout%%8==0 (Cout=%d)", pc.cout);
   ConvLaunch L;
-  L.in = in; L.wpk = pc.d_w; L.bias = pc.d_bias; L.res = res; L.out = out;
+  L.in = in; L.in2 = in2; L.split_planes = in2 ? split_planes : 0; L.wpk = pc.d_w; L.bias = pc.d_bias; L.res = res; L.out = out;
   L.N = N; L.H = H; L.W = W;
   L.Ho = (H - 1) / pc.stride + 1;  // k=3,p=1 or k=1,p=0
   L.Wo = (W - 1) / pc.stride + 1;

@@ -161,7 +161,11 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
     if (img < 0 || (p.dbg & 4)) return;
     const int planes = c == p.nchunks - 1 ? planes_last : p.cp;
     const int iy0 = oy0 * STRIDE - (KS / 2), ix0 = ox0 * STRIDE - (KS / 2);
-    const char* inb = static_cast<const char*>(p.in) + ((size_t)img * p.cin_planes + (size_t)c * p.cp) * HW * 16;
+    // K-concatenated 1x1 layers read the chunks past split_planes from a second tensor (its own plane count)
+    const bool second = p.in2 && c * p.cp >= p.split_planes;
+    const int own_planes = p.in2 ? (second ? p.cin_planes - p.split_planes : p.split_planes) : p.cin_planes;
+    const char* inb = static_cast<const char*>(second ? p.in2 : p.in) +
+                      ((size_t)img * own_planes + (size_t)(c * p.cp - (second ? p.split_planes : 0))) * HW * 16;
     char* xl = xl0 + (grp * 2 + xb) * p.lds_x;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {

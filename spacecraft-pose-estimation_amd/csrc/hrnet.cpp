@@ -79,6 +79,7 @@ struct TensorDesc {
 struct Op {
   int kind;
   int in, out, res;  // tensor ids (-1 none; in == -2: network input; out == -2: heatmaps)
+  int in2;           // second input of a K-concatenated 1x1 conv (-1 none); stored +1 so that Op{} means none
   int conv;          // index into convs
   int conv2;         // OP_BLOCK: second convolution of the block
   int relu, out_f32;
@@ -131,6 +132,37 @@ struct Builder {
     op.kind = OP_CONV; op.in = x; op.res = res; op.conv = (int)net->convs.size() - 1;
     op.relu = relu; op.out_f32 = to_heatmaps;
     op.out = to_heatmaps ? -2 : new_tensor(cout, ds);
+    net->ops.push_back(op);
+    return op.out;
+  }
+  // y = relu(conv_bn_a(xa) + conv_bn_b(xb)), both 1x1: ONE convolution over the concatenated input channels
+  // [xa; xb] with weights [Wa | Wb] and bias ba + bb.  Used for the first Bottleneck, whose residual is itself a
+  // 1x1 conv + BN of the block input (pose_hrnet.py:78-98, :374-391): the 256-channel residual tensor is then
+  // never written or read.  (The sum is formed in the fp32 accumulators, i.e. without the 16-bit rounding the
+  // stored residual would get.)
+  int conv_cat(int xa, const std::string& ca, const std::string& bna, int xb, const std::string& cb,
+               const std::string& bnb, int cout, bool relu) {
+    if (status != SCPOSE_OK) return -1;
+    const int c1 = net->tensors[xa].C, c2 = net->tensors[xb].C;
+    std::vector<float> w1, b1, w2, b2;
+    if (!fold(*W, ca, bna, cout, c1, 1, false, &w1, &b1) || !fold(*W, cb, bnb, cout, c2, 1, false, &w2, &b2)) {
+      status = SCPOSE_E_MISSING; return -1;
+    }
+    std::vector<float> w((size_t)cout * (c1 + c2)), b(cout);
+    for (int o = 0; o < cout; ++o) {
+      for (int i = 0; i < c1; ++i) w[(size_t)o * (c1 + c2) + i] = w1[(size_t)o * c1 + i];
+      for (int i = 0; i < c2; ++i) w[(size_t)o * (c1 + c2) + c1 + i] = w2[(size_t)o * c2 + i];
+      b[o] = b1[o] + b2[o];
+    }
+    PackedConv pc;
+    const int32_t st = conv_upload(w.data(), b.data(), cout, c1 + c2, 1, 1, net->desc.dtype, &pc);
+    if (st != SCPOSE_OK) { status = st; return -1; }
+    if (pc.variant != 0 || (c1 / 8) % pc.cp != 0) { conv_free(&pc); return -2; }   // caller falls back to two convolutions
+    net->convs.push_back(pc);
+    Op op{};
+    op.kind = OP_CONV; op.in = xa; op.in2 = xb + 1; op.res = -1; op.conv = (int)net->convs.size() - 1;
+    op.relu = relu; op.out_f32 = 0;
+    op.out = new_tensor(cout, net->tensors[xa].ds);
     net->ops.push_back(op);
     return op.out;
   }
@@ -194,11 +226,19 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
   // ---- layer1: 4 Bottlenecks (64 -> 256) ----
   for (int b = 0; b < 4; ++b) {
     const std::string p = fmt("layer1.%d", b);
+    static const char* cat_env = getenv("SCPOSE_CAT_DOWNSAMPLE");
+    const bool cat = b == 0 && !(cat_env && atoi(cat_env) == 0);
     int res = x;
-    if (b == 0) res = B.conv(x, p + ".downsample.0", p + ".downsample.1", 256, 1, 1, false);
+    if (b == 0 && !cat) res = B.conv(x, p + ".downsample.0", p + ".downsample.1", 256, 1, 1, false);
     int y = B.conv(x, p + ".conv1", p + ".bn1", 64, 1, 1, true);
     y = B.conv(y, p + ".conv2", p + ".bn2", 64, 3, 1, true);
-    x = B.conv(y, p + ".conv3", p + ".bn3", 256, 1, 1, true, res);
+    int nx = -2;
+    if (cat) nx = B.conv_cat(y, p + ".conv3", p + ".bn3", x, p + ".downsample.0", p + ".downsample.1", 256, true);
+    if (nx == -2) {   // not concatenated (disabled or the packing does not allow the split)
+      if (b == 0 && cat) res = B.conv(x, p + ".downsample.0", p + ".downsample.1", 256, 1, 1, false);
+      nx = B.conv(y, p + ".conv3", p + ".bn3", 256, 1, 1, true, res);
+    }
+    x = nx;
   }
 
   std::vector<int> ylist{x};
@@ -275,6 +315,7 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
   for (size_t i = 0; i < net->ops.size(); ++i) {
     const Op& op = net->ops[i];
     auto use = [&](int t) { if (t >= 0) net->tensors[t].last_use = (int)i; };
+    use(net->ops[i].in2 - 1);
     use(op.in); use(op.res);
     for (int k = 0; k < op.nterms; ++k) use(op.term[k]);
   }
@@ -337,7 +378,7 @@ size_t hrnet_plan(scpose_hrnet* net, int n, int h, int w) {
         net->tensors[t].last_use = -100 - (int)i;  // guard against double release (same tensor twice)
       }
     };
-    done(op.in); done(op.res);
+    done(op.in); done(op.res); done(op.in2 - 1);
     for (int k = 0; k < op.nterms; ++k) done(op.term[k]);
     // an output nobody reads (cannot happen in a well-formed net) is simply never reused
   }
@@ -376,7 +417,8 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
       const TensorDesc& ti = net->tensors[op.in];
       void* out = op.out == -2 ? static_cast<void*>(heatmaps) : ptr(op.out);
       rc = conv_launch(net->convs[op.conv], ptr(op.in), n, h >> ti.ds, w >> ti.ds, ptr(op.res),
-                       op.relu, op.out_f32, out, st);
+                       op.relu, op.out_f32, out, st, op.in2 > 0 ? ptr(op.in2 - 1) : nullptr,
+                       op.in2 > 0 ? net->tensors[op.in].C / 8 : 0);
     } else if (op.kind == OP_BLOCK) {
       const TensorDesc& ti = net->tensors[op.in];
       rc = block_launch(net->convs[op.conv], net->convs[op.conv2], ptr(op.in), n, h >> ti.ds, w >> ti.ds, ptr(op.out), st);
@@ -411,6 +453,7 @@ static void op_work(const scpose_hrnet* net, const Op& op, int h, int w, double*
     const double ho = pc.stride == 2 ? hi / 2 : hi, wo = pc.stride == 2 ? wi / 2 : wi;
     *f = 2.0 * pc.cin * pc.cout * pc.ks * pc.ks * ho * wo;
     *by = pc.cin * hi * wi * 2 + pc.cout * ho * wo * (op.out_f32 ? 4 : 2) + (op.res >= 0 ? pc.cout * ho * wo * 2 : 0);
+    if (op.in2 > 0) *by += 2.0 * pc.cout * ho * wo * 2;   // algorithmic accounting of the unfused pair: the residual tensor written once, read once
     sig[1] = pc.ks * 10 + pc.stride; sig[2] = pc.cin; sig[3] = pc.cout;
   } else if (op.kind == OP_BLOCK) {
     // algorithmic work of the two convolutions as SURVEY.md 8(d) counts it (conv1 in + out, conv2 in + residual + out),
