@@ -124,7 +124,7 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
       if (tw > L.Wo || tw > cap || (ti > 0 && tw >= L.Wo)) continue;
       for (int th = 1; th <= L.Ho && th * tw <= cap; ++th) {
         const int hh = (th - 1) * pc.stride + 1 + 2 * k2, hw = (tw - 1) * pc.stride + 1 + 2 * k2;
-        for (int nseg = 1; nseg <= 4; ++nseg) {
+        for (int nseg = 1; nseg <= 8; ++nseg) {
           if (nseg * th * tw > cap || nseg * hh * hw > halo_cap) break;
           const int ps = (nseg * hh * hw * 16 + 255) & ~255;
           if ((v.occ == 3 ? m32p_lds_bytes(pc, ps, nr) : m32_lds_bytes(pc, ps)) > lds_cap) break;
