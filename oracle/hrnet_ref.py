@@ -6,6 +6,10 @@ Follows /root/reference/landmark_regression/lib/models/pose_hrnet.py:
   * HighResolutionModule .......... branches :139-185, fuse layers :187-242, forward :247-265
   * stages ........................ _make_stage :393-423 (last stage-4 module fuses to branch 0 only)
   * final 1x1 (or 3x3) conv + bias  :323-329, :458
+and, for MODEL.NAME hrnet_cms / hrnet_cms_384 (lib/models/hrnet_cms.py, hrnet_cms_384.py):
+  * stage 4 keeps all four outputs  hrnet_cms.py:321-322 (multi_scale_output=True)
+  * four heads ConvTranspose2d(C_b -> 32, k5 s4 p1 op1 | k3 s2 p1 op1) + Conv2d(32 -> J)   :353-419
+  * top-down pyramid: x_b = head_b(y_b) + bilinear_x2(x_{b+1}), eval returns x_0             :551-562
 
 The network is evaluated functionally from a plain ``state_dict`` whose keys and
 shapes are those of the reference module (``state_dict_spec``), so checkpoints
@@ -38,6 +42,29 @@ def w32_cfg(num_joints=11, image=256):
 
 def w48_cfg(num_joints=11, image=384):
     return _wN_cfg(48, num_joints, image)
+
+
+HEADS = {"pose_hrnet": None, "hrnet_cms": ("equal_to_image", 5, 4), "hrnet_cms_384": ("4x", 3, 2)}
+
+
+def head_of(cfg):
+    """None for pose_hrnet, else (key suffix, kernel, stride) of the four transposed-conv heads."""
+    return HEADS[cfg["MODEL"].get("NAME", "pose_hrnet")]
+
+
+def head_names(cfg):
+    suffix = head_of(cfg)[0]
+    return ["final_layer%s_%s" % ("" if b == 0 else str(b + 1), suffix) for b in range(4)]
+
+
+def with_model(cfg, name):
+    """Copy of cfg for another member of the family (pose_hrnet / hrnet_cms / hrnet_cms_384)."""
+    out = {"MODEL": dict(cfg["MODEL"])}
+    out["MODEL"]["NAME"] = name
+    up = {None: 1}.get(head_of(out), None) or head_of(out)[2]
+    img = out["MODEL"]["IMAGE_SIZE"][0]
+    out["MODEL"]["HEATMAP_SIZE"] = [img // 4 * up, img // 4 * up]
+    return out
 
 
 def _wN_cfg(c, num_joints, image, modules=(1, 4, 3)):
@@ -111,7 +138,7 @@ def state_dict_spec(cfg):
         last_stage = sname == "STAGE4"
         stname = "stage%d" % (si + 2)
         for m in range(scfg["NUM_MODULES"]):
-            multi = not (last_stage and m == scfg["NUM_MODULES"] - 1)
+            multi = head_of(cfg) is not None or not (last_stage and m == scfg["NUM_MODULES"] - 1)
             mp = "%s.%d" % (stname, m)
             if scfg["BLOCK"] != "BASIC":
                 raise NotImplementedError("stage blocks other than BASIC are not used by any shipped config")
@@ -131,7 +158,14 @@ def state_dict_spec(cfg):
                             _conv(sd, "%s.%d.0" % (fp, k), cout, cur[j], 3); _bn(sd, "%s.%d.1" % (fp, k), cout)
         pre = cur
     fk = ex["FINAL_CONV_KERNEL"]
-    _conv(sd, "final_layer", cfg["MODEL"]["NUM_JOINTS"], pre[0], fk, bias=True)
+    if head_of(cfg) is None:
+        _conv(sd, "final_layer", cfg["MODEL"]["NUM_JOINTS"], pre[0], fk, bias=True)
+    else:
+        _, k, _ = head_of(cfg)
+        for b, name in enumerate(head_names(cfg)):
+            sd[name + ".0.weight"] = (pre[b], 32, k, k)          # ConvTranspose2d: (in, out, k, k)
+            sd[name + ".0.bias"] = (32,)
+            _conv(sd, name + ".1", cfg["MODEL"]["NUM_JOINTS"], 32, fk, bias=True)
     return sd
 
 
@@ -148,7 +182,7 @@ def make_state_dict(cfg, seed=0):
             fan_in = shape[1] * shape[2] * shape[3]
             bound = (1.0 / fan_in) ** 0.5                    # kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in))
             sd[name] = (torch.rand(shape, generator=g) * 2 - 1) * bound
-        elif name == "final_layer.bias":
+        elif name.startswith("final_layer") and leaf == "bias":
             sd[name] = (torch.rand(shape, generator=g) * 2 - 1) * 0.05
         elif leaf in ("weight", "running_var"):
             sd[name] = 0.75 + 0.5 * torch.rand(shape, generator=g)
@@ -196,8 +230,38 @@ class _Arith:
         return self.rnd(y) if store else y
 
 
+    def head(self, x, name, k, s):
+        """ConvTranspose2d(k, stride s, padding 1, output_padding 1) + Conv2d (hrnet_cms.py:353-368)."""
+        sd = self.sd
+        wt, bt = sd[name + ".0.weight"].float(), sd[name + ".0.bias"].float()
+        wc, bc = sd[name + ".1.weight"].float(), sd[name + ".1.bias"].float()
+        if self.dt is None:
+            y = F.conv_transpose2d(x, wt, bt, stride=s, padding=1, output_padding=1)
+            return F.conv2d(y, wc, bc, 1, (wc.shape[-1] - 1) // 2)
+        # HIP storage model (csrc/head.hip): the two linear layers are folded into one transposed convolution
+        # C -> J; every kernel tap is a 1x1 convolution whose result ("tap map") is stored in the 16-bit type;
+        # the taps that reach an output pixel are summed in fp32 together with the folded bias.
+        if wc.shape[-1] != 1:
+            raise NotImplementedError("folded heads need FINAL_CONV_KERNEL == 1")
+        w = torch.einsum("cmyx,jm->cjyx", wt.double(), wc[:, :, 0, 0].double()).float()      # (C, J, k, k)
+        b = (wc[:, :, 0, 0].double() @ bt.double() + bc.double()).float()
+        n, _, h, wd = x.shape
+        out = b.view(1, -1, 1, 1).repeat(n, 1, s * h, s * wd).contiguous()
+        for ky in range(k):
+            for kx in range(k):
+                t = self.rnd(F.conv2d(x, self.rnd(w[:, :, ky, kx]).t().reshape(w.shape[1], w.shape[0], 1, 1)))
+                # output row = s*iy - 1 + ky, for the input rows whose target lies inside the map
+                iy0 = 1 if ky == 0 else 0
+                ix0 = 1 if kx == 0 else 0
+                iy1 = min(h, (s * h - ky) // s + 1)
+                ix1 = min(wd, (s * wd - kx) // s + 1)
+                out[:, :, s * iy0 - 1 + ky: s * (iy1 - 1) + ky: s, s * ix0 - 1 + kx: s * (ix1 - 1) + kx: s] += t[:, :, iy0:iy1, ix0:ix1]
+        return out
+
+
 def forward(sd, cfg, x, emulate=None, taps=None):
-    """x: (N,3,H,W) float32, ImageNet-normalised.  Returns (N,J,H/4,W/4) float32 heatmaps.
+    """x: (N,3,H,W) float32, ImageNet-normalised.  Returns (N,J,H/4,W/4) float32 heatmaps
+    (hrnet_cms: (N,J,H,W); hrnet_cms_384: (N,J,H/2,W/2)).
     ``taps``: optional dict that receives named intermediate tensors."""
     ex = extra_of(cfg)
     A = _Arith(sd, emulate)
@@ -241,7 +305,7 @@ def forward(sd, cfg, x, emulate=None, taps=None):
         nb = scfg["NUM_BRANCHES"]
         stname = "stage%d" % (si + 2)
         for m in range(scfg["NUM_MODULES"]):
-            multi = not (sname == "STAGE4" and m == scfg["NUM_MODULES"] - 1)
+            multi = head_of(cfg) is not None or not (sname == "STAGE4" and m == scfg["NUM_MODULES"] - 1)
             mp = "%s.%d" % (stname, m)
             for b in range(nb):
                 t = xs[b]
@@ -271,5 +335,16 @@ def forward(sd, cfg, x, emulate=None, taps=None):
             tap("%s.out0" % mp, xs[0])
         ylist = xs
         pre = cur
-    out = A.conv_bn(ylist[0], "final_layer", None, store=False)
+    if head_of(cfg) is None:
+        out = A.conv_bn(ylist[0], "final_layer", None, store=False)
+        return tap("heatmaps", out)
+    # hrnet_cms.py:551-557: coarse-to-fine sum of the four heads
+    _, k, s = head_of(cfg)
+    names = head_names(cfg)
+    out = None
+    for b in (3, 2, 1, 0):
+        y = A.head(ylist[b], names[b], k, s)
+        if out is not None:
+            y = y + F.interpolate(out, scale_factor=2, mode="bilinear", align_corners=False)
+        out = tap("head%d" % b, y)
     return tap("heatmaps", out)

@@ -5,6 +5,7 @@ container (it never ships; /root/reference does not exist on the GPU box):
   * lib/models/pose_hrnet.py  -- imported as-is (needs only torch); the reference module is built
     from a plain-dict cfg, loaded (strict=True) with the seeded synthetic checkpoint, and run in
     fp32 on seeded inputs.  Vectors: inputs are regenerated from seeds, expected heatmaps stored.
+  * lib/models/hrnet_cms.py, hrnet_cms_384.py -- same recipe for the multi-head family (section 8f row 3).
   * lib/core/inference.py     -- imported under a stub `cv2` module whose getAffineTransform is the
     6x6 solve OpenCV performs (cv2 itself is a third-party wheel absent from the image); covers
     get_max_preds and get_final_preds with POST_PROCESS on and off.
@@ -28,8 +29,8 @@ sys.path.insert(0, ROOT)
 from oracle import hrnet_ref as R  # noqa: E402  (only for the seeded checkpoint/input recipe)
 
 
-def ref_pose_hrnet():
-    spec = importlib.util.spec_from_file_location("ref_pose_hrnet", os.path.join(REF, "lib/models/pose_hrnet.py"))
+def ref_pose_hrnet(name="pose_hrnet"):
+    spec = importlib.util.spec_from_file_location("ref_" + name, os.path.join(REF, "lib/models/%s.py" % name))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     return m
@@ -61,6 +62,34 @@ def hrnet_vectors():
         out[name + "/num_keys"] = np.array([len(sd)], dtype=np.int64)
         print(name, tuple(y.shape), float(y.std()))
     np.savez_compressed(os.path.join(HERE, "hrnet_reference_outputs.npz"), **out)
+
+
+class AttrDict(dict):
+    """dict with attribute access, recursively (hrnet_cms reads cfg.MODEL.EXTRA as well as cfg['MODEL'])."""
+
+    def __init__(self, d):
+        super().__init__({k: AttrDict(v) if isinstance(v, dict) else v for k, v in d.items()})
+
+    __getattr__ = dict.__getitem__
+
+
+def cms_vectors():
+    cases = {"cms_tiny64": ("hrnet_cms", R.tiny_cfg(), 64, 2, 7, 8), "cms384_tiny64": ("hrnet_cms_384", R.tiny_cfg(), 64, 2, 9, 10),
+             "cms384_w32_64": ("hrnet_cms_384", R.w32_cfg(), 64, 1, 11, 12), "cms_w32_64": ("hrnet_cms", R.w32_cfg(), 64, 1, 13, 14)}
+    out = {}
+    for name, (model, base, size, n, wseed, xseed) in cases.items():
+        cfg = R.with_model(base, model)
+        net = ref_pose_hrnet(model).get_pose_net(AttrDict(cfg), False).eval()
+        sd = R.make_state_dict(cfg, seed=wseed)
+        net.load_state_dict(sd, strict=True)
+        x = torch.randn(n, 3, size, size, generator=torch.Generator().manual_seed(xseed))
+        with torch.no_grad():
+            y = net(x)
+        out[name + "/heatmaps"] = y.numpy()
+        out[name + "/meta"] = np.array([size, n, wseed, xseed], dtype=np.int64)
+        out[name + "/num_keys"] = np.array([len(sd)], dtype=np.int64)
+        print(name, tuple(y.shape), float(y.std()))
+    np.savez_compressed(os.path.join(HERE, "hrnet_cms_reference_outputs.npz"), **out)
 
 
 def decode_vectors():
@@ -105,4 +134,5 @@ def decode_vectors():
 if __name__ == "__main__":
     torch.manual_seed(0)
     hrnet_vectors()
+    cms_vectors()
     decode_vectors()
