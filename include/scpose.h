@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SCPOSE_ABI_VERSION 1
+#define SCPOSE_ABI_VERSION 2
 
 enum {
   SCPOSE_OK = 0,
@@ -42,6 +42,13 @@ enum {
 
 /* 16-bit storage / MFMA operand type of the network (accumulation is always fp32). */
 enum { SCPOSE_DT_BF16 = 0, SCPOSE_DT_F16 = 1 };
+
+/* output head = cfg.MODEL.NAME (landmark_regression/lib/models/):
+ *   FINAL_LAYER  pose_hrnet.py:323-329   final_layer conv on branch 0, heat-maps H/4 x W/4
+ *   CMS          hrnet_cms.py:353-419, :551-557   four ConvTranspose2d(k5,s4)+Conv2d heads summed coarse-to-fine
+ *                with bilinear x2 upsampling, heat-maps H x W ("equal_to_image")
+ *   CMS_384      hrnet_cms_384.py (same, k3 s2), heat-maps H/2 x W/2 ("4x") */
+enum { SCPOSE_HEAD_FINAL_LAYER = 0, SCPOSE_HEAD_CMS = 1, SCPOSE_HEAD_CMS_384 = 2 };
 
 /* input formats of scpose_hrnet_forward */
 enum {
@@ -70,6 +77,7 @@ typedef struct scpose_hrnet_desc {
   int32_t num_channels[3][4];  /* EXTRA.STAGEk.NUM_CHANNELS */
   int32_t dtype;               /* SCPOSE_DT_* */
   float mean[3], std[3];       /* Normalize() constants for SCPOSE_IN_U8_NHWC */
+  int32_t head;                /* SCPOSE_HEAD_*: which member of the model family (cfg.MODEL.NAME) */
 } scpose_hrnet_desc;
 
 typedef struct scpose_hrnet* scpose_hrnet_t;
@@ -90,11 +98,16 @@ int32_t scpose_hrnet_destroy(scpose_hrnet_t h);
 /* bytes of device workspace scpose_hrnet_forward needs for a batch of n frames of h x w. */
 int32_t scpose_hrnet_workspace_bytes(scpose_hrnet_t h, int32_t n, int32_t height, int32_t width,
                                      size_t* bytes);
+/* heat-map size scpose_hrnet_forward writes for an input of height x width: H/4 (pose_hrnet, the
+ * cfg.MODEL.HEATMAP_SIZE of the shipped YAMLs), H (hrnet_cms) or H/2 (hrnet_cms_384). */
+int32_t scpose_hrnet_heatmap_size(scpose_hrnet_t h, int32_t height, int32_t width, int32_t* out_h,
+                                  int32_t* out_w);
 /* number of kernel launches of one forward and total conv FLOPs (2*MAC) per frame. */
 int32_t scpose_hrnet_stats(scpose_hrnet_t h, int32_t height, int32_t width, int32_t* launches,
                            double* flops_per_frame, double* act_bytes_per_frame);
 
-/* in: device pointer in in_fmt; heatmaps: device float32 N x J x H/4 x W/4 (NCHW, raw scores,
+/* in: device pointer in in_fmt; heatmaps: device float32 N x J x H/4 x W/4 (scpose_hrnet_heatmap_size for the
+ * hrnet_cms heads) (NCHW, raw scores,
  * exactly what the reference forward returns).  H and W must be multiples of 32. */
 int32_t scpose_hrnet_forward(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n,
                              int32_t height, int32_t width, float* heatmaps, void* workspace,
@@ -147,6 +160,11 @@ int32_t scpose_crop_warp(const uint8_t* frames, const int64_t* offsets, const in
  *   perm       device i32 J: perm[j] = partner joint of j (j itself when unpaired) */
 int32_t scpose_flip_merge(const float* a, const float* b, const int32_t* perm, int32_t n, int32_t j,
                           int32_t h, int32_t w, int32_t shift, float* out, void* stream);
+
+/* Ensemble mean of validate_cv (landmark_regression/lib/core/function.py:530-536,
+ * tools/test_cv_ensemble.py:84-98): acc = (acc + x) / div over count float32 values.  Call once per
+ * additional model with div = 1, and with div = number of models for the last one. */
+int32_t scpose_heatmap_accumulate(float* acc, const float* x, float div, int64_t count, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Batched PnP.  Replaces, per frame, the confidence filter + cv2.solvePnPRansac(...,

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 DT_BF16, DT_F16 = 0, 1
 IN_F32_NCHW, IN_U8_NHWC = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class HrnetDesc(ctypes.Structure):
@@ -28,6 +28,7 @@ class HrnetDesc(ctypes.Structure):
         ("dtype", c_int32),
         ("mean", c_float * 3),
         ("std", c_float * 3),
+        ("head", c_int32),
     ]
 
 
@@ -39,6 +40,7 @@ SYMBOLS = {
                                       POINTER(c_int64), c_int32, c_int32, POINTER(c_void_p)]),
     "scpose_hrnet_destroy": (c_int32, [c_void_p]),
     "scpose_hrnet_workspace_bytes": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_size_t)]),
+    "scpose_hrnet_heatmap_size": (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32)]),
     "scpose_hrnet_stats": (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_int32), POINTER(c_double),
                                      POINTER(c_double)]),
     "scpose_hrnet_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
@@ -53,6 +55,7 @@ SYMBOLS = {
                                    c_void_p]),
     "scpose_crop_warp": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                    c_void_p]),
+    "scpose_heatmap_accumulate": (c_int32, [c_void_p, c_void_p, c_float, c_int64, c_void_p]),
     "scpose_flip_merge": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                     c_void_p]),
     "scpose_pnp_epnp_ransac": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_double,

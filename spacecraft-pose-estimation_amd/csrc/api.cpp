@@ -37,6 +37,13 @@ extern "C" int32_t scpose_flip_merge(const float* a, const float* b, const int32
   return flip_merge_launch(a, b, perm, n, j, h, w, shift, out, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int32_t scpose_heatmap_accumulate(float* acc, const float* x, float div, int64_t count, void* stream) {
+  if (count == 0) return SCPOSE_OK;
+  SCP_REQUIRE(acc && x && count > 0, "heatmap_accumulate: null argument");
+  SCP_REQUIRE(div > 0.f, "heatmap_accumulate: div=%f", (double)div);
+  return heatmap_accumulate_launch(acc, x, div, (size_t)count, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int32_t scpose_max_preds(const float* heatmaps, int32_t n, int32_t j, int32_t h,
                                     int32_t w, float* coords, float* maxvals, void* stream) {
   if (n == 0) return SCPOSE_OK;

@@ -153,6 +153,9 @@ int32_t fuse_sum_launch(const void* const* terms, const int32_t* shifts, int nte
                         int H, int W, int dtype, void* out, hipStream_t stream);
 int32_t crop_warp_launch(const uint8_t* frames, const int64_t* offsets, const int32_t* hw, const double* minv,
                          int N, int oh, int ow, int swap_rb, uint8_t* out, hipStream_t stream);
+int32_t head_gather_launch(const void* taps, const float* bias, const float* prev, int N, int J, int H, int W,
+                           int K, int S, int dtype, float* out, hipStream_t stream);
+int32_t heatmap_accumulate_launch(float* acc, const float* x, float div, size_t count, hipStream_t stream);
 int32_t flip_merge_launch(const float* a, const float* b, const int32_t* perm, int N, int J, int H, int W, int shift,
                           float* out, hipStream_t stream);
 int32_t nchw_to_blocked_launch(const float* src, int N, int C, int H, int W, int dtype, void* dst,

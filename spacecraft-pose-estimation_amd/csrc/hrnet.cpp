@@ -7,6 +7,9 @@
 //   transitions :333-372 (new branch always from the LAST previous branch, :445/:453),
 //   HighResolutionModule branches :139-185 + fuse :187-242/:247-265,
 //   stages :393-423 (last stage-4 module fuses to branch 0 only), final_layer :323-329/:458.
+// desc.head != 0 selects the hrnet_cms family (lib/models/hrnet_cms.py, hrnet_cms_384.py): same trunk with
+//   multi_scale_output=True in the last module (hrnet_cms.py:321-322) and four transposed-conv heads summed
+//   coarse-to-fine (:353-419, :551-557) -- see head.hip.
 // Checkpoint keys are the reference module's state_dict keys.
 #include <math.h>
 #include <stdio.h>
@@ -68,7 +71,7 @@ static bool fold(Weights& W, const std::string& conv, const std::string& bn, int
   return true;
 }
 
-enum OpKind { OP_STEM = 0, OP_CONV = 1, OP_FUSE = 2, OP_BLOCK = 3 };   // OP_BLOCK: fused BasicBlock (conv_block_kernel.h)
+enum OpKind { OP_STEM = 0, OP_CONV = 1, OP_FUSE = 2, OP_BLOCK = 3, OP_HEAD = 4 };   // OP_BLOCK: fused BasicBlock (conv_block_kernel.h); OP_HEAD: head.hip
 
 struct TensorDesc {
   int C, ds;       // channels, log2 spatial downscale w.r.t. the network input
@@ -84,6 +87,7 @@ struct Op {
   int conv2;         // OP_BLOCK: second convolution of the block
   int relu, out_f32;
   int nterms, term[4], shift[4];
+  int head;          // OP_HEAD: index into head_bias; in = tap map, res = coarser level (f32) or -1
 };
 
 }  // namespace scpose
@@ -95,6 +99,8 @@ struct scpose_hrnet {
   float* d_stem_w = nullptr;   // [64][27] folded
   float* d_stem_b = nullptr;   // [64]
   float* d_mean_std = nullptr; // [6]
+  float* d_head_bias = nullptr; // [4][16] folded biases of the hrnet_cms heads
+  int head_k = 0, head_s = 1;   // transposed-conv kernel / stride of the heads (heat-map = S * branch-0 size)
   std::vector<scpose::TensorDesc> tensors;
   std::vector<scpose::Op> ops;
   // cached arena plan
@@ -182,6 +188,51 @@ struct Builder {
     net->ops.push_back(op);
     return t;
   }
+  // x_b = Conv2d(32->J,1x1)(ConvTranspose2d(C->32,K,S,p1,op1)(y)) [+ bilinear_x2(prev)]  (hrnet_cms.py:353-368, :551-557)
+  // folded into one transposed convolution C -> J: an MFMA 1x1 convolution to the tap map + the gather of head.hip.
+  // Returns the f32 tensor id of x_b (or -2 when it is the network output).
+  int head(int y, const std::string& name, int b, int K, int S, int prev, bool to_heatmaps) {
+    if (status != SCPOSE_OK) return -1;
+    const int C = net->tensors[y].C, J = net->desc.num_joints, M = 32, cpt = J <= 8 ? 8 : 16;
+    const float* wt = W->get(name + ".0.weight", (int64_t)C * M * K * K);   // ConvTranspose2d weight: (in, out, k, k)
+    const float* bt = W->get(name + ".0.bias", M);
+    const float* wc = W->get(name + ".1.weight", (int64_t)J * M);
+    const float* bc = W->get(name + ".1.bias", J);
+    if (!W->missing.empty() && !W->allow_missing) { status = SCPOSE_E_MISSING; return -1; }
+    const int cout = K * K * cpt;
+    std::vector<float> w((size_t)cout * C, 0.f), zero(cout, 0.f);
+    if (wt && wc)
+      for (int ci = 0; ci < C; ++ci)
+        for (int tap = 0; tap < K * K; ++tap)
+          for (int j = 0; j < J; ++j) {
+            double acc = 0;
+            for (int m = 0; m < M; ++m) acc += (double)wt[((size_t)ci * M + m) * K * K + tap] * wc[j * M + m];
+            w[((size_t)tap * cpt + j) * C + ci] = (float)acc;
+          }
+    float bias[16] = {0};
+    for (int j = 0; j < J; ++j) {
+      double acc = bc ? bc[j] : 0.0;
+      if (wc && bt) for (int m = 0; m < M; ++m) acc += (double)wc[j * M + m] * bt[m];
+      bias[j] = (float)acc;
+    }
+    if (hipMemcpy(net->d_head_bias + b * 16, bias, sizeof(bias), hipMemcpyHostToDevice) != hipSuccess) {
+      status = SCPOSE_E_HIP; return -1;
+    }
+    PackedConv pc;
+    const int32_t st = conv_upload(w.data(), zero.data(), cout, C, 1, 1, net->desc.dtype, &pc);
+    if (st != SCPOSE_OK) { status = st; return -1; }
+    net->convs.push_back(pc);
+    Op cv{};
+    cv.kind = OP_CONV; cv.in = y; cv.res = -1; cv.conv = (int)net->convs.size() - 1;
+    cv.out = new_tensor(cout, net->tensors[y].ds);
+    net->ops.push_back(cv);
+    Op op{};
+    op.kind = OP_HEAD; op.in = cv.out; op.res = prev; op.conv = -1; op.head = b;
+    // an f32 map of J x (S*h) x (S*w) occupies as many bytes as 2*J*S*S 16-bit channels at the branch resolution
+    op.out = to_heatmaps ? -2 : new_tensor(2 * J * S * S, net->tensors[y].ds);
+    net->ops.push_back(op);
+    return op.out;
+  }
   int fuse(const std::vector<int>& terms, const std::vector<int>& shifts, int C, int ds) {
     if (status != SCPOSE_OK) return -1;
     Op op{};
@@ -264,7 +315,7 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
       }
     }
     for (int m = 0; m < d.num_modules[si]; ++m) {
-      const bool multi = !(si == 2 && m == d.num_modules[si] - 1);
+      const bool multi = d.head != SCPOSE_HEAD_FINAL_LAYER || !(si == 2 && m == d.num_modules[si] - 1);
       const std::string mp = fmt("stage%d.%d", si + 2, m);
       for (int b = 0; b < nb; ++b) {
         int t = xs[b];
@@ -303,8 +354,19 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
     ylist = xs;
     pre = cur;
   }
-  if (B.status == SCPOSE_OK)
+  if (B.status == SCPOSE_OK && d.head == SCPOSE_HEAD_FINAL_LAYER) {
     B.conv(ylist[0], "final_layer", "", d.num_joints, d.final_conv_kernel, 1, false, -1, true, true);
+  } else if (B.status == SCPOSE_OK) {
+    const bool cms = d.head == SCPOSE_HEAD_CMS;
+    net->head_k = cms ? 5 : 3;
+    net->head_s = cms ? 4 : 2;
+    SCP_CHECK_HIP(hipMalloc(&net->d_head_bias, 4 * 16 * sizeof(float)));
+    int prev = -1;
+    for (int b = 3; b >= 0; --b) {      // hrnet_cms.py:551-557: x4, x3 = head3 + up(x4), x2 = ..., x = head + up(x2)
+      const std::string name = fmt("final_layer%s_%s", b == 0 ? "" : fmt("%d", b + 1).c_str(), cms ? "equal_to_image" : "4x");
+      prev = B.head(ylist[b], name, b, net->head_k, net->head_s, prev, b == 0);
+    }
+  }
   if (B.status == SCPOSE_E_MISSING || (!W.missing.empty() && !W.allow_missing)) {
     set_error("checkpoint tensor missing: %s", W.missing.c_str());
     return SCPOSE_E_MISSING;
@@ -419,6 +481,12 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
       rc = conv_launch(net->convs[op.conv], ptr(op.in), n, h >> ti.ds, w >> ti.ds, ptr(op.res),
                        op.relu, op.out_f32, out, st, op.in2 > 0 ? ptr(op.in2 - 1) : nullptr,
                        op.in2 > 0 ? net->tensors[op.in].C / 8 : 0);
+    } else if (op.kind == OP_HEAD) {
+      const TensorDesc& ti = net->tensors[op.in];
+      float* out = op.out == -2 ? heatmaps : static_cast<float*>(ptr(op.out));
+      rc = head_gather_launch(ptr(op.in), net->d_head_bias + op.head * 16, static_cast<const float*>(ptr(op.res)), n,
+                              net->desc.num_joints, h >> ti.ds, w >> ti.ds, net->head_k, net->head_s,
+                              net->desc.dtype, out, st);
     } else if (op.kind == OP_BLOCK) {
       const TensorDesc& ti = net->tensors[op.in];
       rc = block_launch(net->convs[op.conv], net->convs[op.conv2], ptr(op.in), n, h >> ti.ds, w >> ti.ds, ptr(op.out), st);
@@ -464,6 +532,11 @@ static void op_work(const scpose_hrnet* net, const Op& op, int h, int w, double*
     *f = 2.0 * 2.0 * pc.cin * pc.cout * 9 * hi * wi;
     *by = 5.0 * pc.cin * hi * wi * 2;
     sig[1] = 31; sig[2] = pc.cin; sig[3] = pc.cout;
+  } else if (op.kind == OP_HEAD) {
+    const TensorDesc& ti = net->tensors[op.in];
+    const double hi = h >> ti.ds, wi = w >> ti.ds, S = net->head_s, J = net->desc.num_joints;
+    *by = ti.C * hi * wi * 2 + J * S * S * hi * wi * 4 + (op.res >= 0 ? J * S * S * hi * wi : 0);   // tap map + f32 out + coarser f32 level
+    sig[1] = net->head_k * 10 + net->head_s; sig[2] = ti.C; sig[3] = net->desc.num_joints;
   } else {
     const TensorDesc& to = net->tensors[op.out];
     const double ho = h >> to.ds, wo = w >> to.ds;
@@ -491,6 +564,7 @@ void hrnet_free(scpose_hrnet* net) {
   if (net->d_stem_w) (void)hipFree(net->d_stem_w);
   if (net->d_stem_b) (void)hipFree(net->d_stem_b);
   if (net->d_mean_std) (void)hipFree(net->d_mean_std);
+  if (net->d_head_bias) (void)hipFree(net->d_head_bias);
   for (auto& e : net->events) (void)hipEventDestroy(e);
   net->events.clear();
 }
@@ -510,6 +584,11 @@ extern "C" int32_t scpose_hrnet_create(const scpose_hrnet_desc* desc, const char
   SCP_REQUIRE(desc->num_joints > 0, "hrnet_create: num_joints=%d", desc->num_joints);
   SCP_REQUIRE(desc->final_conv_kernel == 1 || desc->final_conv_kernel == 3, "hrnet_create: FINAL_CONV_KERNEL=%d", desc->final_conv_kernel);
   SCP_REQUIRE(desc->dtype == SCPOSE_DT_BF16 || desc->dtype == SCPOSE_DT_F16, "hrnet_create: dtype=%d", desc->dtype);
+  SCP_REQUIRE(desc->head >= SCPOSE_HEAD_FINAL_LAYER && desc->head <= SCPOSE_HEAD_CMS_384, "hrnet_create: head=%d", desc->head);
+  if (desc->head != SCPOSE_HEAD_FINAL_LAYER) {
+    SCP_REQUIRE(desc->final_conv_kernel == 1, "hrnet_create: the hrnet_cms heads are folded, which needs FINAL_CONV_KERNEL == 1 (got %d)", desc->final_conv_kernel);
+    SCP_REQUIRE(desc->num_joints <= 16, "hrnet_create: the hrnet_cms heads support NUM_JOINTS <= 16 (got %d)", desc->num_joints);
+  }
   for (int s = 0; s < 3; ++s) {
     SCP_REQUIRE(desc->num_branches[s] == s + 2, "hrnet_create: STAGE%d NUM_BRANCHES=%d (expected %d)", s + 2, desc->num_branches[s], s + 2);
     SCP_REQUIRE(desc->num_modules[s] >= 1, "hrnet_create: STAGE%d NUM_MODULES=%d", s + 2, desc->num_modules[s]);
@@ -550,6 +629,16 @@ extern "C" int32_t scpose_hrnet_workspace_bytes(scpose_hrnet_t h, int32_t n, int
   SCP_REQUIRE(n > 0 && height > 0 && width > 0 && height % 32 == 0 && width % 32 == 0,
               "hrnet_workspace_bytes: n=%d H=%d W=%d (H, W multiples of 32)", n, height, width);
   *bytes = hrnet_plan(h, n, height, width);
+  return SCPOSE_OK;
+}
+
+extern "C" int32_t scpose_hrnet_heatmap_size(scpose_hrnet_t h, int32_t height, int32_t width, int32_t* out_h,
+                                             int32_t* out_w) {
+  SCP_REQUIRE(h && out_h && out_w, "hrnet_heatmap_size: null argument");
+  SCP_REQUIRE(height > 0 && width > 0 && height % 32 == 0 && width % 32 == 0,
+              "hrnet_heatmap_size: H=%d W=%d (multiples of 32)", height, width);
+  *out_h = height / 4 * h->head_s;
+  *out_w = width / 4 * h->head_s;
   return SCPOSE_OK;
 }
 

@@ -3,6 +3,7 @@
 Interface kept from landmark_regression/lib/models/pose_hrnet.py:
   get_pose_net(cfg, is_train, **kwargs) -> nn.Module              (:495-501)
   module(x: float32 N x 3 x H x W, normalised) -> float32 N x J x H/4 x W/4   (:425-460)
+  (hrnet_cms.py / hrnet_cms_384.py subclass this tree with their four transposed-conv heads)
   .state_dict() / .load_state_dict(sd, strict=False) with the reference's key names and shapes
   (conv weights OIHW, BatchNorm weight/bias/running_mean/running_var/num_batches_tracked).
 
@@ -83,10 +84,13 @@ def _hr_module(channels, num_blocks, multi_scale_output):
 
 
 class PoseHighResolutionNet(nn.Module):
+    MODEL_NAME = "pose_hrnet"     # what the engine is told (ops.HEAD_CODES); overridden by hrnet_cms / hrnet_cms_384
+    HEAD = None                   # (state_dict key suffix, kernel, stride) of the transposed-conv heads, if any
+
     def __init__(self, cfg, **kwargs):
         super().__init__()
         extra = cfg["MODEL"]["EXTRA"]
-        self._cfg_model = {"NUM_JOINTS": int(cfg["MODEL"]["NUM_JOINTS"]),
+        self._cfg_model = {"NAME": self.MODEL_NAME, "NUM_JOINTS": int(cfg["MODEL"]["NUM_JOINTS"]),
                            "EXTRA": {k: (dict(extra[k]) if k.startswith("STAGE") else extra[k]) for k in extra}}
         self.dtype_name = kwargs.get("dtype", "bf16")
         self.conv1 = _conv(3, 64, 3, 2); self.bn1 = nn.BatchNorm2d(64, momentum=BN_MOMENTUM)
@@ -110,14 +114,25 @@ class PoseHighResolutionNet(nn.Module):
                     trans.append(nn.Sequential(*chain))
             setattr(self, "transition%d" % (si + 1), nn.ModuleList(trans))
             nm = int(scfg["NUM_MODULES"])
-            mods = [_hr_module(cur, [int(b) for b in scfg["NUM_BLOCKS"]], not (name == "STAGE4" and m == nm - 1)) for m in range(nm)]
+            mods = [_hr_module(cur, [int(b) for b in scfg["NUM_BLOCKS"]],
+                               self.HEAD is not None or not (name == "STAGE4" and m == nm - 1)) for m in range(nm)]
             setattr(self, "stage%d" % (si + 2), nn.Sequential(*mods))
             pre = cur
-        fk = int(extra["FINAL_CONV_KERNEL"])
-        self.final_layer = _conv(pre[0], int(cfg["MODEL"]["NUM_JOINTS"]), fk, 1, bias=True)
+        self._make_head(pre, int(cfg["MODEL"]["NUM_JOINTS"]), int(extra["FINAL_CONV_KERNEL"]))
         self.pretrained_layers = extra["PRETRAINED_LAYERS"] if "PRETRAINED_LAYERS" in extra else ["*"]
         self._engine = None
         self._engine_version = None
+
+    def _make_head(self, channels, num_joints, fk):
+        if self.HEAD is None:
+            self.final_layer = _conv(channels[0], num_joints, fk, 1, bias=True)
+            return
+        suffix, k, stride = self.HEAD        # hrnet_cms.py:353-419: one ConvTranspose2d + Conv2d pair per branch
+        for b, c in enumerate(channels):
+            name = "final_layer%s_%s" % ("" if b == 0 else str(b + 1), suffix)
+            setattr(self, name, nn.Sequential(
+                nn.ConvTranspose2d(c, 32, kernel_size=k, stride=stride, padding=1, output_padding=1),
+                _conv(32, num_joints, fk, 1, bias=True)))
 
     # ---- engine lifetime: rebuilt whenever parameters may have changed ----
     def _param_version(self):
@@ -144,7 +159,11 @@ class PoseHighResolutionNet(nn.Module):
         raise RuntimeError("init_weights: training-time initialisation is out of scope; load a checkpoint instead")
 
 
-def get_pose_net(cfg, is_train, **kwargs):
+def _get_pose_net(cls, cfg, is_train, **kwargs):
     if is_train:
         raise ValueError("get_pose_net(is_train=True): the MI355X build covers the inference path only")
-    return PoseHighResolutionNet(cfg, **kwargs)
+    return cls(cfg, **kwargs)
+
+
+def get_pose_net(cfg, is_train, **kwargs):
+    return _get_pose_net(PoseHighResolutionNet, cfg, is_train, **kwargs)

@@ -187,6 +187,19 @@ def flip_merge(out, out_flipped, flip_pairs, shift):
     return res
 
 
+def heatmap_accumulate(acc, x, div=1.0):
+    """In place acc = (acc + x) / div on the device: the ensemble sum / mean of validate_cv
+    (lib/core/function.py:530-536).  acc, x: float32 device tensors of the same shape."""
+    _need_cuda(acc, x)
+    if acc.shape != x.shape or acc.dtype != torch.float32 or x.dtype != torch.float32:
+        raise nat.NativeError("heatmap_accumulate: float32 tensors of one shape expected")
+    if not acc.is_contiguous():
+        raise nat.NativeError("heatmap_accumulate: acc must be contiguous (it is updated in place)")
+    nat.check(nat.lib().scpose_heatmap_accumulate(_ptr(acc), _ptr(x.contiguous()), float(div), acc.numel(), _stream()),
+              "heatmap_accumulate")
+    return acc
+
+
 # ------------------------------------------------------------------ PnP
 def pnp_epnp_ransac(kp_xyc, landmarks, K, dist, conf_thr0=0.95, min_pts=15, thr_decay=0.8, thr_iters=100,
                     max_iters=10000, reproj_err=15.0, confidence=0.99, want_rvec=False):
@@ -210,11 +223,19 @@ def pnp_epnp_ransac(kp_xyc, landmarks, K, dist, conf_thr0=0.95, min_pts=15, thr_
 
 
 # ------------------------------------------------------------------ HRNet engine
+HEAD_CODES = {"pose_hrnet": 0, "hrnet_cms": 1, "hrnet_cms_384": 2}     # include/scpose.h SCPOSE_HEAD_*
+
+
 def desc_from_cfg(cfg, dtype="bf16", mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
-    """cfg: yacs-like node or plain dict with MODEL.NUM_JOINTS and MODEL.EXTRA.STAGE{2,3,4}."""
+    """cfg: yacs-like node or plain dict with MODEL.NUM_JOINTS, MODEL.EXTRA.STAGE{2,3,4} and (optionally)
+    MODEL.NAME in pose_hrnet / hrnet_cms / hrnet_cms_384 (the modules of landmark_regression/lib/models/)."""
     model = cfg["MODEL"]
     extra = model["EXTRA"]
     d = nat.HrnetDesc()
+    name = str(model["NAME"]) if "NAME" in model else "pose_hrnet"
+    if name not in HEAD_CODES:
+        raise nat.NativeError("MODEL.NAME=%s: supported models are %s" % (name, ", ".join(HEAD_CODES)))
+    d.head = HEAD_CODES[name]
     d.num_joints = int(model["NUM_JOINTS"])
     d.final_conv_kernel = int(extra["FINAL_CONV_KERNEL"])
     d.num_stages = 3
@@ -269,6 +290,11 @@ class HrnetEngine:
         nat.check(nat.lib().scpose_hrnet_workspace_bytes(self._h, n, h, w, ctypes.byref(b)), "hrnet_workspace_bytes")
         return b.value
 
+    def heatmap_size(self, h, w):
+        oh = c_int32(); ow = c_int32()
+        nat.check(nat.lib().scpose_hrnet_heatmap_size(self._h, h, w, ctypes.byref(oh), ctypes.byref(ow)), "hrnet_heatmap_size")
+        return oh.value, ow.value
+
     def stats(self, h, w):
         l = c_int32(); f = c_double(); by = c_double()
         nat.check(nat.lib().scpose_hrnet_stats(self._h, h, w, ctypes.byref(l), ctypes.byref(f), ctypes.byref(by)), "hrnet_stats")
@@ -291,8 +317,11 @@ class HrnetEngine:
         need = self.workspace_bytes(n, h, w)
         if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        oh, ow = self.heatmap_size(h, w)
         if out is None:
-            out = torch.empty((n, self.num_joints, h // 4, w // 4), dtype=torch.float32, device=x.device)
+            out = torch.empty((n, self.num_joints, oh, ow), dtype=torch.float32, device=x.device)
+        elif tuple(out.shape) != (n, self.num_joints, oh, ow) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise nat.NativeError("hrnet_forward: out must be contiguous float32 %s" % ((n, self.num_joints, oh, ow),))
         fn = nat.lib().scpose_hrnet_forward_profiled if profile else nat.lib().scpose_hrnet_forward
         nat.check(fn(self._h, _ptr(x), fmt, n, h, w, _ptr(out), _ptr(self._ws), self._ws.numel(), _stream()), "hrnet_forward")
         self._last_hw = (h, w)
