@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Drop-in for the reference's landmark_regression/tools/test_cv_ensemble.py (:35-159), on the MI355X HIP path.
+
+    cd landmark_regression
+    python tools/test_cv_ensemble.py --cfg experiments/<name>.yaml TEST.MODEL_FILE a.pth TEST.MODEL_FILE2 b.pth ...
+
+Every one of TEST.MODEL_FILE, MODEL_FILE2 .. MODEL_FILE6 that names an existing file becomes one member of the
+ensemble (:84-98, strict load); the members' heat-maps are averaged per batch (validate_cv) and the result is
+written as pred_real.mat (:155-156).
+
+Same arguments and inputs as tools/test.py (--cfg, --modelDir, --logDir, --dataDir, --prevModelDir, trailing
+yacs KEY VAL overrides).  Multi-GPU: `python -m torch.distributed.run --nproc-per-node N tools/test_cv_ensemble.py
+...` shards the frames over one process per GPU instead of DataParallel (:98).
+"""
+import argparse
+import os
+import pprint
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.utils.data  # noqa: E402
+
+import scpose  # noqa: E402,F401  (alias of ./spacecraft-pose-estimation_amd)
+from importlib import import_module  # noqa: E402
+
+_P = "spacecraft-pose-estimation_amd"
+config_mod = import_module(_P + ".config")
+models = import_module(_P + ".models")
+dataset = import_module(_P + ".dataset")
+parallel = import_module(_P + ".parallel")
+from_utils = import_module(_P + ".utils.utils")
+transforms = import_module(_P + ".utils.transforms")
+JointsMSELoss = import_module(_P + ".core.loss").JointsMSELoss
+validate_cv = import_module(_P + ".core.function").validate_cv
+cfg, update_config = config_mod.cfg, config_mod.update_config
+
+
+def parse_args():
+    parser = argparse.ArgumentParser(description="Train keypoints network")
+    parser.add_argument("--cfg", help="experiment configure file name", required=True, type=str)
+    parser.add_argument("opts", help="Modify config options using the command-line", default=None, nargs=argparse.REMAINDER)
+    parser.add_argument("--modelDir", help="model directory", type=str, default="")
+    parser.add_argument("--logDir", help="log directory", type=str, default="")
+    parser.add_argument("--dataDir", help="data directory", type=str, default="")
+    parser.add_argument("--prevModelDir", help="prev Model directory", type=str, default="")
+    parser.add_argument("--device_crop", action="store_true",
+                        help="(extension) warp the crops on the GPU (scpose_crop_warp) instead of in the data loader")
+    return parser.parse_args()
+
+
+def main():
+    args = parse_args()
+    update_config(cfg, args)
+    logger, final_output_dir, tb_log_dir = from_utils.create_logger(cfg, args.cfg, "valid")
+    logger.info(pprint.pformat(args))
+    logger.info(cfg)
+
+    ws, rank, local = parallel.world()
+    if not torch.cuda.is_available():
+        raise SystemExit("tools/test_cv_ensemble.py: no ROCm device visible; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local if ws > 1 else int(cfg.GPUS[0]))
+
+    cv_models = []
+    for path in (cfg.TEST.MODEL_FILE, cfg.TEST.MODEL_FILE2, cfg.TEST.MODEL_FILE3, cfg.TEST.MODEL_FILE4,
+                 cfg.TEST.MODEL_FILE5, cfg.TEST.MODEL_FILE6):
+        if path and os.path.isfile(path):
+            logger.info("=> ensemble member {} from {}".format(len(cv_models) + 1, path))
+            net = getattr(models, cfg.MODEL.NAME).get_pose_net(cfg, is_train=False)
+            net.load_state_dict(torch.load(path, map_location="cpu"))
+            cv_models.append(net.cuda().eval())
+    if not cv_models:
+        raise SystemExit("tools/test_cv_ensemble.py: none of TEST.MODEL_FILE .. TEST.MODEL_FILE6 is an existing file")
+
+    criterion = JointsMSELoss(use_target_weight=cfg.LOSS.USE_TARGET_WEIGHT).cuda()
+    normalize = transforms.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])
+    valid_dataset = getattr(dataset, cfg.DATASET.DATASET)(
+        cfg, cfg.DATASET.ROOT, cfg.DATA_DIR, cfg.DATASET.TEST_SET, False,
+        transforms.Compose([transforms.ToTensor(), normalize]))
+    lo, hi = parallel.shard_range(len(valid_dataset), rank, ws)
+    subset = torch.utils.data.Subset(valid_dataset, range(lo, hi)) if ws > 1 else valid_dataset
+    valid_dataset.device_crop = bool(args.device_crop)
+    valid_loader = torch.utils.data.DataLoader(subset, batch_size=cfg.TEST.BATCH_SIZE_PER_GPU * len(cfg.GPUS),
+                                               shuffle=False, num_workers=cfg.WORKERS, pin_memory=not args.device_crop,
+                                               collate_fn=valid_dataset.collate_device_crop if args.device_crop else None)
+    validate_cv(cfg, valid_loader, valid_dataset, cv_models, criterion, final_output_dir, tb_log_dir, "pred_real")
+
+
+if __name__ == "__main__":
+    main()

@@ -7,6 +7,10 @@ dataset.evaluate -> <pred_file_name>.mat).  Differences in HOW, not WHAT:
   * with WORLD_SIZE > 1 every rank evaluates its contiguous shard of the dataset and the
     (N,J,3)/(N,6) rows are all-gathered (parallel.py) -- replaces DataParallel;
   * loss / PCK are logged like the reference (they do not affect any output).
+
+validate_cv(): the ensemble loop of lib/core/function.py:500-592 (tools/test_cv_ensemble.py): the heat-maps of
+up to six models are summed and divided by their number on the device (scpose_heatmap_accumulate), then decoded
+exactly like validate() (no flip test there, as in the reference).
 """
 import logging
 import os
@@ -49,8 +53,28 @@ def _print_name_value(name_value, full_arch_name):
 
 def validate(config, val_loader, val_dataset, model, criterion, output_dir, tb_log_dir, pred_file_name="pred",
              writer_dict=None, log_metrics=True):
+    return _run(config, val_loader, val_dataset, [model], criterion, output_dir, pred_file_name, log_metrics,
+                flip_test=bool(config.TEST.FLIP_TEST))
+
+
+def validate_cv(config, val_loader, val_dataset, models, criterion, output_dir, tb_log_dir, pred_file_name,
+                writer_dict=None, log_metrics=True):
+    if not models:
+        raise ValueError("validate_cv: no model given (none of TEST.MODEL_FILE .. MODEL_FILE6 exists?)")
+    return _run(config, val_loader, val_dataset, list(models), criterion, output_dir, pred_file_name, log_metrics,
+                flip_test=False)
+
+
+def _last(outputs):
+    return outputs[-1] if isinstance(outputs, (list, tuple)) else outputs
+
+
+def _run(config, val_loader, val_dataset, models, criterion, output_dir, pred_file_name, log_metrics, flip_test):
     batch_time, losses, acc = AverageMeter(), AverageMeter(), AverageMeter()
-    model.eval()
+    for m in models:
+        m.eval()
+    model = models[0]
+    warned = False
     dev = torch.device("cuda", torch.cuda.current_device())
     dist = parallel.init() if parallel.world()[0] > 1 else None
     num_samples = len(val_dataset)
@@ -63,15 +87,22 @@ def validate(config, val_loader, val_dataset, model, criterion, output_dir, tb_l
                 input = ops.crop_warp(input, meta["trans"].numpy(), (int(size[0]), int(size[1])), device=dev)
             else:
                 input = input.to(dev, non_blocking=True)
-            outputs = model(input)
-            output = outputs[-1] if isinstance(outputs, list) else outputs
-            if config.TEST.FLIP_TEST:
-                out_f = model(input.flip(2) if input.dtype == torch.uint8 else input.flip(3))   # x axis: NHWC crops / NCHW tensors
-                out_f = out_f[-1] if isinstance(out_f, list) else out_f
+            output = _last(model(input))
+            if len(models) > 1:       # ensemble mean (:530-536): sum in model order, one division by len(models)
+                output = output.clone()
+                for k, other in enumerate(models[1:], start=2):
+                    ops.heatmap_accumulate(output, _last(other(input)), float(len(models)) if k == len(models) else 1.0)
+            if flip_test:
+                out_f = _last(model(input.flip(2) if input.dtype == torch.uint8 else input.flip(3)))   # x axis: NHWC crops / NCHW tensors
                 # flip_back + SHIFT_HEATMAP + average (:354-366) in one device kernel, no D2H round trip
                 output = ops.flip_merge(output, out_f, val_dataset.flip_pairs, config.TEST.SHIFT_HEATMAP)
             num_images = input.size(0)
-            if log_metrics and criterion is not None:
+            if log_metrics and criterion is not None and tuple(target.shape) != tuple(output.shape):
+                if not warned:    # the reference would raise inside the loss here
+                    logger.warning("MODEL.HEATMAP_SIZE targets %s do not match the model's heat-maps %s: loss / accuracy "
+                                   "logging is skipped", tuple(target.shape[2:]), tuple(output.shape[2:]))
+                    warned = True
+            elif log_metrics and criterion is not None:
                 target_d = target.to(dev, non_blocking=True)
                 loss = criterion(output, target_d, target_weight.to(dev, non_blocking=True))
                 losses.update(loss.item(), num_images)
