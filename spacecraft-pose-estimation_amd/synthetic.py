@@ -43,9 +43,10 @@ def random_checkpoint(cfg, seed=0):
     """Random-init state_dict of the architecture: Conv2d default init (kaiming-uniform, a=sqrt 5 ==
     U(+-1/sqrt(fan_in))), BN gamma,var ~ U[.75,1.25], beta,mean ~ N(0,.1^2) so activations stay O(1)
     through ~300 layers.  Keys/shapes come from the module tree (== the reference's state_dict)."""
-    from .models.pose_hrnet import PoseHighResolutionNet
+    from importlib import import_module
+    net_cls = import_module(".models." + str(cfg["MODEL"].get("NAME", "pose_hrnet")), __package__).PoseHighResolutionNet
     with torch.device("meta"):
-        spec = PoseHighResolutionNet(cfg).state_dict()
+        spec = net_cls(cfg).state_dict()
     g = torch.Generator().manual_seed(seed)
     sd = OrderedDict()
     for name, meta in spec.items():
@@ -56,7 +57,7 @@ def random_checkpoint(cfg, seed=0):
         elif len(shape) == 4:
             bound = (1.0 / (shape[1] * shape[2] * shape[3])) ** 0.5
             sd[name] = (torch.rand(shape, generator=g) * 2 - 1) * bound
-        elif name == "final_layer.bias":
+        elif name.startswith("final_layer") and leaf == "bias":
             sd[name] = (torch.rand(shape, generator=g) * 2 - 1) * 0.05
         elif leaf in ("weight", "running_var"):
             sd[name] = 0.75 + 0.5 * torch.rand(shape, generator=g)

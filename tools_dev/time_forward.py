@@ -1,4 +1,5 @@
-"""Developer timing of the HIP forward (not the contract bench): python tools_dev/time_forward.py [w48|w32] [N] [size]"""
+"""Developer timing of the HIP forward (not the contract bench): python tools_dev/time_forward.py [w48|w32] [N] [size] [dtype]
+SCPOSE_MODEL=hrnet_cms|hrnet_cms_384 selects the multi-head members of the family."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,6 +13,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 size = int(sys.argv[3]) if len(sys.argv) > 3 else (384 if which == "w48" else 256)
 dtype = sys.argv[4] if len(sys.argv) > 4 else "bf16"
 cfg = R.w48_cfg() if which == "w48" else R.w32_cfg()
+cfg = R.with_model(cfg, os.environ.get("SCPOSE_MODEL", "pose_hrnet"))
 sd = R.make_state_dict(cfg, seed=0)
 eng = ops.HrnetEngine(cfg, sd, dtype=dtype)
 x = torch.randint(0, 256, (n, size, size, 3), dtype=torch.uint8, device="cuda")
