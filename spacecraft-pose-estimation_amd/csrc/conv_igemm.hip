@@ -269,7 +269,9 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
   // keep loads and stores in flight; halve the pixel tile until two of them fit the LDS and the register budget
   static const char* e11 = getenv("SCPOSE_K1_OCC");
   static const char* e11p = getenv("SCPOSE_K1_MINPIX");
-  if (pc.ks == 1 && !out_nchw_f32 && L.Ho * L.Wo >= (e11p ? atoi(e11p) : 4096) && !(e11 && atoi(e11) == 1)) {   // high-resolution maps only: measured slower on the small ones
+  // (not with a single K-step, Cin <= 32: measured 124 us with two workgroups vs 82 us with one for 32->128 @192x192x16)
+  if (pc.ks == 1 && !out_nchw_f32 && L.Ho * L.Wo >= (e11p ? atoi(e11p) : 4096) && !(e11 && atoi(e11) == 1) &&
+      (pc.ksteps_full >= 2 || (e11 && atoi(e11) == 2))) {   // high-resolution maps only: measured slower on the small ones
     while (L.th % 2 == 0 && L.th * L.tw > 64 &&
            (2 * conv_pipe_lds_bytes(pc, L.plane_stride, 1) > 160 * 1024 || pc.mrep * nrep * 4 > 128)) {
       L.th /= 2;
