@@ -217,3 +217,50 @@ def test_accuracy_matches_loop_restatement(pk):
     assert np.allclose(acc[1:], per)
     good = per >= 0
     assert cnt == int(good.sum()) and np.isclose(avg, per[good].mean()) and np.isclose(acc[0], avg)
+
+
+def test_evaluate_pipeline_two_scenes(pk, tmp_path):
+    """evaluate_pipeline.py (reference :62-91) over two scene directories: per scene tools/test.py -> pred.mat ->
+    export_predicted_poses_real.py -> opencv_poses.json, with the reference driver's command line."""
+    from PIL import Image
+    from scipy.io import loadmat
+    rng = np.random.default_rng(11)
+    cfg_node = R.w32_cfg(11, 64)
+    torch.save(R.make_state_dict(cfg_node, seed=33), tmp_path / "model.pth")
+    names = {}
+    for scene, n in (("scene_a", 3), ("scene_b", 5)):
+        frames = tmp_path / "data" / scene / "event-frames"
+        frames.mkdir(parents=True)
+        images, anns = [], []
+        for i in range(n):
+            name = "%s_%02d.png" % (scene, i)
+            Image.fromarray(rng.integers(0, 255, (120, 160, 3), dtype=np.uint8)).save(frames / name)
+            images.append({"id": i + 1, "file_name": name, "width": 160, "height": 120})
+            anns.append({"image_id": i + 1, "bbox": [12 + 2 * i, 9, 88, 72], "keypoints": [2.0] * 33, "id": i, "category_id": 1})
+        det = tmp_path / "det" / scene
+        det.mkdir(parents=True)
+        (det / "real_test.json").write_text(json.dumps({"images": images, "annotations": anns}))     # what stage 1 writes
+        names[scene] = [im["file_name"] for im in images]
+    (tmp_path / "landmarks.csv").write_text("x,y,z\n" + "\n".join(",".join(repr(float(v)) for v in r) for r in P.LANDMARKS))
+    (tmp_path / "calib.json").write_text(json.dumps({"intrinsics": {"camera_matrix": P.CAMERA_K.tolist(),
+                                                                    "distortion_coefficients": P.CAMERA_DIST.tolist()}}))
+    yaml_path = os.path.join(ROOT, "landmark_regression", "experiments", "bench", "w32_256.yaml")
+    cmd = [sys.executable, "evaluate_pipeline.py", "--data_dir", str(tmp_path / "data"), "--detection_model_file", "unused.pth",
+           "--regression_model_file", str(tmp_path / "model.pth"), "--detection_annotations_base", str(tmp_path / "det"),
+           "--regression_annotations_base", str(tmp_path / "reg"), "--pose_estimation_base", str(tmp_path / "poses"),
+           "--validation_annotations", "unused.json", "--landmarks_file", str(tmp_path / "landmarks.csv"),
+           "--calibration_file_path", str(tmp_path / "calib.json"), "--image_width", "160", "--image_height", "120",
+           "--joints_count", "11", "--cfg", yaml_path, "--no_overlay",
+           "--regression_opts", "MODEL.IMAGE_SIZE", "[64, 64]", "MODEL.HEATMAP_SIZE", "[16, 16]", "LOG_DIR", str(tmp_path / "log")]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for scene, files in names.items():
+        preds = loadmat(tmp_path / "reg" / scene / "EventsDataset" / "pose_hrnet" / "w32_256" / "pred.mat")["preds"]
+        assert preds.shape == (len(files), 11, 3)
+        poses = json.load(open(tmp_path / "poses" / scene / "opencv_poses.json"))
+        assert [p["image_name"] for p in poses] == files
+        assert all(np.array(p["rotation_matrix"]).shape == (3, 3) and np.array(p["T"]).shape == (3, 1) for p in poses)
+    # a scene without detection annotations is reported, not silently skipped
+    (tmp_path / "data" / "scene_c" / "event-frames").mkdir(parents=True)
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0 and "stage 1" in (r.stdout + r.stderr)

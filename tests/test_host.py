@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 from oracle import decode_ref as D
 from oracle import hrnet_ref as R
 
@@ -183,3 +185,29 @@ def test_shard_range_is_a_contiguous_partition(P):
 def test_landmark_csv_reader(P, tmp_path):
     (tmp_path / "lm.csv").write_text("x,y,z\n0.1,0.2,0.3\n-1,2,3.5\n")
     assert np.array_equal(P.pose_export.read_landmarks(tmp_path / "lm.csv"), np.array([[0.1, 0.2, 0.3], [-1, 2, 3.5]]))
+
+
+def test_evaluate_pipeline_path_conventions(tmp_path):
+    """evaluate_pipeline.py (reference :49-91): stage-relative paths, scene discovery, detection-file spellings."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("evaluate_pipeline", os.path.join(ROOT, "evaluate_pipeline.py"))
+    ep = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ep)
+    assert ep.under("regression", "out/x") == os.path.join(ROOT, "landmark_regression", "out", "x")
+    assert ep.under("detection", "../shared/det") == os.path.join(ROOT, "shared", "det")
+    assert ep.under("pose", "/abs/lm.csv") == "/abs/lm.csv"
+    (tmp_path / "b_scene").mkdir(); (tmp_path / "a_scene").mkdir(); (tmp_path / "notes.txt").write_text("x")
+    assert ep.scenes_of(str(tmp_path)) == ["a_scene", "b_scene"]
+    with pytest.raises(SystemExit, match="stage 1"):
+        ep.detection_file(str(tmp_path / "a_scene"))
+    (tmp_path / "a_scene" / "real_test.json").write_text("{}")
+    assert ep.detection_file(str(tmp_path / "a_scene")).endswith("real_test.json")
+    (tmp_path / "a_scene" / "test.json").write_text("{}")
+    assert ep.detection_file(str(tmp_path / "a_scene")).endswith(os.sep + "test.json")
+    cfg = os.path.join(ROOT, "landmark_regression", "experiments", "events", "events-config.yaml")
+    assert ep.output_names(cfg, []) == ("EventsDataset", "pose_hrnet")
+    assert ep.output_names(cfg, ["MODEL.NAME", "hrnet_cms", "DATASET.DATASET", "PEdataset"]) == ("PEdataset", "hrnet_cms")
+    a = ep.parse_args(["--data_dir", "d", "--regression_model_file", "m.pth", "--detection_annotations_base", "det",
+                       "--regression_annotations_base", "reg", "--pose_estimation_base", "pose", "--landmarks_file", "lm.csv",
+                       "--calibration_file_path", "calib.json"])
+    assert (a.image_width, a.image_height, a.joints_count) == (640, 480, 24)      # reference defaults (:38-43)
