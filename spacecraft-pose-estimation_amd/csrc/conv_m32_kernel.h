@@ -168,13 +168,12 @@ __global__ __launch_bounds__(256, OCC) void conv_m32_kernel(const ConvLaunch p) 
       xoff[i] = ok ? ((size_t)((p.dbg & 64) ? 0 : img) * p.cin_planes * HW + (size_t)(iy * p.W + ix)) * 16 : ~(size_t)0;
     }
   };
-  // K-chunks are summed in a per-workgroup rotated order: neighbouring CUs, which run in near
-  // lock-step, then pull DIFFERENT weight chunks from L2 at any moment instead of all hammering
-  // the same few cache lines (rotation needs equal-sized chunks)
-  const int crot = (planes_last == p.cp && !(p.dbg & 16)) ? wg % p.nchunks : 0;
+  // K-chunks are summed in their natural order in every workgroup.  (A per-workgroup rotated order, meant to
+  // spread the weight-chunk reads of lock-stepped CUs over L2, measured no faster and made a frame's result depend
+  // on which workgroup computed it, i.e. on its position in the batch.)
   auto issue_x = [&](int cl, int xb) {
     if (p.dbg & 4) return;
-    const int c = cl + crot < p.nchunks ? cl + crot : cl + crot - p.nchunks;
+    const int c = cl;
     const int planes = c == p.nchunks - 1 ? planes_last : p.cp;
     const char* inb = static_cast<const char*>(p.in) + (size_t)c * p.cp * HW * 16;
     char* xl = xl0 + xb * p.lds_x;
@@ -190,7 +189,7 @@ __global__ __launch_bounds__(256, OCC) void conv_m32_kernel(const ConvLaunch p) 
     }
   };
   auto issue_w = [&](int it, int cl, int wb) {
-    const int c = cl + crot < p.nchunks ? cl + crot : cl + crot - p.nchunks;
+    const int c = cl;
     const int planes = c == p.nchunks - 1 ? planes_last : p.cp;
     const int nbytes = (planes >> 1) * KK * (2 * MT * 16);
     const char* ws = static_cast<const char*>(p.wpk) + ((size_t)(it - fdiv(it, p.fd_nmblk) * p.n_mblk) * p.nchunks + c) * chunk_wbytes;
@@ -273,7 +272,7 @@ __global__ __launch_bounds__(256, OCC) void conv_m32_kernel(const ConvLaunch p) 
       }
       const unsigned long long t1 = now();
       {  // (3) MFMA loop: plane pairs x KK taps, taps unrolled so that every LDS offset is an immediate
-        const int planes = (last && crot == 0) ? planes_last : p.cp;
+        const int planes = last ? planes_last : p.cp;
         const int npp = (p.dbg & 1) ? 0 : planes >> 1;
         const uint32_t xl = (uint32_t)(size_t)(xl0 + xb * p.lds_x) + half * p.plane_stride;
         uint32_t wa = (uint32_t)(size_t)(wl0 + (w_resident ? 0 : (wc & 1)) * p.lds_w) + (half * MT + wm * (MR * 32) + r) * 16;

@@ -64,7 +64,6 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
   const int wg = xcd_remap(blockIdx.x, p.grid);
   const int it_begin = wg * p.items_per_wg;
   const int it_end = min(p.items_total, it_begin + p.items_per_wg);
-  const int crot = wg % p.nchunks;   // rotated chunk order (equal-sized chunks are a host-side requirement)
 
   auto pixel_of = [&](int pidx, int& ps, int& py, int& px) {   // flattened pixel -> (segment, y, x); ps < 0 = none
     if (pidx < P) {
@@ -119,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
       }
     };
     auto issue_x = [&](int cl, int xb) {
-      const int c = cl + crot < p.nchunks ? cl + crot : cl + crot - p.nchunks;
+      const int c = cl;   // chunks in natural order: results do not depend on the workgroup (batch position)
       const char* inb = static_cast<const char*>(p.in) + (size_t)c * p.cp * HW * 16;
       char* xl = xl0 + xb * p.lds_x;
 #pragma unroll
@@ -147,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
         }
     }
     auto issue_w = [&](int it, int cl, int wb) {
-      const int c = cl + crot < p.nchunks ? cl + crot : cl + crot - p.nchunks;
+      const int c = cl;   // chunks in natural order: results do not depend on the workgroup (batch position)
       const int nbytes = ksteps_full * (2 * MT * 16);
       if constexpr (WREG > 0) {   // registers -> LDS (same image as the DMA would write)
         char* wl = wl0 + wb * p.lds_w + ptid * 16;
@@ -315,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
         {  // MFMA loop: plane pairs x KK taps, taps unrolled so that every LDS offset is an immediate
           const int npp = (p.dbg & 1) ? 0 : p.cp >> 1;
           const uint32_t xl = (uint32_t)(size_t)(xl0 + xb * p.lds_x) + half * p.plane_stride;
-          const int cidx = c + crot < p.nchunks ? c + crot : c + crot - p.nchunks;
+          const int cidx = c;
           uint32_t wa = (uint32_t)(size_t)(wl0 + (w_resident ? cidx : (wc & 1)) * p.lds_w) + (half * MT + r) * 16;
           const int hw16 = p.halo_w * 16;
           frag_t a0[MR], b0[NR], a1[MR], b1[NR];

@@ -149,3 +149,35 @@ def test_fused_basic_block_matches_two_convs(gpu_ops, shape, dtype):
     tol = 1.5e-2 * ref.abs() + 1.5e-2 * ref.pow(2).mean().sqrt()
     assert not ((got - ref).abs() > tol).any(), "fused vs CPU: max |d| %.4g" % (got - ref).abs().max()
     assert not ((got - two).abs() > tol).any(), "fused vs unfused HIP: max |d| %.4g" % (got - two).abs().max()
+
+
+EQUIVARIANCE = [  # cin cout k s H   N  res   -- one shape per kernel family at batch sizes that fill the persistent grid
+    (96, 96, 3, 1, 48, 96, True),      # conv_m32p, weights in producer registers
+    (192, 192, 3, 1, 24, 128, True),   # conv_m32p, several K-chunks
+    (384, 384, 3, 1, 12, 256, True),   # conv_m32p, two segments per work item
+    (48, 96, 3, 2, 96, 64, False),     # conv_m32p stride 2
+    (64, 64, 3, 1, 96, 48, False),     # conv_m32 (single role)
+    (256, 48, 3, 1, 96, 32, False),
+    (64, 256, 1, 1, 96, 32, True),     # conv_pipe 1x1, two workgroups per CU
+    (48, 48, 3, 1, 96, 48, True),      # conv_pipe 3x3 (unfused branch-0 layer)
+]
+
+
+@pytest.mark.parametrize("case", EQUIVARIANCE, ids=lambda c: "c%d-%d_k%d_s%d_%d_n%d" % c[:6])
+def test_conv_is_equivariant_under_frame_permutation(gpu_ops, case):
+    """A frame's result must not depend on its position in the batch, i.e. on which workgroup computes it
+    (bit-exact): K-chunks and taps are accumulated in one fixed order everywhere."""
+    cin, cout, k, s, H, N, use_res = case
+    g = torch.Generator().manual_seed(cin + cout + H)
+    conv = gpu_ops.Conv(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, torch.randn(cout, generator=g) * 0.1, stride=s)
+    x = torch.randn(N, cin // 8, H, H, 8, generator=g).bfloat16().cuda()
+    Ho = (H - 1) // s + 1
+    r = torch.randn(N, cout // 8, Ho, Ho, 8, generator=g).bfloat16().cuda() if use_res else None
+    perm = torch.randperm(N, generator=g).cuda()
+    y = conv(x, residual=r, relu=True)
+    yp = conv(x[perm].contiguous(), residual=r[perm].contiguous() if use_res else None, relu=True)
+    assert torch.equal(yp, y[perm])
+    # and a sub-batch gives the same frames (different grid size / items per workgroup)
+    m = max(1, N // 3)
+    ys = conv(x[:m].contiguous(), residual=r[:m].contiguous() if use_res else None, relu=True)
+    assert torch.equal(ys, y[:m])

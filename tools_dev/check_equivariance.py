@@ -1,0 +1,41 @@
+"""Which layer classes of the W48 / 384x384 / batch-256 forward are not bit-exact under a permutation of the
+frames?  python tools_dev/check_equivariance.py [N]   (developer diagnostic)"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, scpose
+from importlib import import_module
+ops = import_module("spacecraft-pose-estimation_amd.ops")
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+SHAPES = [  # cin, cout, k, s, H, residual
+    (64, 64, 3, 2, 192, 0), (64, 64, 1, 1, 96, 0), (64, 64, 3, 1, 96, 0), (64, 256, 1, 1, 96, 1), (256, 64, 1, 1, 96, 0),
+    (256, 48, 3, 1, 96, 0), (256, 96, 3, 2, 96, 0), (48, 48, 3, 1, 96, 1), (96, 96, 3, 1, 48, 1), (192, 192, 3, 1, 24, 1),
+    (384, 384, 3, 1, 12, 1), (96, 48, 1, 1, 48, 0), (192, 48, 1, 1, 24, 0), (384, 48, 1, 1, 12, 0), (192, 96, 1, 1, 24, 0),
+    (384, 96, 1, 1, 12, 0), (384, 192, 1, 1, 12, 0), (48, 96, 3, 2, 96, 0), (48, 48, 3, 2, 96, 0), (48, 192, 3, 2, 48, 0),
+    (96, 192, 3, 2, 48, 0), (48, 48, 3, 2, 48, 0), (48, 384, 3, 2, 24, 0), (96, 96, 3, 2, 48, 0), (96, 384, 3, 2, 24, 0),
+    (192, 384, 3, 2, 24, 0)]
+g = torch.Generator().manual_seed(0)
+perm = torch.randperm(N, generator=g).cuda()
+for cin, cout, k, s, H, res in SHAPES:
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    conv = ops.Conv(w, torch.randn(cout, generator=g) * 0.1, stride=s)
+    x = torch.randn(N, cin // 8, H, H, 8, generator=g).bfloat16().cuda()
+    Ho = (H - 1) // s + 1
+    r = torch.randn(N, cout // 8, Ho, Ho, 8, generator=g).bfloat16().cuda() if res else None
+    y = conv(x, residual=r, relu=True)
+    y2 = conv(x, residual=r, relu=True)
+    yp = conv(x[perm].contiguous(), residual=r[perm].contiguous() if res else None, relu=True)
+    d = (yp.float() - y[perm].float()).abs()
+    nbad = int((d > 0).sum())
+    print("conv %3d->%3d k%d s%d %3dx%-3d res=%d: repeat %s  permuted %s  (%d values differ, max %.3g, frames %s)" % (
+        cin, cout, k, s, H, H, res, "ok " if torch.equal(y, y2) else "BAD", "ok " if nbad == 0 else "BAD", nbad, float(d.max()),
+        sorted(set((d.flatten(1).max(1).values > 0).nonzero().flatten().tolist()))[:8]))
+# fused BasicBlock
+for C, H in ((48, 96),):
+    c1 = ops.Conv(torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5, torch.randn(C, generator=g) * 0.1)
+    c2 = ops.Conv(torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5, torch.randn(C, generator=g) * 0.1)
+    x = torch.randn(N, C // 8, H, H, 8, generator=g).bfloat16().cuda()
+    y = ops.basic_block(c1, c2, x)
+    yp = ops.basic_block(c1, c2, x[perm].contiguous())
+    d = (yp.float() - y[perm].float()).abs()
+    print("fused block C=%d %dx%d: permuted %s (%d values differ)" % (C, H, H, "ok" if int((d > 0).sum()) == 0 else "BAD", int((d > 0).sum())))
