@@ -120,7 +120,8 @@ FULL_SIZE = {   # BASELINE.json configs[2] (the bench workload), configs[1], and
 @pytest.mark.parametrize("name", list(FULL_SIZE))
 def test_forward_full_size_properties(gpu_ops, name):
     """BASELINE.json configurations at full size, through properties that do not need the CPU oracle on the whole
-    batch: run-to-run determinism, equivariance under a permutation of the frames, equal frames -> equal heat-maps;
+    batch: run-to-run determinism, equivariance under a permutation of the frames, independence of the batch size,
+    equal frames -> equal heat-maps;
     plus the oracle on ONE frame taken from the full batch."""
     make_cfg, size, n, dt = FULL_SIZE[name]
     cfg = make_cfg()
@@ -137,6 +138,8 @@ def test_forward_full_size_properties(gpu_ops, name):
     assert torch.equal(eng(x[perm].contiguous()), a[perm]), "a frame's heat-maps depend on its position in the batch"
     assert torch.equal(a[n - 56], a[5])
     assert not torch.equal(a[6], a[5])
+    for m in (37, 1):         # and do not depend on the batch size (other grid sizes / items per workgroup)
+        assert torch.equal(eng(x[:m].contiguous()), a[:m]), "heat-maps of the first %d frames change with the batch size" % m
     # the last frame of the full batch against the oracle (16-bit storage model and fp32 reference arithmetic)
     mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
