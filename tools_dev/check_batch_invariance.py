@@ -1,0 +1,24 @@
+"""Which layer shapes give different bits for a frame when the batch size changes?  (developer diagnostic)
+python tools_dev/check_batch_invariance.py H W N   -- W48 layer classes on the maps of an H x W input"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, scpose
+from importlib import import_module
+ops = import_module("spacecraft-pose-estimation_amd.ops")
+H, W, N = (int(v) for v in sys.argv[1:4])
+C = 48
+LAYERS = [(64, 64, 3, 2, 1), (64, 64, 1, 1, 2), (64, 64, 3, 1, 2), (64, 256, 1, 1, 2), (256, 64, 1, 1, 2), (256, C, 3, 1, 2), (256, 2 * C, 3, 2, 2)]
+for b in range(4):
+    LAYERS.append((C << b, C << b, 3, 1, 2 + b))
+    for j in range(b + 1, 4):
+        LAYERS.append((C << j, C << b, 1, 1, 2 + j))
+        LAYERS.append((C << b, C << b, 3, 2, 2 + b))
+        LAYERS.append((C << b, C << j, 3, 2, 2 + b))
+g = torch.Generator().manual_seed(0)
+for cin, cout, k, s, ds in LAYERS:
+    h, w = H >> ds, W >> ds
+    conv = ops.Conv(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, torch.randn(cout, generator=g) * 0.1, stride=s)
+    x = torch.randn(N, cin // 8, h, w, 8, generator=g).bfloat16().cuda()
+    y = conv(x, relu=True)
+    bad = [m for m in range(1, N) if not torch.equal(conv(x[:m].contiguous(), relu=True), y[:m])]
+    print("conv %3d->%3d k%d s%d %3dx%-3d: %s" % (cin, cout, k, s, h, w, "ok" if not bad else "differs at sub-batch sizes %s" % bad[:6]))
