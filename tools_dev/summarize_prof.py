@@ -2,26 +2,8 @@
 usage: python tools_dev/summarize_prof.py <stats_dir> <fetch_dir> <write_dir> <out_prefix>"""
 import csv, glob, re, subprocess, sys, collections, os
 
-def demangle(n):
-    if n.startswith("_Z"):
-        try:
-            n = subprocess.run(["c++filt", n], capture_output=True, text=True).stdout.strip() or n
-        except Exception:
-            pass
-    n = re.sub(r"\(.*$", "", n)
-    n = n.replace("scpose::", "").replace("void ", "")
-    return n
-
-def short(n):
-    n = demangle(n)
-    m = re.search(r"(conv_\w+_kernel<[^>]*>)", n)
-    if m: return m.group(1).replace(" ", "")
-    m = re.search(r"conv_igemm_kernel<(.*)>", n)
-    if m:
-        a = [x.strip() for x in m.group(1).split(",")]
-        if len(a) == 5:
-            return "conv_igemm<%s k%s s%s mrep%s nrep%s>" % ({"0": "bf16", "1": "f16"}.get(a[0], a[0]), a[1], a[2], a[3], a[4])
-    return n[:60]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from summarize_prof_names import demangle, short  # noqa: E402,F401
 
 stats_dir, fetch_dir, write_dir, out = sys.argv[1:5]
 rows = list(csv.DictReader(open((glob.glob(stats_dir + "/*/*kernel_stats.csv") + glob.glob(stats_dir + "/*kernel_stats.csv"))[0])))
