@@ -13,6 +13,7 @@ namespace scpose {
 
 // ---- error plumbing (thread-local message, int status; nothing throws across the ABI) ----
 void set_error(const char* fmt, ...);
+const char* dev_env(const char* name);   // getenv() for development switches; null unless SCPOSE_DEV=1 (util.cpp)
 const char* last_error();
 
 #define SCP_CHECK_HIP(expr)                                                         \

@@ -7,7 +7,7 @@
 namespace scpose {
 
 bool block_fusable(const PackedConv& c1, const PackedConv& c2) {
-  static const char* e = getenv("SCPOSE_FUSE_BLOCK");
+  static const char* e = dev_env("SCPOSE_FUSE_BLOCK");
   if (e && atoi(e) == 0) return false;
   const int C = c1.cin;
   return c1.variant == 0 && c2.variant == 0 && c1.ks == 3 && c2.ks == 3 && c1.stride == 1 && c2.stride == 1 &&
@@ -34,7 +34,7 @@ int32_t block_launch(const PackedConv& c1, const PackedConv& c2, const void* in,
   if (grid > L.tiles_total) grid = L.tiles_total;
   L.tiles_per_wg = (L.tiles_total + grid - 1) / grid;
   L.grid = (L.tiles_total + L.tiles_per_wg - 1) / L.tiles_per_wg;
-  { static const char* e = getenv("SCPOSE_DBG"); const int dbg = e ? atoi(e) : 0;
+  { static const char* e = dev_env("SCPOSE_DBG"); const int dbg = e ? atoi(e) : 0;
     L.dbg_buf = (dbg & 8) ? conv_dbg_buffer(stream) : nullptr;
     if (dbg & 8) conv_dbg_set_grid(L.grid); }
   const int mrep = c1.cin / 16;

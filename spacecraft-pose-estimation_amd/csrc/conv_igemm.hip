@@ -239,7 +239,7 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
     if (2 * conv_pipe_lds_bytes(pc, L.plane_stride, 1) > 160 * 1024) { L.th = th0; set_geometry(); }
   }
   {   // development: SCPOSE_TILE="th,tw" overrides the tile of weight-resident 3x3 stride-1 layers
-    static const char* e = getenv("SCPOSE_TILE");
+    static const char* e = dev_env("SCPOSE_TILE");
     int eth = 0, etw = 0;
     if (e && resident && pc.ks == 3 && pc.stride == 1 && sscanf(e, "%d,%d", &eth, &etw) == 2 && eth > 0 && etw > 0) {
       L.th = eth; L.tw = etw; set_geometry();
@@ -261,14 +261,14 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
     if (groups == 1 && 2 * pc.mrep * nrep * 4 <= 224) nt = 2;
   }
   if (!resident && pc.ks == 3 && pc.stride == 2 && pc.mrep >= 4 && nrep <= 2) {
-    static const char* e = getenv("SCPOSE_S2_NT");
+    static const char* e = dev_env("SCPOSE_S2_NT");
     nt = e ? atoi(e) : 2;   // weight chunk shared by 2 sequential pixel tiles (measured: 3 is no better than 1)
   }
   if (resident && 2 * conv_pipe_lds_bytes(pc, L.plane_stride, 1) <= 160 * 1024) occ = 2;
   // 1x1 layers are bound by their memory instructions (K is tiny): two workgroups per CU double the waves that
   // keep loads and stores in flight; halve the pixel tile until two of them fit the LDS and the register budget
-  static const char* e11 = getenv("SCPOSE_K1_OCC");
-  static const char* e11p = getenv("SCPOSE_K1_MINPIX");
+  static const char* e11 = dev_env("SCPOSE_K1_OCC");
+  static const char* e11p = dev_env("SCPOSE_K1_MINPIX");
   // (not with a single K-step, Cin <= 32: measured 124 us with two workgroups vs 82 us with one for 32->128 @192x192x16)
   if (pc.ks == 1 && !out_nchw_f32 && L.Ho * L.Wo >= (e11p ? atoi(e11p) : 4096) && !(e11 && atoi(e11) == 1) &&
       (pc.ksteps_full >= 2 || (e11 && atoi(e11) == 2))) {   // high-resolution maps only: measured slower on the small ones

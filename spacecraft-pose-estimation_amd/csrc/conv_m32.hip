@@ -21,9 +21,9 @@ static const M32Variant kVariants[] = {
 };
 
 bool conv_m32_choose(int cin, int cout, int ks, int stride, int* mr, int* wm, int* cp) {
-  static const char* e = getenv("SCPOSE_M32");
+  static const char* e = dev_env("SCPOSE_M32");
   if (e && atoi(e) == 0) return false;
-  static const char* e2 = getenv("SCPOSE_M32_S2");
+  static const char* e2 = dev_env("SCPOSE_M32_S2");
   if (ks != 3 || cin % 16 != 0) return false;
   // stride 2 (fuse down paths, transition): producer/consumer kernel only, which needs >= 3 K-chunks;
   // measured 1.4-1.7x faster than the 16x16x32 kernel on these input-heavy layers (SCPOSE_M32_S2=0 disables)
@@ -100,7 +100,7 @@ static size_t m32_lds_bytes(const PackedConv& pc, int plane_stride) {
 int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream) {
   const int wn = 4 / pc.wm;
   const int k2 = pc.ks / 2;
-  static const char* occ_env = getenv("SCPOSE_M32_OCC");
+  static const char* occ_env = dev_env("SCPOSE_M32_OCC");
   const int occ_only = occ_env ? atoi(occ_env) : 0;
   // tile search over the built variants: maximise useful MFMA columns, prefer two workgroups per CU
   // (one computes while the other is stalled in its memory instructions), then pixels per weight chunk
@@ -111,7 +111,7 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   const int cus = conv_device_cus();
   const int tw_cand[8] = {L.Wo, 64, 48, 32, 24, 16, 12, 8};
   for (const M32Variant& v : kVariants) {
-    static const char* nr_env = getenv("SCPOSE_M32_NR");   // development: restrict the search to one column count
+    static const char* nr_env = dev_env("SCPOSE_M32_NR");   // development: restrict the search to one column count
     if (v.mr != pc.mrep || v.wm != pc.wm || (occ_only && v.occ != occ_only) || (nr_env && v.nr != atoi(nr_env))) continue;
     const int nr = v.nr;
     const int cap = wn * nr * 32;
@@ -174,10 +174,10 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   L.zero16 = conv_zero_page();
   SCP_REQUIRE(L.zero16, "conv: cannot allocate the zero page");
   L.tiles_total = L.N * L.tiles_x * L.tiles_y;
-  { static const char* e = getenv("SCPOSE_NST"); const int v = e ? atoi(e) : 0;   // producer/consumer kernel: stages that store the previous tile
+  { static const char* e = dev_env("SCPOSE_NST"); const int v = e ? atoi(e) : 0;   // producer/consumer kernel: stages that store the previous tile
     L.total_blocks = (b_occ == 3 && v > 0 && v <= pc.nchunks - 2) ? v : 0; }
   L.items_total = ((L.tiles_total + L.nt - 1) / L.nt) * pc.n_mblk;
-  { static const char* e = getenv("SCPOSE_DBG"); L.dbg = e ? atoi(e) : 0; }
+  { static const char* e = dev_env("SCPOSE_DBG"); L.dbg = e ? atoi(e) : 0; }
   L.dbg_buf = nullptr;
   if (L.dbg & 8) L.dbg_buf = conv_dbg_buffer(stream);
   if (L.dbg & 32)
@@ -194,7 +194,7 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   conv_dbg_set_grid(L.grid);
   if (b_occ == 3) {
     // L.groups doubles as "K-chunks of weights held in producer registers" for the producer/consumer kernel
-    static const char* wr_env = getenv("SCPOSE_M32_WREG");
+    static const char* wr_env = dev_env("SCPOSE_M32_WREG");
     L.groups = (pc.n_mblk == 1 && pc.nchunks == 6 && pc.stride == 1 && pc.mrep == 3 && b_nr == 3 && !(wr_env && atoi(wr_env) == 0)) ? 6 : 1;
     if (pc.dtype == SCPOSE_DT_BF16) return conv_m32p_dispatch_bf16(pc.stride, pc.mrep, b_nr, L, lds, stream);
     return conv_m32p_dispatch_f16(pc.stride, pc.mrep, b_nr, L, lds, stream);

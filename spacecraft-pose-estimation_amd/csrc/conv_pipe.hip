@@ -77,12 +77,12 @@ int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, 
   L.fd_nmblk = make_fastdiv(pc.n_mblk);
   L.nt = nt;
   L.items_total = ((L.tiles_total + nt * groups - 1) / (nt * groups)) * pc.n_mblk;
-  { static const char* e = getenv("SCPOSE_DBG"); L.dbg = e ? atoi(e) : 0; }
+  { static const char* e = dev_env("SCPOSE_DBG"); L.dbg = e ? atoi(e) : 0; }
   L.dbg_buf = nullptr;
   if (L.dbg & 8) L.dbg_buf = conv_dbg_buffer(stream);
   const int cus = conv_device_cus();
   int per_cu = (int)((160 * 1024) / lds);
-  { static const char* e = getenv("SCPOSE_K1_WGS"); const int cap = (pc.ks == 1 && e) ? atoi(e) : 2; per_cu = per_cu < 1 ? 1 : (per_cu > cap ? cap : per_cu); }
+  { static const char* e = dev_env("SCPOSE_K1_WGS"); const int cap = (pc.ks == 1 && e) ? atoi(e) : 2; per_cu = per_cu < 1 ? 1 : (per_cu > cap ? cap : per_cu); }
   if (occ < 2 || groups > 1) per_cu = 1;   // the variant's register budget assumes one workgroup per CU
   int grid = cus * per_cu;
   if (grid > L.items_total) grid = L.items_total;

@@ -277,7 +277,7 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
   // ---- layer1: 4 Bottlenecks (64 -> 256) ----
   for (int b = 0; b < 4; ++b) {
     const std::string p = fmt("layer1.%d", b);
-    static const char* cat_env = getenv("SCPOSE_CAT_DOWNSAMPLE");
+    static const char* cat_env = dev_env("SCPOSE_CAT_DOWNSAMPLE");
     const bool cat = b == 0 && !(cat_env && atoi(cat_env) == 0);
     int res = x;
     if (b == 0 && !cat) res = B.conv(x, p + ".downsample.0", p + ".downsample.1", 256, 1, 1, false);

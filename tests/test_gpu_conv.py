@@ -181,3 +181,32 @@ def test_conv_is_equivariant_under_frame_permutation(gpu_ops, case):
     m = max(1, N // 3)
     ys = conv(x[:m].contiguous(), residual=r[:m].contiguous() if use_res else None, relu=True)
     assert torch.equal(ys, y[:m])
+
+
+def test_development_switches_need_scpose_dev(gpu_ops):
+    """A stray SCPOSE_* variable must not steer a production process: the ablation switch SCPOSE_DBG=1 (skip the MFMA
+    loops) is ignored unless SCPOSE_DEV=1 is set too, and then the library says so on stderr."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import torch, scpose; from importlib import import_module; "
+            "ops = import_module('spacecraft-pose-estimation_amd.ops'); g = torch.Generator().manual_seed(0); "
+            "w = torch.randn(96, 96, 3, 3, generator=g) / 30; x = torch.randn(2, 12, 16, 16, 8, generator=g).bfloat16(); "
+            "y = ops.Conv(w)(x.cuda()).float().cpu(); "
+            "xr = x.float().permute(0, 1, 4, 2, 3).reshape(2, 96, 16, 16); "
+            "ref = torch.nn.functional.conv2d(xr, w.bfloat16().float(), padding=1).reshape(2, 12, 8, 16, 16).permute(0, 1, 3, 4, 2); "
+            "print('REL %%.4f' %% float((y - ref).norm() / ref.norm()))") % root
+
+    def run(extra):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("SCPOSE_")}
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rel = float([l for l in r.stdout.splitlines() if l.startswith("REL")][0].split()[1])
+        return rel, r.stderr
+
+    rel, err = run({"SCPOSE_DBG": "1"})
+    assert rel < 1e-2 and "SCPOSE_DEV" not in err
+    rel, err = run({"SCPOSE_DBG": "1", "SCPOSE_DEV": "1"})
+    assert rel > 0.5 and "SCPOSE_DEV=1" in err

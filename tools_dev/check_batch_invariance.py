@@ -1,5 +1,6 @@
 """Which layer shapes give different bits for a frame when the batch size changes?  (developer diagnostic)
 python tools_dev/check_batch_invariance.py H W N   -- W48 layer classes on the maps of an H x W input"""
+import _dev  # noqa: F401  (enables the library's development switches when SCPOSE_* variables are set)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, scpose

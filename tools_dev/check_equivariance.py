@@ -1,5 +1,6 @@
 """Which layer classes of the W48 / 384x384 / batch-256 forward are not bit-exact under a permutation of the
 frames?  python tools_dev/check_equivariance.py [N]   (developer diagnostic)"""
+import _dev  # noqa: F401  (enables the library's development switches when SCPOSE_* variables are set)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, scpose

@@ -1,3 +1,4 @@
+import _dev  # noqa: F401  (enables the library's development switches when SCPOSE_* variables are set)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F

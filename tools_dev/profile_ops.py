@@ -1,5 +1,6 @@
 """Per-launch-class timing of the HIP forward via scpose_hrnet_forward_profiled.
 usage: python tools_dev/profile_ops.py [w48|w32] [N] [size]"""
+import _dev  # noqa: F401  (enables the library's development switches when SCPOSE_* variables are set)
 import sys, os, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,4 +1,5 @@
 """Time the fused BasicBlock kernel: python tools_dev/time_block.py C H N"""
+import _dev  # noqa: F401  (enables the library's development switches when SCPOSE_* variables are set)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, scpose

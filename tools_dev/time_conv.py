@@ -1,4 +1,5 @@
 """Time one conv layer shape: python tools_dev/time_conv.py cin cout k s H N [res]"""
+import _dev  # noqa: F401  (enables the library's development switches when SCPOSE_* variables are set)
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, scpose

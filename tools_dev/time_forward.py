@@ -1,5 +1,6 @@
 """Developer timing of the HIP forward (not the contract bench): python tools_dev/time_forward.py [w48|w32] [N] [size] [dtype]
 SCPOSE_MODEL=hrnet_cms|hrnet_cms_384 selects the multi-head members of the family."""
+import _dev  # noqa: F401  (enables the library's development switches when SCPOSE_* variables are set)
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
