@@ -146,9 +146,11 @@ int32_t scpose_max_preds(const float* heatmaps, int32_t n, int32_t j, int32_t h,
  *   frames    device u8: the samples' full frames (H_i x W_i x 3, any sizes) packed back to back
  *   offsets   device i64 N: byte offset of sample i's frame inside `frames`
  *   frame_hw  device i32 N x 2: (H_i, W_i)
- *   minv      device f64 N x 6: row-major 2x3 INVERSE of the reference's `trans` (crop pixel -> frame pixel)
+ *   minv      device f64 N x 6: row-major 2x3 INVERSE of the reference's `trans` (crop pixel -> frame pixel),
+ *             inverted the way cv::warpAffine does it (OpenCV 3.4 imgwarp.cpp; utils/transforms.py:invert_affine_cv)
  *   crops     device u8 N x out_h x out_w x 3 = the SCPOSE_IN_U8_NHWC input of scpose_hrnet_forward
- * swap_rb != 0 exchanges channels 0 and 2 (BGR frame -> RGB crop).  Border value 0, bilinear in f64. */
+ * swap_rb != 0 exchanges channels 0 and 2 (BGR frame -> RGB crop).  Border value 0.  Arithmetic: OpenCV's
+ * fixed-point uint8 path (coordinates quantised to 1/32 px, integer weights scaled by 2^15, (sum + 2^14) >> 15). */
 int32_t scpose_crop_warp(const uint8_t* frames, const int64_t* offsets, const int32_t* frame_hw,
                          const double* minv, int32_t n, int32_t out_h, int32_t out_w, int32_t swap_rb,
                          uint8_t* crops, void* stream);

@@ -149,10 +149,10 @@ def crop_warp(frames, trans, out_wh, swap_rb=False, device=None):
             raise ValueError("crop_warp: frames must be HxWx3 uint8")
         flat.append(t.reshape(-1)); offs.append(o); hw.append((t.shape[0], t.shape[1])); o += t.numel()
     buf = torch.cat(flat).to(dev, non_blocking=True)
+    from .utils.transforms import invert_affine_cv
     minv = np.zeros((n, 6), dtype=np.float64)
     for i in range(n):
-        m = np.vstack([np.asarray(trans[i], dtype=np.float64), [0, 0, 1]])
-        minv[i] = np.linalg.inv(m)[:2].reshape(-1)      # same inverse as the NumPy restatement
+        minv[i] = invert_affine_cv(trans[i])            # the inverse map exactly as cv::warpAffine derives it
     offs_d = torch.tensor(offs, dtype=torch.int64, device=dev)
     hw_d = torch.tensor(hw, dtype=torch.int32, device=dev)
     minv_d = torch.from_numpy(minv).to(dev)

@@ -52,30 +52,58 @@ def affine_transform(pt, t):
     return np.dot(t, np.array([pt[0], pt[1], 1.0]).T)[:2]
 
 
+def invert_affine_cv(trans):
+    """The inverse map cv2.warpAffine derives from a forward 2x3 matrix (OpenCV 3.4 imgwarp.cpp, cv::warpAffine,
+    branch !WARP_INVERSE_MAP), in its operation order: returns the six doubles [a11 a12 b1 a21 a22 b2]."""
+    m = np.asarray(trans, dtype=np.float64).reshape(6).copy()
+    d = m[0] * m[4] - m[1] * m[3]
+    d = 1.0 / d if d != 0 else 0.0
+    a11, a22 = m[4] * d, m[0] * d
+    m[0] = a11; m[1] *= -d; m[3] *= -d; m[4] = a22
+    b1 = -m[0] * m[2] - m[1] * m[5]
+    b2 = -m[3] * m[2] - m[4] * m[5]
+    m[2] = b1; m[5] = b2
+    return m
+
+
+def _sat_int(v):
+    """cv::saturate_cast<int>(double): round half to even (cvRound), clamp to int32."""
+    return np.clip(np.rint(v), -2147483648.0, 2147483647.0).astype(np.int64)
+
+
 def warp_affine_bilinear(img, trans, out_wh):
-    """cv2.warpAffine(img, trans, (W, H), flags=INTER_LINEAR) with constant-0 border, restated in
-    NumPy: dst(x, y) = bilinear(src, M^-1 [x, y, 1]).  (OpenCV interpolates with 5-bit fixed-point
-    weights; this float version differs from it by at most ~1 grey level -- parity unpinned.)"""
+    """cv2.warpAffine(img, trans, (W, H), flags=INTER_LINEAR), constant-0 border, for uint8 images: the FIXED-POINT
+    algorithm OpenCV runs (3.4 imgwarp.cpp: hal::warpAffine + WarpAffineInvoker + remapBilinear with
+    FixedPtCast<int, uchar, 15>), restated in NumPy:
+      * source coordinates in 1/1024 px: X = round(M0*x*1024) + round((M1*y + M2)*1024) + 16, then >> 5, i.e. quantised
+        to 1/32 px (INTER_BITS = 5) with the +16 as rounding offset;
+      * integer bilinear weights (32-a)(32-b)*32 ... a*b*32 for the 5-bit fractions a, b (they sum to 32768; OpenCV's
+        table entry for a = b = 0 is [32767, 0, 0, 1], which yields the same pixel as [32768, 0, 0, 0]);
+      * pixel = (sum of the four taps * weights + 16384) >> 15, taps outside the frame count as 0.
+    cv2 is not available to compare with (parity unpinned); the anchors are the algorithm's known answers
+    (identity, integer shifts, half-pixel averages round up) in tests/."""
     w, h = int(out_wh[0]), int(out_wh[1])
-    m = np.vstack([np.asarray(trans, dtype=np.float64), [0, 0, 1]])
-    minv = np.linalg.inv(m)
-    xs, ys = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
-    sx = minv[0, 0] * xs + minv[0, 1] * ys + minv[0, 2]
-    sy = minv[1, 0] * xs + minv[1, 1] * ys + minv[1, 2]
-    x0 = np.floor(sx).astype(np.int64); y0 = np.floor(sy).astype(np.int64)
-    fx = (sx - x0)[..., None]; fy = (sy - y0)[..., None]
-    src = img.astype(np.float32)
-    if src.ndim == 2:
-        src = src[..., None]
+    m = invert_affine_cv(trans)
+    xs = np.arange(w, dtype=np.float64)
+    ys = np.arange(h, dtype=np.float64)
+    adelta = _sat_int(m[0] * xs * 1024.0)
+    bdelta = _sat_int(m[3] * xs * 1024.0)
+    x0 = _sat_int((m[1] * ys + m[2]) * 1024.0) + 16
+    y0 = _sat_int((m[4] * ys + m[5]) * 1024.0) + 16
+    X = (x0[:, None] + adelta[None, :]) >> 5
+    Y = (y0[:, None] + bdelta[None, :]) >> 5
+    sx = np.clip(X >> 5, -32768, 32767); sy = np.clip(Y >> 5, -32768, 32767)
+    a = (X & 31)[..., None]; b = (Y & 31)[..., None]
+    src = img if img.ndim == 3 else img[..., None]
     hh, ww = src.shape[:2]
 
     def tap(yy, xx):
         ok = (yy >= 0) & (yy < hh) & (xx >= 0) & (xx < ww)
-        v = src[np.clip(yy, 0, hh - 1), np.clip(xx, 0, ww - 1)]
+        v = src[np.clip(yy, 0, hh - 1), np.clip(xx, 0, ww - 1)].astype(np.int64)
         return v * ok[..., None]
-    out = (tap(y0, x0) * (1 - fx) * (1 - fy) + tap(y0, x0 + 1) * fx * (1 - fy) +
-           tap(y0 + 1, x0) * (1 - fx) * fy + tap(y0 + 1, x0 + 1) * fx * fy)
-    out = np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    acc = (tap(sy, sx) * ((32 - a) * (32 - b) * 32) + tap(sy, sx + 1) * (a * (32 - b) * 32) +
+           tap(sy + 1, sx) * ((32 - a) * b * 32) + tap(sy + 1, sx + 1) * (a * b * 32))
+    out = np.clip((acc + 16384) >> 15, 0, 255).astype(np.uint8)
     return out if img.ndim == 3 else out[..., 0]
 
 
