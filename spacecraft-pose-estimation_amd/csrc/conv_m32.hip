@@ -178,6 +178,13 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
     L.total_blocks = (b_occ == 3 && v > 0 && v <= pc.nchunks - 2) ? v : 0; }
   L.items_total = ((L.tiles_total + L.nt - 1) / L.nt) * pc.n_mblk;
   { static const char* e = dev_env("SCPOSE_DBG"); L.dbg = e ? atoi(e) : 0; }
+  {   // producer/consumer kernel: buffer-addressed global traffic when both tensors fit a 32-bit descriptor
+    static const char* e = dev_env("SCPOSE_M32_BUF");
+    const size_t ib = (size_t)L.N * L.cin_planes * L.H * L.W * 16, ob = (size_t)L.N * ((pc.cout + 7) / 8) * L.Ho * L.Wo * 16;
+    const bool fits = ib < 0xfffffff0ull && ob < 0xfffffff0ull && !(e && atoi(e) == 0);
+    L.in_bytes = fits ? (uint32_t)ib : 0;
+    L.out_bytes = fits ? (uint32_t)ob : 0;
+  }
   L.dbg_buf = nullptr;
   if (L.dbg & 8) L.dbg_buf = conv_dbg_buffer(stream);
   if (L.dbg & 32)

@@ -106,7 +106,13 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
 #pragma unroll
     for (int k = 0; k < NQ; ++k) pixel_of(k * 256 + ptid < PXCAP ? k * 256 + ptid : P, qs[k], qy[k], qx[k]);
 
+    // Tensors below 4 GiB are addressed through buffer descriptors (conv_pipe_kernel.h: dma16_buf): per-item 32-bit
+    // lane offsets, chunk / plane displacement in an SGPR, padding lanes out of range.  Larger ones keep 64-bit pointers.
+    const bool buf = p.in_bytes != 0;
+    const buf_rsrc_t rs_in = make_buf(p.in, p.in_bytes), rs_res = make_buf(p.res ? p.res : p.out, p.out_bytes),
+                     rs_out = make_buf(p.out, p.out_bytes);
     size_t xoff[MAXP];
+    uint32_t xvo[MAXP];
     auto locate_halo = [&](int it) {
 #pragma unroll
       for (int i = 0; i < MAXP; ++i) {
@@ -114,13 +120,22 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
         decode_tile(it, hs[i], img, oy0, ox0);
         const int iy = oy0 * STRIDE - (KS / 2) + hy[i], ix = ox0 * STRIDE - (KS / 2) + hx[i];
         const bool ok = img >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        xoff[i] = ok ? ((size_t)img * p.cin_planes * HW + (size_t)(iy * p.W + ix)) * 16 : ~(size_t)0;
+        if (buf) xvo[i] = ok ? (uint32_t)(img * p.cin_planes * HW + (iy * p.W + ix)) * 16u : BUF_OOB;
+        else xoff[i] = ok ? ((size_t)img * p.cin_planes * HW + (size_t)(iy * p.W + ix)) * 16 : ~(size_t)0;
       }
     };
     auto issue_x = [&](int cl, int xb) {
       const int c = cl;   // chunks in natural order: results do not depend on the workgroup (batch position)
       const char* inb = static_cast<const char*>(p.in) + (size_t)c * p.cp * HW * 16;
       char* xl = xl0 + xb * p.lds_x;
+      if (buf) {
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i)
+          if (hs[i] >= 0)
+            for (int pl = 0; pl < p.cp; ++pl)
+              dma16_buf(rs_in, xvo[i], (uint32_t)((c * p.cp + pl) * HW) * 16u, xl + pl * p.plane_stride + (i * 256 + wave * 64) * 16);
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < MAXP; ++i) {
         if (hs[i] >= 0) {
@@ -183,12 +198,23 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
         decode_tile(it, qs[k], img, oy0, ox0);
         const int oy = oy0 + qy[k], ox = ox0 + qx[k];
         const bool ok = img >= 0 && oy < p.Ho && ox < p.Wo;
-        qb[k] = ok ? ((size_t)img * cout_planes * HoWo + (size_t)oy * p.Wo + ox) * 16 : ~(size_t)0;
+        // buffer addressing: the 32-bit offset lives in the same slot (BUF_OOB for pixels outside the map)
+        if (buf) qb[k] = ok ? (size_t)((uint32_t)(img * cout_planes * HoWo + oy * p.Wo + ox) * 16u) : (size_t)BUF_OOB;
+        else qb[k] = ok ? ((size_t)img * cout_planes * HoWo + (size_t)oy * p.Wo + ox) * 16 : ~(size_t)0;
       }
     };
     // planes [pl0, pl1) of the retire buffer: residual rows of tile `it` -> RO (LDS-DMA)
     auto load_residual = [&](int it, const size_t* qb, int pl0, int pl1) {
       const int plane0 = (it - fdiv(it, p.fd_nmblk) * p.n_mblk) * ROPL;
+      if (buf) {
+        for (int pl = pl0; pl < pl1; ++pl)
+#pragma unroll
+          for (int k = 0; k < NQ; ++k)
+            if (k * 256 + ptid < PXCAP)
+              dma16_buf(rs_res, plane0 + pl < cout_planes ? (uint32_t)qb[k] : BUF_OOB, (uint32_t)((plane0 + pl) * HoWo) * 16u,
+                        ro + ((pl * PXCAP) + k * 256 + wave * 64) * 16);
+        return;
+      }
       for (int pl = pl0; pl < pl1; ++pl)
 #pragma unroll
         for (int k = 0; k < NQ; ++k)
@@ -202,6 +228,15 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
     // planes [pl0, pl1) of the retire buffer: results of tile `it` -> global
     auto store_results = [&](int it, const size_t* qb, int pl0, int pl1) {
       const int plane0 = (it - fdiv(it, p.fd_nmblk) * p.n_mblk) * ROPL;
+      if (buf) {
+        for (int pl = pl0; pl < pl1 && plane0 + pl < cout_planes; ++pl)
+#pragma unroll
+          for (int k = 0; k < NQ; ++k)
+            if (k * 256 + ptid < PXCAP)     // pixels outside the map carry BUF_OOB: the store is dropped by the hardware
+              store16_buf(rs_out, (uint32_t)qb[k], (uint32_t)((plane0 + pl) * HoWo) * 16u,
+                          *reinterpret_cast<const u32x4*>(ro + ((pl * PXCAP) + k * 256 + ptid) * 16));
+        return;
+      }
       for (int pl = pl0; pl < pl1; ++pl)
 #pragma unroll
         for (int k = 0; k < NQ; ++k)
@@ -214,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
     if (!(p.dbg & 128)) __builtin_amdgcn_s_setprio(3);   // memory instructions ahead of the consumers' MFMA stream
     size_t qb_cur[NQ], qb_prev[NQ];
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) qb_cur[k] = qb_prev[k] = ~(size_t)0;
+    for (int k = 0; k < NQ; ++k) qb_cur[k] = qb_prev[k] = buf ? (size_t)BUF_OOB : ~(size_t)0;
     int wc = 0, xb = 0;
     if (it_begin < it_end) {
       locate_halo(it_begin);
