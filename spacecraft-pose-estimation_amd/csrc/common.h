@@ -84,8 +84,9 @@ struct ConvLaunch {
   int32_t nt;            // pixel tiles per wave group processed one after the other on one staged weight chunk
   int32_t groups;        // wave groups (256 threads each) working on different tiles in parallel (1 or 2)
   FastDiv fd_npix, fd_tw, fd_hp, fd_halo_w, fd_tiles_img, fd_tiles_x, fd_nmblk;   // conv_m32: divisions by launch constants
-  uint32_t in_bytes, out_bytes;   // conv_m32p: sizes of the input / output (= residual) tensors when both are < 4 GiB
-                                  // (buffer-addressed producer traffic), else 0 (64-bit global addressing)
+  uint32_t in_bytes, out_bytes;   // sizes of the input / output (= residual) tensors when both are < 4 GiB
+                                  // (buffer-addressed global traffic, conv_pipe_kernel.h: dma16_buf), else 0 (64-bit
+                                  // addressing).  conv_pipe: out_bytes = size of in2 (K-concatenated second input).
   unsigned long long* dbg_buf;  // development: per-workgroup phase cycle sums (dbg & 8), else null
   int32_t dbg;           // development ablation bits (0 in production): 1 skip MFMA loop, 2 skip epilogue, 4 skip input DMA
 };

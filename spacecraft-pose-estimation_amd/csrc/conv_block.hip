@@ -24,6 +24,11 @@ int32_t block_launch(const PackedConv& c1, const PackedConv& c2, const void* in,
   L.in = in; L.w1 = c1.d_w; L.w2 = c2.d_w; L.b1 = c1.d_bias; L.b2 = c2.d_bias; L.out = out;
   L.zero16 = conv_zero_page();
   SCP_REQUIRE(L.zero16, "block: cannot allocate the zero page");
+  {
+    static const char* e = dev_env("SCPOSE_M32_BUF");
+    const size_t bytes = (size_t)N * (c1.cin / 8) * H * W * 16;
+    L.bytes = (bytes < 0xfffffff0ull && !(e && atoi(e) == 0)) ? (uint32_t)bytes : 0;
+  }
   L.N = N; L.H = H; L.W = W;
   L.tiles_x = (W + kBlockTile - 1) / kBlockTile;
   L.tiles_y = (H + kBlockTile - 1) / kBlockTile;

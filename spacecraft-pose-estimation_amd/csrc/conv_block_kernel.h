@@ -36,6 +36,7 @@ struct BlockLaunch {
   const float* b2;
   void* out;             // blocked N x C x H x W
   const void* zero16;
+  uint32_t bytes;        // size of in (= out) when < 4 GiB: buffer-addressed global traffic (conv_pipe_kernel.h), else 0
   int32_t N, H, W;
   int32_t tiles_x, tiles_y, tiles_total, tiles_per_wg, grid;
   FastDiv fd_tiles_img, fd_tiles_x;
@@ -104,12 +105,20 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
   };
   // input tile (20 x 20 halo of the 16 x 16 outputs): one pixel per thread, all planes
   const int hy = tid / 20, hx = tid - hy * 20;
+  const bool buf = p.bytes != 0;
+  const buf_rsrc_t rs_in = make_buf(p.in, p.bytes), rs_out = make_buf(p.out, p.bytes);
   auto issue_x = [&](int t) {
     if (tid < 400) {
       int img, oy0, ox0;
       decode(t, img, oy0, ox0);
       const int iy = oy0 - 2 + hy, ix = ox0 - 2 + hx;
       const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      if (buf) {   // 32-bit lane offset, plane displacement in an SGPR, padding pixels out of range (read as zeros)
+        const uint32_t voff = ok ? (uint32_t)(img * PLANES * HW + iy * p.W + ix) * 16u : BUF_OOB;
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl) dma16_buf(rs_in, voff, (uint32_t)(pl * HW) * 16u, xl + pl * XS + wave * 1024);
+        return;
+      }
       const char* src0 = static_cast<const char*>(p.in) + ((size_t)img * PLANES * HW + (size_t)(ok ? iy * p.W + ix : 0)) * 16;
 #pragma unroll
       for (int pl = 0; pl < PLANES; ++pl) {
@@ -295,7 +304,9 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
       u32x4 ov;
       ov[0] = relu2_16(pack2<T>(v[0], v[1]), 0u); ov[1] = relu2_16(pack2<T>(v[2], v[3]), 0u);
       ov[2] = relu2_16(pack2<T>(v[4], v[5]), 0u); ov[3] = relu2_16(pack2<T>(v[6], v[7]), 0u);
-      if (store_ok)
+      if (buf)
+        store16_buf(rs_out, store_ok ? (uint32_t)((img * PLANES + psel) * HW + oy * p.W + ox) * 16u : BUF_OOB, (uint32_t)(2 * m * HW) * 16u, ov);
+      else if (store_ok)
         *reinterpret_cast<u32x4*>(static_cast<char*>(p.out) + (((size_t)img * PLANES + 2 * m + psel) * HW + (size_t)oy * p.W + ox) * 16) = ov;
     }
     const unsigned long long t6 = now();

@@ -279,6 +279,14 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
     }
     if (2 * conv_pipe_lds_bytes(pc, L.plane_stride, 1) <= 160 * 1024 && pc.mrep * nrep * 4 <= 128) occ = 2;
   }
+  {   // buffer-addressed input DMA when the input tensor(s) fit a 32-bit descriptor
+    static const char* e = dev_env("SCPOSE_M32_BUF");
+    const size_t plane = (size_t)N * H * W * 16;
+    const size_t ib = plane * (in2 ? split_planes : L.cin_planes), ib2 = in2 ? plane * (L.cin_planes - split_planes) : 0;
+    const bool fits = ib < 0xfffffff0ull && ib2 < 0xfffffff0ull && !(e && atoi(e) == 0);
+    L.in_bytes = fits ? (uint32_t)ib : 0;
+    L.out_bytes = fits ? (uint32_t)ib2 : 0;
+  }
   L.cp = pc.cp; L.nchunks = pc.nchunks; L.ksteps_full = pc.ksteps_full;
   L.n_mblk = pc.n_mblk;
   L.relu = relu; L.out_nchw_f32 = out_nchw_f32;

@@ -165,9 +165,12 @@ __global__ __launch_bounds__(256, OCC) void conv_m32_kernel(const ConvLaunch p) 
       decode_tile(it, hs[i], img, oy0, ox0);
       const int iy = oy0 * STRIDE - (KS / 2) + hy[i], ix = ox0 * STRIDE - (KS / 2) + hx[i];
       const bool ok = img >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      xoff[i] = ok ? ((size_t)((p.dbg & 64) ? 0 : img) * p.cin_planes * HW + (size_t)(iy * p.W + ix)) * 16 : ~(size_t)0;
+      // buffer addressing (p.in_bytes != 0): the slot holds a 32-bit offset, BUF_OOB for padding pixels
+      if (p.in_bytes) xoff[i] = ok ? (size_t)((uint32_t)(img * p.cin_planes * HW + iy * p.W + ix) * 16u) : (size_t)BUF_OOB;
+      else xoff[i] = ok ? ((size_t)((p.dbg & 64) ? 0 : img) * p.cin_planes * HW + (size_t)(iy * p.W + ix)) * 16 : ~(size_t)0;
     }
   };
+  const buf_rsrc_t rs_in = make_buf(p.in, p.in_bytes);
   // K-chunks are summed in their natural order in every workgroup.  (A per-workgroup rotated order, meant to
   // spread the weight-chunk reads of lock-stepped CUs over L2, measured no faster and made a frame's result depend
   // on which workgroup computed it, i.e. on its position in the batch.)
@@ -177,6 +180,14 @@ __global__ __launch_bounds__(256, OCC) void conv_m32_kernel(const ConvLaunch p) 
     const int planes = c == p.nchunks - 1 ? planes_last : p.cp;
     const char* inb = static_cast<const char*>(p.in) + (size_t)c * p.cp * HW * 16;
     char* xl = xl0 + xb * p.lds_x;
+    if (p.in_bytes) {   // conv_pipe_kernel.h: dma16_buf (plane displacement in an SGPR, hardware zero fill for padding)
+#pragma unroll
+      for (int i = 0; i < MAXP; ++i)
+        if (hs[i] >= 0)
+          for (int pl = 0; pl < planes; ++pl)
+            dma16_buf(rs_in, (uint32_t)xoff[i], (uint32_t)((c * p.cp + pl) * HW) * 16u, xl + pl * p.plane_stride + (i * 256 + wave * 64) * 16);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
       if (hs[i] >= 0) {

@@ -191,6 +191,21 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
     const char* inb = static_cast<const char*>(second ? p.in2 : p.in) +
                       ((size_t)img * own_planes + (size_t)(c * p.cp - (second ? p.split_planes : 0))) * HW * 16;
     char* xl = xl0 + (grp * 2 + xb) * p.lds_x;
+    if (p.in_bytes) {   // buffer addressing (tensors < 4 GiB): image / chunk / plane displacement in an SGPR, padding out of range
+      const buf_rsrc_t rs = second ? make_buf(p.in2, p.out_bytes) : make_buf(p.in, p.in_bytes);   // out_bytes: size of in2 here
+      const uint32_t sbase = (uint32_t)((img * own_planes + (c * p.cp - (second ? p.split_planes : 0))) * HW) * 16u;
+#pragma unroll
+      for (int i = 0; i < MAXP; ++i) {
+        if (hy[i] >= 0) {
+          const int iy = iy0 + hy[i], ix = ix0 + hx[i];
+          const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+          const uint32_t voff = ok ? (uint32_t)(iy * p.W + ix) * 16u : BUF_OOB;
+          for (int pl = 0; pl < planes; ++pl)
+            dma16_buf(rs, voff, sbase + (uint32_t)(pl * HW) * 16u, xl + pl * p.plane_stride + (i * 256 + wave * 64) * 16);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
       if (hy[i] >= 0) {
