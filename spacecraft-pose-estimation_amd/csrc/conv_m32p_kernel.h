@@ -109,6 +109,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
     // Tensors below 4 GiB are addressed through buffer descriptors (conv_pipe_kernel.h: dma16_buf): per-item 32-bit
     // lane offsets, chunk / plane displacement in an SGPR, padding lanes out of range.  Larger ones keep 64-bit pointers.
     const bool buf = p.in_bytes != 0;
+    const buf_rsrc_t rs_w = make_buf(p.wpk, (uint32_t)(p.n_mblk * p.nchunks * (int)chunk_wbytes));
     const buf_rsrc_t rs_in = make_buf(p.in, p.in_bytes), rs_res = make_buf(p.res ? p.res : p.out, p.out_bytes),
                      rs_out = make_buf(p.out, p.out_bytes);
     size_t xoff[MAXP];
@@ -183,11 +184,11 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
         }
         return;
       }
-      const char* ws = static_cast<const char*>(p.wpk) + ((size_t)(it - fdiv(it, p.fd_nmblk) * p.n_mblk) * p.nchunks + c) * chunk_wbytes;
+      const uint32_t wchunk = (uint32_t)(((it - fdiv(it, p.fd_nmblk) * p.n_mblk) * p.nchunks + c) * (int)chunk_wbytes);
       char* wl = wl0 + wb * p.lds_w;
-      for (int o = 0; o < nbytes; o += 4096) {
+      for (int o = 0; o < nbytes; o += 4096) {   // packed weights are far below 4 GiB: always buffer-addressed
         const int mine = o + ptid * 16;
-        if (mine < nbytes) dma16(ws + mine, wl + o + wave * 1024);
+        if (mine < nbytes) dma16_buf(rs_w, (uint32_t)ptid * 16u, wchunk + (uint32_t)o, wl + o + wave * 1024);
       }
     };
     // byte offset of (image, plane 0, pixel) in out / res for this thread's retire-buffer pixels
