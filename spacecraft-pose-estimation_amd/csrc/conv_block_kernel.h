@@ -77,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
   char* xl = w2l + WBYTES;
   char* ml = xl + PLANES * XS;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA bases / M0
   const int q = lane >> 4, r = lane & 15, half = lane >> 5, psel = q & 1;
   const int HW = p.H * p.W;
   const int tiles_per_img = p.tiles_x * p.tiles_y;

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, OCC) void conv_m32_kernel(const ConvLaunch p) 
   char* wl0 = smem + 1024 + p.lds_bias;
   char* xl0 = wl0 + p.nbuf_w * p.lds_w;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA bases / M0
   const int half = lane >> 5, r = lane & 31;
   const int wm = wave / WN, wn = wave - wm * WN;
   const int HW = p.H * p.W;
@@ -203,11 +203,12 @@ __global__ __launch_bounds__(256, OCC) void conv_m32_kernel(const ConvLaunch p) 
     const int c = cl;
     const int planes = c == p.nchunks - 1 ? planes_last : p.cp;
     const int nbytes = (planes >> 1) * KK * (2 * MT * 16);
-    const char* ws = static_cast<const char*>(p.wpk) + ((size_t)(it - fdiv(it, p.fd_nmblk) * p.n_mblk) * p.nchunks + c) * chunk_wbytes;
+    const buf_rsrc_t rs_w = make_buf(p.wpk, (uint32_t)(p.n_mblk * p.nchunks * (int)chunk_wbytes));   // packed weights: far below 4 GiB
+    const uint32_t wchunk = (uint32_t)(((it - fdiv(it, p.fd_nmblk) * p.n_mblk) * p.nchunks + c) * (int)chunk_wbytes);
     char* wl = wl0 + wb * p.lds_w;
     for (int o = 0; o < nbytes; o += 4096) {
       const int mine = o + tid * 16;
-      if (mine < nbytes) dma16(ws + mine, wl + o + wave * 1024);
+      if (mine < nbytes) dma16_buf(rs_w, (uint32_t)tid * 16u, wchunk + (uint32_t)o, wl + o + wave * 1024);
     }
   };
 

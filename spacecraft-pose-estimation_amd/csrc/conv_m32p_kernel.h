@@ -44,7 +44,8 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
   char* xl0 = wl0 + p.nbuf_w * p.lds_w;
   char* ro = xl0 + 2 * p.lds_x;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: role branch, LDS-DMA bases and M0 values stay scalar
   const bool producer = wave_all >= 4;
   const int wave = wave_all & 3, ptid = tid & 255;
   const int half = lane >> 5, r = lane & 31;

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
   char* xl0 = wl0 + p.nbuf_w * p.lds_w;
 
   const int lane = threadIdx.x & 63;
-  const int wave_all = threadIdx.x >> 6;           // 0 .. 4G-1: weight-chunk DMA is spread over all waves
+  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 .. 4G-1 (scalar): weight-chunk DMA is spread over all waves
   const int grp = wave_all >> 2;                     // this wave's tile group
   const int wave = wave_all & 3, tid = threadIdx.x & 255;   // position inside the group
   const int q = lane >> 4, r = lane & 15;
@@ -225,11 +225,12 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
     const int nbytes = ksteps * (4 * MT * 16);
     const int slice = (((nbytes + nparts - 1) / nparts) + 4096 * G - 1) / (4096 * G) * (4096 * G);   // whole rounds of the workgroup
     const int lo = part * slice, hi = min(nbytes, lo + slice);
-    const char* ws = static_cast<const char*>(p.wpk) + ((size_t)item_mb(it) * p.nchunks + c) * chunk_wbytes;
+    const buf_rsrc_t rs_w = make_buf(p.wpk, (uint32_t)(p.n_mblk * p.nchunks * (int)chunk_wbytes));   // packed weights: far below 4 GiB
+    const uint32_t wchunk = (uint32_t)((item_mb(it) * p.nchunks + c) * (int)chunk_wbytes);
     char* wl = wl0 + wb * p.lds_w;
     for (int o = lo; o < hi; o += 4096 * G) {
       const int mine = o + (int)threadIdx.x * 16;
-      if (mine < hi) dma16(ws + mine, wl + o + wave_all * 1024);
+      if (mine < hi) dma16_buf(rs_w, threadIdx.x * 16u, wchunk + (uint32_t)o, wl + o + wave_all * 1024);
     }
   };
 
