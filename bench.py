@@ -236,6 +236,17 @@ def main():
                      "share_of_forward": round(ms / sum(v[0] for v in prof_ms.values()), 4),
                      "flop_per_byte": round(ai, 1),
                      "also_tflops": round(flops / sec / 1e12, 2), "also_gbs": round(byts / sec / 1e9, 1)})
+        # the next kernel classes by share of the forward, each against its own roofline (same definitions)
+        ridge = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+        others = []
+        total_ms = sum(v[0] for v in prof_ms.values())
+        for k2, (ms2, calls2, fl2, by2) in sorted(prof_ms.items(), key=lambda kv: -kv[1][0])[1:5]:
+            hb = (fl2 / by2 if by2 else float("inf")) < ridge
+            ach = by2 / (ms2 / 1e3) / 1e9 if hb else fl2 / (ms2 / 1e3) / 1e12
+            others.append({"class": "%d:%d:%d:%d" % k2, "share_of_forward": round(ms2 / total_ms, 4), "avg_launch_us": round(ms2 / calls2 * 1e3, 2),
+                           "bound": "hbm" if hb else "mfma", "achieved": round(ach, 1), "unit": "GB/s" if hb else "TFLOP/s",
+                           "frac": round(ach / (HBM_PEAK_GBS if hb else MFMA_PEAK_TFLOPS), 4)})
+        roof["next_classes"] = others      # class = kind:10*ksize+stride|nterms:Cin:Cout (kind 1 conv, 2 fuse sum, 3 fused BasicBlock)
         fwd_ms = sum(v[0] for v in prof_ms.values()) / max(prof_steps, 1)
         cpu = None
         if world == 1 and args.cpu_frames > 0:
