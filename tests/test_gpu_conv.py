@@ -210,3 +210,19 @@ def test_development_switches_need_scpose_dev(gpu_ops):
     assert rel < 1e-2 and "SCPOSE_DEV" not in err
     rel, err = run({"SCPOSE_DBG": "1", "SCPOSE_DEV": "1"})
     assert rel > 0.5 and "SCPOSE_DEV=1" in err
+
+
+def test_conv_64bit_addressing_path(gpu_ops):
+    """Tensors of 4 GiB and more cannot use buffer descriptors and take the 64-bit addressing path of every kernel.
+    That path is forced here with the development switch SCPOSE_M32_BUF=0 and must pass the same parity cases
+    (a sub-process: the switches are read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCPOSE_DEV="1", SCPOSE_M32_BUF="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_conv.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "(test_conv_matches_cpu and bf16) or test_fused_basic_block or equivariant"],
+                       capture_output=True, text=True, env=env, cwd=root, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
