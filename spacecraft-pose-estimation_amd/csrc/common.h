@@ -148,7 +148,7 @@ size_t pack_conv_weights_m32(const float* w, int cout, int cin, int ks, int mt, 
 int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream);   // SCPOSE_E_UNSUPPORTED-free: returns 1 if the shape has no good tiling (caller falls back)
 
 // ---- stem: 3 -> 64, 3x3 stride 2 from f32 NCHW or u8 NHWC ----------------------------------
-int32_t stem_launch(const void* in, int in_fmt, const float* w_folded /*dev [64][27]*/,
+int32_t stem_launch(const void* in, int in_fmt, const float* w_folded /*dev [8][27][8]: channel group, tap, channel*/,
                     const float* bias /*dev [64]*/, const float* mean_std /*dev [6] or null*/,
                     int N, int H, int W, int dtype, void* out, hipStream_t stream);
 

@@ -96,7 +96,7 @@ struct scpose_hrnet {
   scpose_hrnet_desc desc;
   int device = 0;
   std::vector<scpose::PackedConv> convs;
-  float* d_stem_w = nullptr;   // [64][27] folded
+  float* d_stem_w = nullptr;   // folded, [8][27][8] (channel group, tap, channel in group)
   float* d_stem_b = nullptr;   // [64]
   float* d_mean_std = nullptr; // [6]
   float* d_head_bias = nullptr; // [4][16] folded biases of the hrnet_cms heads
@@ -262,7 +262,10 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
     SCP_CHECK_HIP(hipMalloc(&net->d_stem_w, w.size() * 4));
     SCP_CHECK_HIP(hipMalloc(&net->d_stem_b, b.size() * 4));
     SCP_CHECK_HIP(hipMalloc(&net->d_mean_std, 6 * 4));
-    SCP_CHECK_HIP(hipMemcpy(net->d_stem_w, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float> wp(w.size());   // [64][27] -> [8 groups][27][8]: the stem kernel advances channel pairs with packed FMAs
+    for (int o = 0; o < 64; ++o)
+      for (int k = 0; k < 27; ++k) wp[((size_t)(o / 8) * 27 + k) * 8 + o % 8] = w[(size_t)o * 27 + k];
+    SCP_CHECK_HIP(hipMemcpy(net->d_stem_w, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
     SCP_CHECK_HIP(hipMemcpy(net->d_stem_b, b.data(), b.size() * 4, hipMemcpyHostToDevice));
     float ms[6] = {d.mean[0], d.mean[1], d.mean[2], d.std[0], d.std[1], d.std[2]};
     SCP_CHECK_HIP(hipMemcpy(net->d_mean_std, ms, sizeof(ms), hipMemcpyHostToDevice));

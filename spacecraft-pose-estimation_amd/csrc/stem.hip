@@ -7,7 +7,7 @@
 //
 // K = 27 is too thin for MFMA; the layer is 0.13 % of the network's FLOPs and is bound by
 // its 64-channel output write, so it runs on the f32 VALU: one thread per output pixel, all
-// 64 output channels, weights through the scalar cache (wave-uniform addresses -> s_load).
+// 64 output channels (two per packed-f32 FMA), weights through the scalar cache (wave-uniform addresses -> s_load).
 // Output is the blocked [N][8][H/2][W/2][8] 16-bit tensor the MFMA convolutions consume.
 #include "common.h"
 
@@ -30,6 +30,16 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const void* __restrict_
   typedef typename StemDt<DT>::type T;
   const int Ho = H >> 1, Wo = W >> 1;
   const size_t total = (size_t)N * Ho * Wo;
+  // uint8 input: ToTensor + Normalize have only 3 x 256 possible results; every block tabulates them once with the
+  // reference's operations ((u/255 - mean)/std, two IEEE divisions each) instead of dividing 54 times per thread
+  __shared__ float lut[FMT == SCPOSE_IN_U8_NHWC ? 768 : 1];
+  if constexpr (FMT == SCPOSE_IN_U8_NHWC) {
+    for (int e = threadIdx.x; e < 768; e += 256) {
+      const int c = e >> 8;
+      lut[e] = ((float)(e & 255) / 255.0f - mean_std[c]) / mean_std[3 + c];
+    }
+    __syncthreads();
+  }
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= total) return;
   const int ox = (int)(gid % Wo);
@@ -51,9 +61,8 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const void* __restrict_
           if constexpr (FMT == SCPOSE_IN_F32_NCHW) {
             v = static_cast<const float*>(in)[(((size_t)n * 3 + c) * H + iy) * W + ix];
           } else {
-            const float u = (float)static_cast<const uint8_t*>(in)[(((size_t)n * H + iy) * W + ix) * 3 + c];
-            // ToTensor: u/255 ; Normalize: (t - mean)/std   (same op order as torchvision)
-            v = (u / 255.0f - mean_std[c]) / mean_std[3 + c];
+            // ToTensor: u/255 ; Normalize: (t - mean)/std   (same op order as torchvision), tabulated above
+            v = lut[c * 256 + static_cast<const uint8_t*>(in)[(((size_t)n * H + iy) * W + ix) * 3 + c]];
           }
         }
         x[c * 9 + ky * 3 + kx] = v;
@@ -63,17 +72,25 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const void* __restrict_
 
   const size_t plane = (size_t)Ho * Wo;
   char* obase = static_cast<char*>(out) + (((size_t)n * 8) * plane + (size_t)oy * Wo + ox) * 16;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll 1
   for (int cg = 0; cg < 8; ++cg) {
+    // weights of this 8-channel group as [k][8] (hrnet.cpp repacks them): channel pairs are adjacent, so one packed
+    // FMA (v_pk_fma_f32, two f32 lanes per instruction) advances two output channels; per channel the 27 fused
+    // multiply-adds still run in k order from the bias, i.e. the same bits as a scalar fmaf chain
+    const f32x2* wg = reinterpret_cast<const f32x2*>(w + cg * (27 * 8));
+    f32x2 a2[4];
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) a2[jp] = f32x2{bias[cg * 8 + 2 * jp], bias[cg * 8 + 2 * jp + 1]};
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const f32x2 xk = f32x2{x[k], x[k]};
+#pragma unroll
+      for (int jp = 0; jp < 4; ++jp) a2[jp] = __builtin_elementwise_fma(xk, wg[k * 4 + jp], a2[jp]);
+    }
     float acc[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float* wr = w + (cg * 8 + j) * 27;
-      float a = bias[cg * 8 + j];
-#pragma unroll
-      for (int k = 0; k < 27; ++k) a = fmaf(x[k], wr[k], a);
-      acc[j] = fmaxf(a, 0.f);
-    }
+    for (int jp = 0; jp < 4; ++jp) { acc[2 * jp] = fmaxf(a2[jp].x, 0.f); acc[2 * jp + 1] = fmaxf(a2[jp].y, 0.f); }
     uint4 o;
     o.x = (uint32_t)stem_bits<T>(acc[0]) | ((uint32_t)stem_bits<T>(acc[1]) << 16);
     o.y = (uint32_t)stem_bits<T>(acc[2]) | ((uint32_t)stem_bits<T>(acc[3]) << 16);
