@@ -110,7 +110,15 @@ struct PackedConv {
   int mrep;
   int variant = 0;     // 0: 16x16x32 MFMA kernels (conv_pipe / conv_stag), 1: 32x32x16 kernel (conv_m32)
   int wm = 1;          // variant 1: waves along Cout (mt = 32*mrep*wm)
+  // streaming 1x1 kernel (conv1x1.hip): weights [k-step][k-group][cout_pad1][8] and bias in MFMA row order, when eligible
+  void* d_w1 = nullptr;
+  float* d_b1 = nullptr;
+  size_t w1_bytes = 0;
+  int cout_pad1 = 0;
 };
+bool conv1x1_stream_eligible(const PackedConv& pc);
+int32_t conv1x1_stream_launch(const PackedConv& pc, const void* in, int N, int H, int W, const void* res, int relu,
+                              void* out, hipStream_t stream);
 
 // Pick (mrep, cp) for a layer independent of the spatial size; tiles are chosen per launch.
 void choose_mrep_cp(int cin, int cout, int ks, int stride, int* mrep, int* cp);

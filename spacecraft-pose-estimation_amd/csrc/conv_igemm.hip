@@ -170,6 +170,27 @@ int32_t conv_upload(const float* w, const float* bias, int cout, int cin, int ks
         if (co < cout) hb[pos] = bias[co];
       }
   }
+  if (ks == 1 && stride == 1 && cout % 8 == 0 && pc->variant == 0) {   // streaming 1x1 kernel (conv1x1.hip) when the weights fit 64 KB of LDS
+    const int planes = cin / 8, ksteps = (planes + 3) / 4, cpad = (cout + 63) / 64 * 64;
+    const size_t wb = (size_t)ksteps * 4 * cpad * 16;
+    const bool ks_ok = ksteps >= 1 && ksteps <= 4;   // Cin <= 128 (see conv1x1.hip)
+    if (ks_ok && wb <= 64 * 1024) {
+      std::vector<uint16_t> h1(wb / 2);
+      const size_t got = pack_conv_weights(w, cout, cin, 1, cpad, planes, dtype, h1.data(), nullptr, nullptr);
+      SCP_REQUIRE(got == wb, "conv1x1: packed size %zu != %zu", got, wb);
+      std::vector<float> b1(cpad, 0.f);
+      if (bias)
+        for (int pos = 0; pos < cpad; ++pos) {
+          const int co = (pos & ~15) + conv_row_channel(pos & 15);
+          if (co < cout) b1[pos] = bias[co];
+        }
+      SCP_CHECK_HIP(hipMalloc(&pc->d_w1, wb));
+      SCP_CHECK_HIP(hipMalloc(&pc->d_b1, b1.size() * sizeof(float)));
+      SCP_CHECK_HIP(hipMemcpy(pc->d_w1, h1.data(), wb, hipMemcpyHostToDevice));
+      SCP_CHECK_HIP(hipMemcpy(pc->d_b1, b1.data(), b1.size() * sizeof(float), hipMemcpyHostToDevice));
+      pc->w1_bytes = wb; pc->cout_pad1 = cpad;
+    }
+  }
   SCP_REQUIRE(conv_zero_page() != nullptr, "conv: cannot allocate the zero page");  // create-time, not in the launch path
   SCP_CHECK_HIP(hipMalloc(&pc->d_w, pc->wbytes));
   SCP_CHECK_HIP(hipMalloc(&pc->d_bias, hb.size() * sizeof(float)));
@@ -181,7 +202,9 @@ int32_t conv_upload(const float* w, const float* bias, int cout, int cin, int ks
 void conv_free(PackedConv* pc) {
   if (pc->d_w) (void)hipFree(pc->d_w);
   if (pc->d_bias) (void)hipFree(pc->d_bias);
-  pc->d_w = nullptr; pc->d_bias = nullptr;
+  if (pc->d_w1) (void)hipFree(pc->d_w1);
+  if (pc->d_b1) (void)hipFree(pc->d_b1);
+  pc->d_w = nullptr; pc->d_bias = nullptr; pc->d_w1 = nullptr; pc->d_b1 = nullptr;
 }
 
 int plane_stride_for(int stride, int halo_h, int halo_w) {
@@ -216,6 +239,12 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
     SCP_REQUIRE(!out_nchw_f32, "conv m32: float32 NCHW output unsupported");
     L.relu = relu; L.out_nchw_f32 = 0;
     return conv_launch_m32(pc, L, stream);
+  }
+  {   // 1x1 layers whose weights fit LDS: barrier-free streaming kernel (needs buffer-addressable tensors)
+    static const char* e1 = dev_env("SCPOSE_K1_STREAM");
+    const size_t ib = (size_t)N * L.cin_planes * H * W * 16, ob = (size_t)N * (pc.cout / 8) * H * W * 16;
+    if (pc.d_w1 && !in2 && !out_nchw_f32 && ib < 0xfffffff0ull && ob < 0xfffffff0ull && !(e1 && atoi(e1) == 0))
+      return conv1x1_stream_launch(pc, in, N, H, W, res, relu, out, stream);
   }
   int nrep;
   choose_tile(pc.ks, pc.stride, L.Ho, L.Wo, &nrep, &L.th, &L.tw);

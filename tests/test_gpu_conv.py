@@ -226,3 +226,17 @@ def test_conv_64bit_addressing_path(gpu_ops):
                        capture_output=True, text=True, env=env, cwd=root, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("shape", [(32, 400, 1, 64, 24), (64, 256, 1, 96, 32), (96, 48, 1, 48, 64), (128, 64, 1, 32, 64),
+                                   (192, 96, 1, 24, 64), (256, 64, 1, 96, 32), (384, 48, 1, 12, 64), (96, 96, 3, 48, 64)],
+                         ids=lambda s: "c%d-%d_k%d_%d_n%d" % s)
+def test_conv_is_run_to_run_deterministic(gpu_ops, shape):
+    """Four launches on the same input give the same bits (every 1x1 variant -- streaming kernel for Cin <= 128, conv_pipe
+    above -- and one 3x3 layer): no kernel depends on scheduling order or on uninitialised state."""
+    cin, cout, k, H, N = shape
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    conv = gpu_ops.Conv(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, torch.randn(cout, generator=g) * 0.1)
+    x = torch.randn(N, cin // 8, H, H, 8, generator=g).bfloat16().cuda()
+    ys = [conv(x, relu=True) for _ in range(4)]
+    assert all(torch.equal(y, ys[0]) for y in ys[1:])
