@@ -10,7 +10,8 @@
 // ends up with the 8 channels of one (plane, pixel) and stores 16 bytes; residual vectors are fetched the same way.
 // No barriers after the prologue, no LDS traffic besides the weight fragments: the kernel is a pure HBM stream with
 // as many waves in flight as registers allow.  Replaces conv_pipe for the 1x1 layers of layer1 (Bottleneck conv1 /
-// conv3, pose_hrnet.py:78-98) and of the fuse up-paths (:197-208) whose packed weights fit 64 KB.
+// conv3, pose_hrnet.py:78-98), of the fuse up-paths (:197-208) and the tap maps of the hrnet_cms heads, whenever the
+// packed weights fit 64 KB.
 #include <type_traits>
 
 #include "common.h"
@@ -117,6 +118,19 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_stream_kernel(const Conv1Lau
 #pragma unroll
           for (int g = 0; g < NG; ++g) acc[m][g] = c1_mfma<T>(a, b[s][g], acc[m][g]);
         }
+      // All MFMAs of the pass retire before the epilogue touches an accumulator.  hipcc's own wait states in front of
+      // v_permlane32_swap were too short for the 8-pass 16x16x32 MFMA (lanes 12-15 of the last-written registers came
+      // out stale, run-to-run different): 20 explicit wait states, with every accumulator as an operand so that
+      // neither the MFMAs nor the epilogue can be moved across.
+      if constexpr (NG == 4)
+        asm volatile("s_nop 15\n\ts_nop 3"
+                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]),
+                       "+v"(acc[1][2]), "+v"(acc[1][3]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]),
+                       "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3]));
+      else
+        asm volatile("s_nop 15\n\ts_nop 3"
+                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]),
+                       "+v"(acc[3][0]), "+v"(acc[3][1]));
       // ---- epilogue: pair pixel groups (2gp, 2gp+1): lower half-wave keeps group 2gp, upper half-wave group 2gp+1 ----
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -162,11 +176,10 @@ int32_t conv1x1_stream_launch(const PackedConv& pc, const void* in, int N, int H
   L.out_bytes = (uint32_t)((size_t)N * L.cout_planes * L.HW * 16);
   L.w_bytes = (uint32_t)pc.w1_bytes;
   const int ksteps = (L.cin_planes + 3) / 4;
-  // register budget: fragments KSTEPS*NG*4 + accumulators 16*NG + residual vectors 8*NG per lane.  Built for
-  // Cin <= 128 (1-4 k-steps, 64 pixels per wave, 2 workgroups per CU, no scratch).  The Cin = 192 / 256 variants
-  // (32 pixels per wave) were up to 1.4x faster than conv_pipe but not run-to-run deterministic at 96x96 (cause not
-  // found yet), so those layers stay on conv_pipe (conv_igemm.hip: conv_upload only packs for <= 4 k-steps).
-  const int ng = 4;
+  // register budget: fragments KSTEPS*NG*4 + accumulators 16*NG + residual vectors 8*NG per lane: 64 pixels per wave
+  // up to Cin = 128, 32 pixels per wave for Cin = 192 / 256 / 384; two workgroups per CU; every variant is free of
+  // scratch spills.
+  const int ng = ksteps <= 4 ? 4 : 2;
   L.blocks_per_img = (L.HW + 16 * ng - 1) / (16 * ng);
   L.total_blocks = N * L.blocks_per_img;
   const size_t lds = pc.w1_bytes + (size_t)pc.cout_pad1 * 4;
@@ -193,6 +206,9 @@ int32_t conv1x1_stream_launch(const PackedConv& pc, const void* in, int N, int H
     case 2: C1_LAUNCH(2, 4, 2); break;
     case 3: C1_LAUNCH(3, 4, 2); break;
     case 4: C1_LAUNCH(4, 4, 2); break;
+    case 6: C1_LAUNCH(6, 2, 2); break;
+    case 8: C1_LAUNCH(8, 2, 2); break;
+    case 12: C1_LAUNCH(12, 2, 2); break;
     default:
       set_error("conv1x1: %d k-steps unsupported", ksteps);
       return SCPOSE_E_INVALID;
