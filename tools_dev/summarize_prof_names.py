@@ -12,6 +12,9 @@ def demangle(n):
     return n
 
 def short(n):
+    m = re.search(r"conv1x1_stream_kernelI(DF16b|DF16_)Li(\d+)ELi(\d+)ELi(\d+)E", n)     # c++filt does not know DF16b
+    if m:
+        return "conv1x1_stream_kernel<%s,%s,%s,%s>" % ("bf16" if m.group(1) == "DF16b" else "f16", m.group(2), m.group(3), m.group(4))
     n = demangle(n)
     m = re.search(r"(conv_\w+_kernel<[^>]*>)", n)
     if m: return m.group(1).replace(" ", "")
