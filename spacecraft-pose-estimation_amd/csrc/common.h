@@ -118,7 +118,7 @@ struct PackedConv {
 };
 bool conv1x1_stream_eligible(const PackedConv& pc);
 int32_t conv1x1_stream_launch(const PackedConv& pc, const void* in, int N, int H, int W, const void* res, int relu,
-                              void* out, hipStream_t stream);
+                              void* out, hipStream_t stream, const void* in2 = nullptr, int split_planes = 0);
 
 // Pick (mrep, cp) for a layer independent of the spatial size; tiles are chosen per launch.
 void choose_mrep_cp(int cin, int cout, int ks, int stride, int* mrep, int* cp);

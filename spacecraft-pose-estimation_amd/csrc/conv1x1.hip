@@ -22,6 +22,9 @@ namespace scpose {
 
 struct Conv1Launch {
   const void* in; const void* w; const float* bias; const void* res; void* out;
+  const void* in2;          // K-concatenated layer: planes >= split_planes come from this tensor (else null)
+  int32_t split_planes;     // multiple of 4: a k-step never straddles the two tensors
+  uint32_t in2_bytes;
   uint32_t in_bytes, out_bytes, w_bytes;
   int32_t N, HW, cin_planes, cout_planes, cout_pad, relu;
   int32_t blocks_per_img, total_blocks;
@@ -63,6 +66,7 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_stream_kernel(const Conv1Lau
   float* bias_l = reinterpret_cast<float*>(smem + p.w_bytes);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4, psel = q & 1, upper = lane >> 5;
+  const buf_rsrc_t rs_in2 = make_buf(p.in2 ? p.in2 : p.in, p.in2 ? p.in2_bytes : p.in_bytes);
   const buf_rsrc_t rs_w = make_buf(p.w, p.w_bytes), rs_in = make_buf(p.in, p.in_bytes),
                    rs_res = make_buf(p.res ? p.res : p.out, p.out_bytes), rs_out = make_buf(p.out, p.out_bytes);
   for (uint32_t o = 0; o < p.w_bytes; o += 4096)
@@ -76,15 +80,19 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_stream_kernel(const Conv1Lau
     const int img = blk / p.blocks_per_img, p0 = (blk - img * p.blocks_per_img) * PXW;
     // ---- B fragments of this wave's pixels: KSTEPS x NG 16-byte vectors per lane ----
     u32x4 b[KSTEPS][NG];
-    const uint32_t in_img = (uint32_t)(img * p.cin_planes * HW) * 16u;
+    const int planes1 = p.in2 ? p.split_planes : p.cin_planes;           // planes held by the first tensor
+    const uint32_t in_img = (uint32_t)(img * planes1 * HW) * 16u;
+    const uint32_t in2_img = (uint32_t)(img * (p.cin_planes - planes1) * HW) * 16u;
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
       const int plane = 4 * s + q;
+      const bool second = p.in2 && 4 * s >= p.split_planes;              // wave-uniform
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const int pix = p0 + g * 16 + r;
         const bool ok = plane < p.cin_planes && pix < HW;
-        b[s][g] = load16_buf(rs_in, ok ? (uint32_t)(plane * HW + pix) * 16u : BUF_OOB, in_img);
+        if (second) b[s][g] = load16_buf(rs_in2, ok ? (uint32_t)((plane - p.split_planes) * HW + pix) * 16u : BUF_OOB, in2_img);
+        else b[s][g] = load16_buf(rs_in, ok ? (uint32_t)(plane * HW + pix) * 16u : BUF_OOB, in_img);
       }
     }
     // pixel this lane stores for pair gp: group 2*gp + upper, column r
@@ -168,11 +176,13 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_stream_kernel(const Conv1Lau
 bool conv1x1_stream_eligible(const PackedConv& pc) { return pc.d_w1 != nullptr; }
 
 int32_t conv1x1_stream_launch(const PackedConv& pc, const void* in, int N, int H, int W, const void* res, int relu,
-                              void* out, hipStream_t stream) {
+                              void* out, hipStream_t stream, const void* in2, int split_planes) {
   Conv1Launch L;
+  L.in2 = in2; L.split_planes = in2 ? split_planes : 0;
   L.in = in; L.w = pc.d_w1; L.bias = pc.d_b1; L.res = res; L.out = out;
   L.N = N; L.HW = H * W; L.cin_planes = pc.cin / 8; L.cout_planes = pc.cout / 8; L.cout_pad = pc.cout_pad1; L.relu = relu;
-  L.in_bytes = (uint32_t)((size_t)N * L.cin_planes * L.HW * 16);
+  L.in_bytes = (uint32_t)((size_t)N * (in2 ? split_planes : L.cin_planes) * L.HW * 16);
+  L.in2_bytes = in2 ? (uint32_t)((size_t)N * (L.cin_planes - split_planes) * L.HW * 16) : 0;
   L.out_bytes = (uint32_t)((size_t)N * L.cout_planes * L.HW * 16);
   L.w_bytes = (uint32_t)pc.w1_bytes;
   const int ksteps = (L.cin_planes + 3) / 4;

@@ -243,8 +243,8 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
   {   // 1x1 layers whose weights fit LDS: barrier-free streaming kernel (needs buffer-addressable tensors)
     static const char* e1 = dev_env("SCPOSE_K1_STREAM");
     const size_t ib = (size_t)N * L.cin_planes * H * W * 16, ob = (size_t)N * (pc.cout / 8) * H * W * 16;
-    if (pc.d_w1 && !in2 && !out_nchw_f32 && ib < 0xfffffff0ull && ob < 0xfffffff0ull && !(e1 && atoi(e1) == 0))
-      return conv1x1_stream_launch(pc, in, N, H, W, res, relu, out, stream);
+    if (pc.d_w1 && (!in2 || split_planes % 4 == 0) && !out_nchw_f32 && ib < 0xfffffff0ull && ob < 0xfffffff0ull && !(e1 && atoi(e1) == 0))
+      return conv1x1_stream_launch(pc, in, N, H, W, res, relu, out, stream, in2, split_planes);
   }
   int nrep;
   choose_tile(pc.ks, pc.stride, L.Ho, L.Wo, &nrep, &L.th, &L.tw);
