@@ -2,12 +2,18 @@
 """End-to-end poses/s of the HIP HRNet -> decode -> EPnP/RANSAC path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    N>1 either under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (the driver's
+    launch: RANK / LOCAL_RANK / WORLD_SIZE come from the environment) or stand-alone: without WORLD_SIZE in the
+    environment `bench.py --gpus N` starts its N ranks itself as fresh child processes (parallel.spawn_local_ranks,
+    before anything touches the GPU in the parent) and exits non-zero if one of them dies.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): HRNet-W48,
 384x384 synthetic RGB crops, 11 landmarks, 256 frames per GPU per step, bf16 MFMA; weak scaling:
 every rank processes its own contiguous shard of the frame list and the per-rank (R, t,
 status) blocks are all-gathered over RCCL (13 float64 per frame) -- SURVEY.md section 8(e).
+At N = 8 this is BASELINE.json configs[3]: 2048 frames per step, 256 per rank.
+`--events` switches to configs[4] (side line, not the headline): HRNet-W32 256x256 on the f16 MFMA
+kernels, every batch half RGB noise crops and half synthetic event frames.
 
 A step, timed with inputs resident in HBM: uint8 crops -> pose_hrnet forward -> heatmap decode
 -> batched EPnP+RANSAC -> all-gather -> (R, t, status) on the host of rank 0.
@@ -17,12 +23,18 @@ the PnP stage consumes seeded synthetic keypoints (landmarks projected through r
 heatmaps inside the timed region.  Nothing is skipped or cached between steps.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      dominant kernel class, from HIP events recorded around every launch of the
-                timed steps (scpose_hrnet_forward_profiled): algorithmic bytes|flops / time.
+  roofline      dominant kernel class (largest summed time), from HIP events recorded around every
+                launch of the profiled timed steps (scpose_hrnet_forward_profiled).  Algorithmic bytes
+                are the bytes THAT launch has to move (a fused BasicBlock: its input once + its output
+                once), the bound is chosen from flops / those bytes against the ridge, and `frac` is
+                against that bound's peak.  `traffic` (PMC bytes per launch) is reported only when
+                profiles/roofline_traffic.json was measured on the same kernel sources (src_sha).
   cpu_baseline  the CPU oracle (oracle/, a port of the reference path) timed on this host's
                 cores on a bounded sample of the same workload.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -41,6 +53,16 @@ IMAGE = 384
 JOINTS = 11
 
 
+def source_hash():
+    """sha256 over the kernel sources the shipped library is built from; PMC figures measured on other sources are stale."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "spacecraft-pose-estimation_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,6 +73,8 @@ def parse():
     ap.add_argument("--image", type=int, default=None)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--events", action="store_true",
+                    help="BASELINE configs[4] side line: HRNet-W32 256x256, f16 MFMA kernels, mixed RGB + event-frame batch")
     ap.add_argument("--chained", action="store_true",
                     help="feed the PnP stage with the decoded (random-weight) keypoints instead of synthetic ones")
     return ap.parse_args()
@@ -96,6 +120,17 @@ def cpu_baseline(cfg, sd, image, nframes, kp_sample):
 
 def main():
     args = parse()
+    if args.events:
+        args.model, args.dtype = "w32", "f16"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # stand-alone multi-GPU launch: this parent never touches the GPU (device_count() does not initialise HIP)
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d device(s) visible" % (args.gpus, have))
+        import scpose  # noqa: F401
+        from importlib import import_module
+        par = import_module("spacecraft-pose-estimation_amd.parallel")
+        raise SystemExit(par.spawn_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,7 +162,7 @@ def main():
 
     # ---- synthetic inputs, resident in HBM before the timed region (shard = rank's slice) ----
     g = torch.Generator().manual_seed(1000 + rank)
-    frames = torch.randint(0, 256, (B, image, image, 3), generator=g, dtype=torch.uint8).to(dev)
+    frames = (syn.mixed_batch(B, image, g) if args.events else syn.rgb_crops(B, image, g)).to(dev)
     center = torch.full((B, 2), image / 2.0, dtype=torch.float32, device=dev)
     scale = torch.full((B, 2), image / 200.0 * 1.5, dtype=torch.float32, device=dev)
     kp_np, _, _ = syn.keypoints(B, np.random.default_rng(2000 + rank), noise_px=1.0, outlier_frac=0.1)
@@ -207,46 +242,52 @@ def main():
     if rank == 0:
         ok = int((host[:, 12] > 0).sum().item())
         total_frames = world * B * args.steps
-        # ---- roofline of the dominant kernel class (largest summed time over the timed steps) ----
-        key, (ms, calls, flops, byts) = max(prof_ms.items(), key=lambda kv: kv[1][0])
-        kind, a, cin, cout = key
-        kname = {0: "stem_conv1_kernel (3->64 3x3 s2, f32 VALU)", 2: "fuse_sum_kernel (%d terms, C=%d)" % (a, cin),
-                 3: "fused BasicBlock 2 x (3x3 s1 %d->%d) (conv_block_kernel; algorithmic bytes = the unfused 5 tensors)" % (cin, cout)}.get(
-            kind, "conv %dx%d s%d %d->%d (MFMA implicit-GEMM; variant names in profiles/*_kernel_stats.csv)" % (a // 10, a // 10, a % 10, cin, cout))
-        ai = flops / byts if byts else float("inf")
-        hbm_bound = ai < MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
-        sec = ms / 1e3
-        if hbm_bound:
-            roof = {"bound": "hbm", "achieved": round(byts / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
-        else:
-            roof = {"bound": "mfma", "achieved": round(flops / sec / 1e12, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
-        roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-        # HBM bytes per launch from the PMC counters: they need separate rocprofv3 --pmc passes, so the
-        # number is read from the committed summary of those passes (same command, same batch) or null
-        roof["traffic"] = None
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json"))).get("%d:%d:%d:%d" % key)
-            if tr and tr.get("batch") == B and args.dtype == "bf16" and image == 384:
-                roof["traffic"] = tr["fetch_bytes"] + tr["write_bytes"]
-                roof["traffic_unit"] = "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE), %s" % tr["kernel"]
-                roof["algorithmic_bytes_per_launch"] = byts / calls
-        except (OSError, ValueError):
-            pass
-        roof.update({"kernel": kname, "launches": calls, "profiled_steps": prof_steps, "avg_launch_us": round(ms / calls * 1e3, 2),
-                     "share_of_forward": round(ms / sum(v[0] for v in prof_ms.values()), 4),
-                     "flop_per_byte": round(ai, 1),
-                     "also_tflops": round(flops / sec / 1e12, 2), "also_gbs": round(byts / sec / 1e9, 1)})
-        # the next kernel classes by share of the forward, each against its own roofline (same definitions)
-        ridge = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
-        others = []
+        # ---- roofline of the dominant kernel class (largest summed time over the profiled steps) ----
+        ridge = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)     # flop per byte above which the MFMA peak binds
         total_ms = sum(v[0] for v in prof_ms.values())
-        for k2, (ms2, calls2, fl2, by2) in sorted(prof_ms.items(), key=lambda kv: -kv[1][0])[1:5]:
-            hb = (fl2 / by2 if by2 else float("inf")) < ridge
-            ach = by2 / (ms2 / 1e3) / 1e9 if hb else fl2 / (ms2 / 1e3) / 1e12
-            others.append({"class": "%d:%d:%d:%d" % k2, "share_of_forward": round(ms2 / total_ms, 4), "avg_launch_us": round(ms2 / calls2 * 1e3, 2),
-                           "bound": "hbm" if hb else "mfma", "achieved": round(ach, 1), "unit": "GB/s" if hb else "TFLOP/s",
-                           "frac": round(ach / (HBM_PEAK_GBS if hb else MFMA_PEAK_TFLOPS), 4)})
-        roof["next_classes"] = others      # class = kind:10*ksize+stride|nterms:Cin:Cout (kind 1 conv, 2 fuse sum, 3 fused BasicBlock)
+        sha = source_hash()
+        try:
+            traffic_db = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json")))
+        except (OSError, ValueError):
+            traffic_db = {}
+
+        def describe(key, ms, calls, flops, byts):
+            """One kernel class against ITS roofline.  flops / byts: algorithmic work of the profiled launches (bytes =
+            what the launch itself must move: a fused BasicBlock counts its input once + its output once)."""
+            kind, a, cin, cout = key
+            name = {0: "stem_conv1_kernel (3->64 3x3 s2, f32 VALU)", 2: "fuse_sum_kernel (%d terms, C=%d)" % (a, cin),
+                    3: "conv_block_kernel: fused BasicBlock 2 x (3x3 s1 %d->%d), input read once + output written once" % (cin, cout),
+                    4: "head_gather_kernel (k%d s%d, C=%d)" % (a // 10, a % 10, cin)}.get(
+                kind, "conv %dx%d s%d %d->%d (MFMA implicit-GEMM)" % (a // 10, a // 10, a % 10, cin, cout))
+            ai = flops / byts if byts else float("inf")
+            sec = ms / 1e3
+            if ai < ridge:
+                r = {"bound": "hbm", "achieved": round(byts / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+            else:
+                r = {"bound": "mfma", "achieved": round(flops / sec / 1e12, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+            r["frac"] = round(r["achieved"] / r["peak"], 4)
+            # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes; summary committed under
+            # profiles/): only reported when it was measured on exactly these kernel sources, batch, dtype and image
+            r["traffic"] = None
+            tr = traffic_db.get("%d:%d:%d:%d" % key)
+            if tr and tr.get("src_sha") == sha and tr.get("batch") == B and tr.get("dtype") == args.dtype and tr.get("image") == image:
+                r["traffic"] = tr["fetch_bytes"] + tr["write_bytes"]
+                r["traffic_unit"] = "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE), %s" % tr["kernel"]
+            r.update({"class": "%d:%d:%d:%d" % key, "kernel": name, "launches": calls, "avg_launch_us": round(ms / calls * 1e3, 2),
+                      "share_of_forward": round(ms / total_ms, 4), "algorithmic_bytes_per_launch": byts / calls,
+                      "algorithmic_flops_per_launch": flops / calls, "flop_per_byte": round(ai, 1),
+                      "also_tflops": round(flops / sec / 1e12, 2), "also_gbs": round(byts / sec / 1e9, 1)})
+            return r
+
+        ranked = sorted(prof_ms.items(), key=lambda kv: -kv[1][0])
+        roof = describe(ranked[0][0], *ranked[0][1])
+        roof["profiled_steps"] = prof_steps
+        roof["src_sha"] = sha
+        # the next kernel classes by share of the forward, each against its own roofline (same definitions);
+        # class = kind:10*ksize+stride|nterms:Cin:Cout (kind 0 stem, 1 conv, 2 fuse sum, 3 fused BasicBlock, 4 head gather)
+        roof["next_classes"] = [{k: v for k, v in describe(k2, *v2).items()
+                                 if k in ("class", "share_of_forward", "avg_launch_us", "bound", "achieved", "unit", "frac", "traffic")}
+                                for k2, v2 in ranked[1:6]]
         fwd_ms = sum(v[0] for v in prof_ms.values()) / max(prof_steps, 1)
         cpu = None
         if world == 1 and args.cpu_frames > 0:
@@ -259,8 +300,10 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "HRNet-%s %dx%d %d joints, batch %d per GPU + batched EPnP-RANSAC HIP kernel%s" % (
-                           args.model.upper(), image, image, JOINTS, B, " (PnP chained to decoded keypoints)" if args.chained else ""),
+            "config": {"workload": "%sHRNet-%s %dx%d %d joints, batch %d per GPU + batched EPnP-RANSAC HIP kernel%s%s" % (
+                           "BASELINE configs[4] side line: mixed RGB + event-frame batch, " if args.events else "",
+                           args.model.upper(), image, image, JOINTS, B, " (PnP chained to decoded keypoints)" if args.chained else "",
+                           "; %d frames per step frame-sharded over %d GPUs%s" % (world * B, world, " = BASELINE configs[3]" if world * B == 2048 and world == 8 else "") if world > 1 else ""),
                        "frames_per_step": world * B, "parallelism": "frame-sharded x%d, all-gather of (R,t,status); PnP/gather/D2H of step i overlap the forward of step i+1" % world,
                        "pnp_input": "decoded" if args.chained else "synthetic projected landmarks, 1 px noise, 10% outliers",
                        "launches_per_forward": st["launches"], "gflop_per_frame": round(st["flops_per_frame"] / 1e9, 3),

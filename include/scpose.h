@@ -13,9 +13,15 @@
  *     (inputs, outputs, workspace).  The library owns only the opaque handle and the packed
  *     weights it uploads at create time (freed by scpose_hrnet_destroy).
  *   - STREAMS: every launch function takes a hipStream_t as void*; nothing synchronises
- *     internally, nothing allocates in a launch function (hipGraph-capturable).
+ *     internally and nothing allocates in a launch function, with one exception: the first
+ *     launch of a kernel on a device opts that kernel into large LDS (hipFuncSetAttribute) and,
+ *     for 64-bit-addressed tensors, allocates a 256-byte zero page -- both memoised PER DEVICE.
+ *     Run one forward eagerly on a device before capturing launches into a hipGraph there
+ *     (scpose_hrnet_graph_* below does so itself).
  *   - THREADING: a handle is bound to the device current at create time and is not
- *     thread-safe; distinct handles are independent; there is no global mutable state.
+ *     thread-safe; distinct handles are independent.  The only process-wide state is the
+ *     per-device memoisation above (idempotent, indexed by device id) and the thread-local
+ *     error message.
  *   - "blocked" activation layout used between layers: [N][C/8][H][W][8] 16-bit elements
  *     (bf16 or f16), C a multiple of 8.
  */

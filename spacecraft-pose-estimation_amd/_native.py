@@ -10,6 +10,8 @@ from ctypes import (POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_si
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libscpose_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
+if os.environ.get("SCPOSE_DEV") == "1" and os.environ.get("SCPOSE_LIB"):
+    LIB_PATH = os.path.abspath(os.environ["SCPOSE_LIB"])   # development A/B runs of two builds on one box (tools_dev/README.md)
 
 DT_BF16, DT_F16 = 0, 1
 IN_F32_NCHW, IN_U8_NHWC = 0, 1

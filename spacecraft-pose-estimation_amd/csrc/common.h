@@ -34,6 +34,15 @@ const char* last_error();
     }                                     \
   } while (0)
 
+// Kernels that use more than 64 KB of dynamic LDS must be opted in with hipFuncSetAttribute, which applies to the
+// device that is current at the call.  One memo per kernel instantiation, indexed by device: the attribute is set the
+// first time that instantiation is launched on each device (idempotent per-device memoisation like conv_zero_page();
+// never a per-process flag, which would leave a second device of the same process without the opt-in).
+struct LdsOptIn {
+  bool done[16] = {false};
+};
+int32_t lds_opt_in(const void* kernel, int bytes, LdsOptIn* memo);
+
 // Exact unsigned division by a launch-time constant (n < 2^31): q = (mulhi(n, mul) + n*add) >> shift.
 struct FastDiv {
   uint32_t mul, shift, add, d;

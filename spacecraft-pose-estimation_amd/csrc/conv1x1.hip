@@ -202,12 +202,12 @@ int32_t conv1x1_stream_launch(const PackedConv& pc, const void* in, int N, int H
 #define C1_LAUNCH(KS, NGV, OC)                                                                                              \
   do {                                                                                                                  \
     if (bf) {                                                                                                           \
-      static bool set_b = false;                                                                                        \
-      if (!set_b) { SCP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_stream_kernel<__bf16, KS, NGV, OC>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); set_b = true; } \
+      static LdsOptIn set_b;                                                                                            \
+      { const int32_t rc_ = lds_opt_in(reinterpret_cast<const void*>(conv1x1_stream_kernel<__bf16, KS, NGV, OC>), 80 * 1024, &set_b); if (rc_ != SCPOSE_OK) return rc_; } \
       hipLaunchKernelGGL((conv1x1_stream_kernel<__bf16, KS, NGV, OC>), dim3(grid), dim3(256), lds, stream, L);             \
     } else {                                                                                                            \
-      static bool set_f = false;                                                                                        \
-      if (!set_f) { SCP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_stream_kernel<_Float16, KS, NGV, OC>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); set_f = true; } \
+      static LdsOptIn set_f;                                                                                            \
+      { const int32_t rc_ = lds_opt_in(reinterpret_cast<const void*>(conv1x1_stream_kernel<_Float16, KS, NGV, OC>), 80 * 1024, &set_f); if (rc_ != SCPOSE_OK) return rc_; } \
       hipLaunchKernelGGL((conv1x1_stream_kernel<_Float16, KS, NGV, OC>), dim3(grid), dim3(256), lds, stream, L);           \
     }                                                                                                                   \
   } while (0)

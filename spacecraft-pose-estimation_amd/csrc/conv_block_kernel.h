@@ -325,11 +325,8 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
 template <int DT, int MREP>
 int32_t block_launch_one(const BlockLaunch& L, hipStream_t st) {
   auto kern = conv_block_kernel<DT, MREP>;
-  static bool big_lds_enabled = false;
-  if (!big_lds_enabled) {
-    SCP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    big_lds_enabled = true;
-  }
+  static LdsOptIn big_lds;   // per device (common.h)
+  { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(kern), 160 * 1024, &big_lds); if (rc != SCPOSE_OK) return rc; }
   hipLaunchKernelGGL(kern, dim3(L.grid), dim3(512), block_lds_bytes(MREP), st, L);
   SCP_CHECK_HIP(hipGetLastError());
   return SCPOSE_OK;

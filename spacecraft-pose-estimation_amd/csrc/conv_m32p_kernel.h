@@ -349,7 +349,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
           }
         }
         {  // MFMA loop: plane pairs x KK taps, taps unrolled so that every LDS offset is an immediate
-          const int npp = (p.dbg & 1) ? 0 : p.cp >> 1;
+          const int npp = (p.dbg & 1) ? 0 : ((p.dbg & 256) ? 2 : 1) * (p.cp >> 1);   // dbg 256: every stage's MFMA loop twice (timing experiment, wrong results)
           const uint32_t xl = (uint32_t)(size_t)(xl0 + xb * p.lds_x) + half * p.plane_stride;
           const int cidx = c;
           uint32_t wa = (uint32_t)(size_t)(wl0 + (w_resident ? cidx : (wc & 1)) * p.lds_w) + (half * MT + r) * 16;
@@ -495,11 +495,8 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
 template <int DT, int STRIDE, int MR, int NR, int WREG = 0>
 int32_t m32p_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
   auto kern = conv_m32p_kernel<DT, 3, STRIDE, MR, NR, WREG>;
-  static bool big_lds_enabled = false;
-  if (!big_lds_enabled) {
-    SCP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    big_lds_enabled = true;
-  }
+  static LdsOptIn big_lds;   // per device (common.h)
+  { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(kern), 160 * 1024, &big_lds); if (rc != SCPOSE_OK) return rc; }
   hipLaunchKernelGGL(kern, dim3(L.grid), dim3(512), lds, st, L);
   SCP_CHECK_HIP(hipGetLastError());
   return SCPOSE_OK;

@@ -526,11 +526,8 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
 template <int DT, int KS, int STRIDE, int MREP, int NREP, int NT, int OCC, int G = 1>
 int32_t pipe_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
   auto kern = conv_pipe_kernel<DT, KS, STRIDE, MREP, NREP, NT, OCC, G>;
-  static bool big_lds_enabled = false;   // once per instantiation, outside any graph capture
-  if (!big_lds_enabled) {
-    SCP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    big_lds_enabled = true;
-  }
+  static LdsOptIn big_lds;   // per device (common.h)
+  { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(kern), 160 * 1024, &big_lds); if (rc != SCPOSE_OK) return rc; }
   hipLaunchKernelGGL(kern, dim3(L.grid), dim3(256 * G), lds, st, L);
   SCP_CHECK_HIP(hipGetLastError());
   return SCPOSE_OK;

@@ -330,11 +330,8 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvLaunch p) {
 template <int DT, int MREP, int NREP>
 int32_t stag_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
   auto kern = conv_stag_kernel<DT, MREP, NREP>;
-  static bool big_lds_enabled = false;
-  if (!big_lds_enabled) {
-    SCP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    big_lds_enabled = true;
-  }
+  static LdsOptIn big_lds;   // per device (common.h)
+  { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(kern), 160 * 1024, &big_lds); if (rc != SCPOSE_OK) return rc; }
   hipLaunchKernelGGL(kern, dim3(L.grid), dim3(512), lds, st, L);
   SCP_CHECK_HIP(hipGetLastError());
   return SCPOSE_OK;

@@ -106,7 +106,7 @@ struct scpose_hrnet {
   // cached arena plan
   int plan_n = -1, plan_h = -1, plan_w = -1;
   size_t plan_bytes = 0;
-  // per-op HIP events of the last profiled forward (ops.size()+1, created on first use)
+  // per-op HIP events of the last profiled forward (ops.size()+1, created by scpose_hrnet_create)
   std::vector<hipEvent_t> events;
   bool events_valid = false;
 };
@@ -465,10 +465,7 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
   }
   char* base = static_cast<char*>(ws);
   auto ptr = [&](int t) -> void* { return t >= 0 ? base + net->tensors[t].off : nullptr; };
-  if (profile && net->events.empty()) {
-    net->events.resize(net->ops.size() + 1);
-    for (auto& e : net->events) SCP_CHECK_HIP(hipEventCreate(&e));
-  }
+  SCP_REQUIRE(!profile || net->events.size() == net->ops.size() + 1, "hrnet_forward: profiling events missing");
   net->events_valid = false;
   size_t opi = 0;
   for (const Op& op : net->ops) {
@@ -510,7 +507,9 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
 }
 
 // per-op algorithmic work (per frame) and a signature identifying the kernel variant
-static void op_work(const scpose_hrnet* net, const Op& op, int h, int w, double* f, double* by, int32_t sig[4]) {
+// `unfused`: count a fused BasicBlock as SURVEY.md 8(d) counts the unfused pair (5 tensors); otherwise the bytes are the
+// ones the launch itself has to move (block input once + output once), which is what a roofline of that launch needs.
+static void op_work(const scpose_hrnet* net, const Op& op, int h, int w, double* f, double* by, int32_t sig[4], bool unfused = false) {
   *f = 0; *by = 0;
   sig[0] = op.kind; sig[1] = sig[2] = sig[3] = 0;
   if (op.kind == OP_STEM) {
@@ -524,16 +523,16 @@ static void op_work(const scpose_hrnet* net, const Op& op, int h, int w, double*
     const double ho = pc.stride == 2 ? hi / 2 : hi, wo = pc.stride == 2 ? wi / 2 : wi;
     *f = 2.0 * pc.cin * pc.cout * pc.ks * pc.ks * ho * wo;
     *by = pc.cin * hi * wi * 2 + pc.cout * ho * wo * (op.out_f32 ? 4 : 2) + (op.res >= 0 ? pc.cout * ho * wo * 2 : 0);
-    if (op.in2 > 0) *by += 2.0 * pc.cout * ho * wo * 2;   // algorithmic accounting of the unfused pair: the residual tensor written once, read once
+    if (op.in2 > 0 && unfused) *by += 2.0 * pc.cout * ho * wo * 2;   // the unfused pair writes the residual tensor once and reads it once; the K-concatenated launch does neither
     sig[1] = pc.ks * 10 + pc.stride; sig[2] = pc.cin; sig[3] = pc.cout;
   } else if (op.kind == OP_BLOCK) {
-    // algorithmic work of the two convolutions as SURVEY.md 8(d) counts it (conv1 in + out, conv2 in + residual + out),
-    // so that the figures stay comparable with the unfused path; the fused kernel itself moves 2 of those 5 tensors
+    // flops of the two convolutions; bytes: the fused launch reads x once and writes the block output once (the
+    // intermediate tensor and the residual re-read of the unfused pair -- 3 of its 5 tensors -- never touch HBM)
     const PackedConv& pc = net->convs[op.conv];
     const TensorDesc& ti = net->tensors[op.in];
     const double hi = h >> ti.ds, wi = w >> ti.ds;
     *f = 2.0 * 2.0 * pc.cin * pc.cout * 9 * hi * wi;
-    *by = 5.0 * pc.cin * hi * wi * 2;
+    *by = (unfused ? 5.0 : 2.0) * pc.cin * hi * wi * 2;
     sig[1] = 31; sig[2] = pc.cin; sig[3] = pc.cout;
   } else if (op.kind == OP_HEAD) {
     const TensorDesc& ti = net->tensors[op.in];
@@ -553,7 +552,7 @@ void hrnet_stats(scpose_hrnet* net, int h, int w, int* launches, double* flops, 
   double f = 0, by = 0;
   for (const Op& op : net->ops) {
     double of, ob; int32_t sig[4];
-    op_work(net, op, h, w, &of, &ob, sig);
+    op_work(net, op, h, w, &of, &ob, sig, true);   // whole-net figure in SURVEY.md 8(d)'s accounting (422 MB for W48 384^2)
     if (op.kind == OP_STEM) ob -= 3.0 * h * w;   // network input is not an inter-layer activation
     f += of; by += ob;
   }
@@ -568,7 +567,7 @@ void hrnet_free(scpose_hrnet* net) {
   if (net->d_stem_b) (void)hipFree(net->d_stem_b);
   if (net->d_mean_std) (void)hipFree(net->d_mean_std);
   if (net->d_head_bias) (void)hipFree(net->d_head_bias);
-  for (auto& e : net->events) (void)hipEventDestroy(e);
+  for (auto& e : net->events) if (e) (void)hipEventDestroy(e);
   net->events.clear();
 }
 
@@ -613,7 +612,12 @@ extern "C" int32_t scpose_hrnet_create(const scpose_hrnet_desc* desc, const char
   if (!net) { set_error("hrnet_create: out of host memory"); return SCPOSE_E_NOMEM; }
   net->desc = *desc;
   (void)hipGetDevice(&net->device);
-  const int32_t rc = hrnet_build(net, W);
+  int32_t rc = hrnet_build(net, W);
+  if (rc == SCPOSE_OK) {   // per-launch profiling events exist from create on: no launch function allocates anything
+    net->events.assign(net->ops.size() + 1, nullptr);
+    for (auto& e : net->events)
+      if (hipEventCreate(&e) != hipSuccess) { set_error("hrnet_create: hipEventCreate failed"); rc = SCPOSE_E_HIP; break; }
+  }
   if (rc != SCPOSE_OK) { hrnet_free(net); delete net; return rc; }
   *out = net;
   return SCPOSE_OK;

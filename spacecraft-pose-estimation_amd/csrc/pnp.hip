@@ -800,11 +800,8 @@ int32_t pnp_launch(const float* kp_xyc, const double* landmarks, const double* K
   PnpArgs a{kp_xyc, landmarks, K, dist, rot, tvec, rvec, status, N, J, conf_thr0, thr_decay, min_pts, thr_iters,
             max_iters, reproj_err, confidence};
   const size_t lds = (size_t)(144 * 64 + kMaxJ * 9) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    SCP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pnp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  static LdsOptIn big_lds;   // per device (common.h)
+  { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(pnp_kernel), (int)lds, &big_lds); if (rc != SCPOSE_OK) return rc; }
   hipLaunchKernelGGL(pnp_kernel, dim3(N), dim3(64), lds, stream, a);
   SCP_CHECK_HIP(hipGetLastError());
   return SCPOSE_OK;

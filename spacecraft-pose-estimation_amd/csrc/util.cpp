@@ -32,4 +32,13 @@ const char* dev_env(const char* name) {
   return enabled ? getenv(name) : nullptr;
 }
 
+int32_t lds_opt_in(const void* kernel, int bytes, LdsOptIn* memo) {
+  int dev = 0;
+  SCP_CHECK_HIP(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 16 && memo->done[dev]) return SCPOSE_OK;
+  SCP_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  if (dev >= 0 && dev < 16) memo->done[dev] = true;
+  return SCPOSE_OK;
+}
+
 }  // namespace scpose

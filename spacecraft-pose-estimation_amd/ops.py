@@ -210,8 +210,18 @@ def pnp_epnp_ransac(kp_xyc, landmarks, K, dist, conf_thr0=0.95, min_pts=15, thr_
     n, j, _ = kp.shape
     dev = kp.device
     lm = landmarks.contiguous().double()
+    if lm.dim() != 2 or tuple(lm.shape) != (j, 3):
+        raise nat.NativeError("pnp_epnp_ransac: landmarks must be (%d, 3) to match the keypoints, got %s" % (j, tuple(lm.shape)))
     Kd = K.contiguous().double()
-    dd = dist.contiguous().double() if dist is not None else torch.zeros(5, dtype=torch.float64, device=dev)
+    if Kd.numel() != 9:
+        raise nat.NativeError("pnp_epnp_ransac: K must be a 3x3 camera matrix, got %s" % (tuple(K.shape),))
+    # distortion vector: the kernel reads exactly (k1, k2, p1, p2, k3).  cv2 also accepts 4 coefficients (k3 = 0);
+    # the 8/12/14-coefficient rational / thin-prism / tilted models are not implemented and must not be truncated.
+    dd = dist.contiguous().double().reshape(-1) if dist is not None else torch.zeros(5, dtype=torch.float64, device=dev)
+    if dd.numel() == 4:
+        dd = torch.cat([dd, torch.zeros(1, dtype=torch.float64, device=dd.device)])
+    elif dd.numel() != 5:
+        raise nat.NativeError("pnp_epnp_ransac: %d distortion coefficients; supported are 4 or 5 (k1,k2,p1,p2[,k3])" % dd.numel())
     rot = torch.empty((n, 3, 3), dtype=torch.float64, device=dev)
     tv = torch.empty((n, 3), dtype=torch.float64, device=dev)
     rv = torch.empty((n, 3), dtype=torch.float64, device=dev)

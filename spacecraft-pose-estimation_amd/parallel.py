@@ -55,3 +55,56 @@ def gather_rows(local, n_total, dist=None):
     dist.all_gather_into_tensor(out, pad)
     parts = [out[r * maxrows: r * maxrows + (hi - lo)] for r, (lo, hi) in enumerate(sizes)]
     return torch.cat(parts, 0)
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_local_ranks(argv, nprocs, env=None, timeout=None):
+    """Start `nprocs` fresh worker processes `argv` on this node, one per rank (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment: what torch.distributed.run would set), wait for all of
+    them and return the largest exit code.  Rank 0 inherits stdout (it prints the result), the others' stdout is
+    discarded; stderr is inherited.  If a worker dies the rest are terminated and its code is returned.
+
+    The caller must not have touched the GPU: workers are CHILD processes started with subprocess (never an exec of a
+    process that initialised HIP), so `bench.py --gpus N` and `tools/test.py` can launch themselves without torchrun
+    (replaces the in-process torch.nn.DataParallel of landmark_regression/tools/test.py:98)."""
+    import subprocess
+    import time
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(nprocs), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    procs = []
+    for r in range(nprocs):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(list(argv), env=e, stdout=None if r == 0 else subprocess.DEVNULL))
+    t0 = time.time()
+    worst = 0
+    try:
+        alive = set(range(nprocs))
+        while alive:
+            for r in sorted(alive):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                alive.discard(r)
+                if rc != 0:
+                    worst = rc if worst == 0 else worst
+                    for q in alive:
+                        procs[q].terminate()
+            if timeout is not None and time.time() - t0 > timeout:
+                worst = worst or 124
+                for q in alive:
+                    procs[q].terminate()
+                timeout = None
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+            p.wait()
+    return worst

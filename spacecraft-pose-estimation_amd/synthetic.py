@@ -111,3 +111,28 @@ def keypoints(n, rng, noise_px=1.0, outlier_frac=0.0, landmarks=TANGO_LANDMARKS,
         kp[i, :, 2] = 1.0
         rs[i], ts[i] = r, t
     return kp, rs, ts
+
+
+def rgb_crops(n, image, generator):
+    """uint8 (n, H, W, 3) uniform noise crops (SURVEY.md section 8d 'RGB crops')."""
+    return torch.randint(0, 256, (n, image, image, 3), generator=generator, dtype=torch.uint8)
+
+
+def event_frames(n, image, generator, p_one=0.02, p_two=0.01):
+    """uint8 (n, H, W, 3) synthetic v2e event frames (BASELINE.json configs[4]).
+
+    The reference renders accumulated event counts c (all polarities folded to +1, v2e/e2v.py:128-130) as
+    (c + full_scale) / (2 * full_scale) with full_scale = 2 (v2e/v2ecore/renderer.py:247-249), scales by 255, truncates
+    to uint8 and replicates the gray value to three channels (cv2.COLOR_GRAY2BGR, renderer.py:343): a frame holds only
+    the values 127 (no event), 191 (one event) and 255 (two or more).  Here: Bernoulli pixels, p_one at 191, p_two at 255."""
+    u = torch.rand((n, image, image), generator=generator)
+    gray = torch.full((n, image, image), 127, dtype=torch.uint8)
+    gray[u < p_one + p_two] = 191
+    gray[u < p_two] = 255
+    return gray.unsqueeze(-1).expand(n, image, image, 3).contiguous()
+
+
+def mixed_batch(n, image, generator):
+    """First half RGB noise crops, second half event frames: the mixed-modality batch of configs[4]."""
+    n_rgb = n - n // 2
+    return torch.cat([rgb_crops(n_rgb, image, generator), event_frames(n // 2, image, generator)], 0)

@@ -10,6 +10,11 @@ container (it never ships; /root/reference does not exist on the GPU box):
     6x6 solve OpenCV performs (cv2 itself is a third-party wheel absent from the image); covers
     get_max_preds and get_final_preds with POST_PROCESS on and off.
 
+  * lib/core/evaluate.py (accuracy), lib/utils/transforms.py (flip_back), lib/core/loss.py (JointsMSELoss) --
+    imported under the same cv2 stub; the three tensor lines of validate() that turn flip_back's result into the
+    merged heat-map (lib/core/function.py:360-365: SHIFT_HEATMAP column shift, then (output + flipped) * 0.5) are
+    applied to the reference flip_back's output here, since function.py itself needs yacs/json_tricks/torchvision.
+
 Only data is written (npz): no reference source text.  Re-run: python tests/golden/make_golden.py
 """
 import importlib
@@ -92,7 +97,9 @@ def cms_vectors():
     np.savez_compressed(os.path.join(HERE, "hrnet_cms_reference_outputs.npz"), **out)
 
 
-def decode_vectors():
+def install_cv2_stub():
+    if "cv2" in sys.modules:
+        return
     cv2 = types.ModuleType("cv2")
 
     def getAffineTransform(src, dst):
@@ -105,6 +112,10 @@ def decode_vectors():
     cv2.getAffineTransform = getAffineTransform
     sys.modules["cv2"] = cv2
     sys.path.insert(0, os.path.join(REF, "lib"))
+
+
+def decode_vectors():
+    install_cv2_stub()
     inf = importlib.import_module("core.inference")
 
     class Node:
@@ -131,8 +142,61 @@ def decode_vectors():
     print("decode vectors", hm.shape)
 
 
+def host_vectors():
+    """accuracy / flip test / loss: the logging-only and flip-test rows."""
+    install_cv2_stub()
+    ev = importlib.import_module("core.evaluate")
+    tr = importlib.import_module("utils.transforms")
+    ls = importlib.import_module("core.loss")
+    rng = np.random.default_rng(7)
+    out = {}
+    # ---- accuracy (lib/core/evaluate.py:41-71) ----
+    n, j, h, w = 6, 11, 24, 20
+    output = rng.standard_normal((n, j, h, w)).astype(np.float32)
+    target = np.zeros((n, j, h, w), dtype=np.float32)
+    for a in range(n):
+        for b in range(j):
+            y, x = int(rng.integers(0, h)), int(rng.integers(0, w))
+            if b == 3:
+                x = 1            # target x <= 1: joint does not take part
+            if b == 4 and a % 2:
+                y = 0            # some samples of a joint excluded
+            target[a, b, y, x] = 1.0
+            if (a + b) % 3 == 0:  # make some predictions hit exactly / nearly
+                output[a, b, y, min(x + (a % 2), w - 1)] = 10.0
+    target[:, 7] = 0.0             # an all-zero target map: argmax 0 -> coords (0, 0) -> never scored (acc -1)
+    acc, avg, cnt, pred = ev.accuracy(output.copy(), target.copy())
+    out["acc_output"] = output; out["acc_target"] = target
+    out["acc"] = np.asarray(acc, dtype=np.float64); out["acc_avg"] = np.array([avg], dtype=np.float64)
+    out["acc_cnt"] = np.array([cnt], dtype=np.int64); out["acc_pred"] = np.asarray(pred)
+    thr = 0.2
+    acc2, avg2, cnt2, _ = ev.accuracy(output.copy(), target.copy(), thr=thr)   # thr is accepted but the reference ignores it (dist_acc default 0.5)
+    out["acc_thr02"] = np.asarray(acc2, dtype=np.float64)
+    # ---- flip test (lib/utils/transforms.py:15-29 + lib/core/function.py:360-365) ----
+    a = rng.standard_normal((4, j, h, w)).astype(np.float32)
+    b = rng.standard_normal((4, j, h, w)).astype(np.float32)
+    pairs = [[0, 1], [2, 3], [4, 7], [8, 10]]
+    out["flip_a"] = a; out["flip_b"] = b; out["flip_pairs"] = np.array(pairs, dtype=np.int64)
+    fb = tr.flip_back(b.copy(), pairs)
+    out["flip_back"] = np.ascontiguousarray(fb)
+    for shift in (0, 1):
+        of = torch.from_numpy(np.ascontiguousarray(fb).copy())
+        if shift:
+            of[:, :, :, 1:] = of.clone()[:, :, :, 0:-1]          # function.py:361-363
+        out["flip_merged_shift%d" % shift] = ((torch.from_numpy(a) + of) * 0.5).numpy()   # function.py:365
+    # ---- JointsMSELoss (lib/core/loss.py:15-39) ----
+    tw = (rng.random((n, j, 1)) > 0.3).astype(np.float32)
+    out["loss_target_weight"] = tw
+    for use in (0, 1):
+        crit = ls.JointsMSELoss(bool(use))
+        out["loss_use%d" % use] = np.array([crit(torch.from_numpy(output), torch.from_numpy(target), torch.from_numpy(tw)).item()], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "host_reference_outputs.npz"), **out)
+    print("host vectors: acc", acc, "cnt", cnt, "loss", out["loss_use0"], out["loss_use1"])
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     hrnet_vectors()
     cms_vectors()
     decode_vectors()
+    host_vectors()

@@ -45,3 +45,44 @@ def test_two_rank_gather_preserves_frame_order():
         for p in procs:
             p.join(60)
         assert res == [(0, True), (1, True)]
+
+
+_RANK_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, scpose
+from importlib import import_module
+par = import_module("spacecraft-pose-estimation_amd.parallel")
+ws, rank, local = par.world()
+if os.environ.get("FAIL_RANK") == str(rank):
+    sys.exit(7)
+dist = par.init("gloo")
+lo, hi = par.shard_range(2048 // 8 * ws, rank, ws)          # 256 frames per rank (BASELINE configs[3] at ws = 8)
+block = torch.full((hi - lo, 13), float(rank), dtype=torch.float64)
+out = torch.empty((ws * (hi - lo), 13), dtype=torch.float64)
+dist.all_gather_into_tensor(out, block)                     # the exchange bench.py performs per step
+ok = all(float(out[r * (hi - lo), 0]) == r for r in range(ws))
+dist.barrier()
+if rank == 0:
+    print("RESULT", ws, out.shape[0], ok)
+dist.destroy_process_group()
+"""
+
+
+def test_spawn_local_ranks_runs_the_bench_exchange(tmp_path, capfd):
+    """parallel.spawn_local_ranks (what `bench.py --gpus N` uses without torchrun): N fresh child processes with the
+    torchrun environment, rank 0's stdout passed through, exit code 0; a dying rank terminates the job non-zero."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import scpose  # noqa: F401
+    from importlib import import_module
+    par = import_module("spacecraft-pose-estimation_amd.parallel")
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT % ROOT)
+    rc = par.spawn_local_ranks([sys.executable, str(script)], 2, timeout=240)
+    out = capfd.readouterr().out
+    assert rc == 0
+    assert "RESULT 2 512 True" in out
+    env = dict(os.environ, FAIL_RANK="1")
+    rc = par.spawn_local_ranks([sys.executable, str(script)], 2, env=env, timeout=240)
+    assert rc != 0
