@@ -75,6 +75,8 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--events", action="store_true",
                     help="BASELINE configs[4] side line: HRNet-W32 256x256, f16 MFMA kernels, mixed RGB + event-frame batch")
+    ap.add_argument("--graph", type=int, default=1,
+                    help="1: un-profiled steps replay the forward from a hipGraph with concurrent branches (scpose_hrnet_graph_*); 0: eager launches")
     ap.add_argument("--chained", action="store_true",
                     help="feed the PnP stage with the decoded (random-weight) keypoints instead of synthetic ones")
     return ap.parse_args()
@@ -178,6 +180,8 @@ def main():
     gathered = [torch.empty((world * B, 13), dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
     host_buf = [torch.empty((world * B, 13), dtype=torch.float64).pin_memory() for _ in range(2)] if rank == 0 else None
     side = torch.cuda.Stream(device=dev)
+    # captured forward, one graph per output buffer (same kernels, same results; scpose.h: scpose_hrnet_graph_*)
+    graphs = [eng.capture(frames, out=heat[k], concurrent=True) for k in range(2)] if args.graph else None
     done = [None, None]
     counter = [0]
 
@@ -189,7 +193,10 @@ def main():
         main = torch.cuda.current_stream()
         if done[k] is not None:
             main.wait_event(done[k])              # buffers k were last read by the side stream two steps ago
-        eng.forward(frames, out=heat[k], profile=profile)
+        if graphs is not None and not profile:
+            graphs[k].replay()
+        else:
+            eng.forward(frames, out=heat[k], profile=profile)
         fwd_done = torch.cuda.Event()
         fwd_done.record(main)
         with torch.cuda.stream(side):
@@ -306,6 +313,7 @@ def main():
                            "; %d frames per step frame-sharded over %d GPUs%s" % (world * B, world, " = BASELINE configs[3]" if world * B == 2048 and world == 8 else "") if world > 1 else ""),
                        "frames_per_step": world * B, "parallelism": "frame-sharded x%d, all-gather of (R,t,status); PnP/gather/D2H of step i overlap the forward of step i+1" % world,
                        "pnp_input": "decoded" if args.chained else "synthetic projected landmarks, 1 px noise, 10% outliers",
+                       "forward": ("hipGraph replay with concurrent branches (%d nodes); every third step eager with per-launch events" % graphs[0].nodes) if graphs else "eager launches",
                        "launches_per_forward": st["launches"], "gflop_per_frame": round(st["flops_per_frame"] / 1e9, 3),
                        "act_mbytes_per_frame": round(st["act_bytes_per_frame"] / 1e6, 2)},
             "hrnet_forward_ms": round(fwd_ms, 3),

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SCPOSE_ABI_VERSION 2
+#define SCPOSE_ABI_VERSION 3
 
 enum {
   SCPOSE_OK = 0,
@@ -118,6 +118,33 @@ int32_t scpose_hrnet_stats(scpose_hrnet_t h, int32_t height, int32_t width, int3
 int32_t scpose_hrnet_forward(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n,
                              int32_t height, int32_t width, float* heatmaps, void* workspace,
                              size_t workspace_bytes, void* stream);
+
+/* Captured forward.  The launch list of one forward for a FIXED (input buffer, batch shape, heat-map buffer, workspace)
+ * is recorded once into a hipGraph and replayed with one call: for small batches the host-side launch cost of the
+ * ~280 kernels disappears, and with concurrent != 0 the ops that do not depend on each other -- the branches of a
+ * HighResolutionModule (pose_hrnet.py:247-253), the rows of its fuse layer (:254-265), the transition convolutions
+ * (:333-372) -- are recorded on parallel graph branches, so that the small-grid kernels of the low-resolution
+ * branches fill the CUs the high-resolution ones leave idle.  Results are bit-identical to scpose_hrnet_forward.
+ * The concurrent memory plan keeps a tensor alive until every op that may run beside its last reader has finished:
+ * size the workspace with scpose_hrnet_graph_workspace_bytes (>= scpose_hrnet_workspace_bytes).
+ * create runs one eager forward on an internal stream (it needs valid input in `in`) and synchronises it; launch
+ * only enqueues.  The caller refills `in` and reads `heatmaps` in stream order around scpose_hrnet_graph_launch. */
+typedef struct scpose_hrnet_graph* scpose_hrnet_graph_t;
+int32_t scpose_hrnet_graph_workspace_bytes(scpose_hrnet_t h, int32_t n, int32_t height, int32_t width, size_t* bytes);
+int32_t scpose_hrnet_graph_create(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n, int32_t height,
+                                  int32_t width, float* heatmaps, void* workspace, size_t workspace_bytes,
+                                  int32_t concurrent, scpose_hrnet_graph_t* out);
+int32_t scpose_hrnet_graph_launch(scpose_hrnet_graph_t g, void* stream);
+int32_t scpose_hrnet_graph_nodes(scpose_hrnet_graph_t g, int32_t* nodes);   /* kernel + dependency nodes captured */
+int32_t scpose_hrnet_graph_destroy(scpose_hrnet_graph_t g);
+
+/* Unit-level parity hook: runs the forward up to and including the op that produces the named intermediate tensor
+ * and writes it as float32 N x C x h x w (converted from the 16-bit blocked layout).  Names follow the forward of
+ * pose_hrnet.py:425-460: "stem1" (:426-428), "stem2" (:429-431), "layer1" (:432), "stage<S>.<M>.out0" = y_list[0]
+ * after module M of stage S (:247-265).  With out == NULL only *channels / *out_h / *out_w are filled (shape query). */
+int32_t scpose_hrnet_forward_tap(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n, int32_t height,
+                                 int32_t width, const char* tap, float* out, int32_t* channels, int32_t* out_h,
+                                 int32_t* out_w, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Measurement hooks (bench.py): the same forward with a HIP event recorded on `stream` before
  * every launch and after the last one, then per-launch milliseconds, algorithmic FLOPs and

@@ -277,7 +277,9 @@ def forward(sd, cfg, x, emulate=None, taps=None):
     x = tap("stem2", A.conv_bn(x, "conv2", "bn2", 2, relu=True))
     for b in range(4):
         p = "layer1.%d" % b
-        res = A.conv_bn(x, p + ".downsample.0", p + ".downsample.1") if b == 0 else x
+        # storage model: the HIP plan runs the first Bottleneck's downsample 1x1 conv and its conv3 as ONE K-concatenated
+        # convolution (csrc/hrnet.cpp: conv_cat), so that residual is summed in fp32 and never rounded to 16 bits
+        res = A.conv_bn(x, p + ".downsample.0", p + ".downsample.1", store=False) if b == 0 else x
         y = A.conv_bn(x, p + ".conv1", p + ".bn1", relu=True)
         y = A.conv_bn(y, p + ".conv2", p + ".bn2", relu=True)
         x = A.conv_bn(y, p + ".conv3", p + ".bn3", relu=True, residual=res)

@@ -15,7 +15,7 @@ if os.environ.get("SCPOSE_DEV") == "1" and os.environ.get("SCPOSE_LIB"):
 
 DT_BF16, DT_F16 = 0, 1
 IN_F32_NCHW, IN_U8_NHWC = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class HrnetDesc(ctypes.Structure):
@@ -47,6 +47,14 @@ SYMBOLS = {
                                      POINTER(c_double)]),
     "scpose_hrnet_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                        c_void_p, c_size_t, c_void_p]),
+    "scpose_hrnet_graph_workspace_bytes": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_size_t)]),
+    "scpose_hrnet_graph_create": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_size_t,
+                                            c_int32, POINTER(c_void_p)]),
+    "scpose_hrnet_graph_launch": (c_int32, [c_void_p, c_void_p]),
+    "scpose_hrnet_graph_nodes": (c_int32, [c_void_p, POINTER(c_int32)]),
+    "scpose_hrnet_graph_destroy": (c_int32, [c_void_p]),
+    "scpose_hrnet_forward_tap": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_char_p, c_void_p,
+                                           POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), c_void_p, c_size_t, c_void_p]),
     "scpose_hrnet_forward_profiled": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                                 c_void_p, c_size_t, c_void_p]),
     "scpose_hrnet_profile_read": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,

@@ -76,7 +76,6 @@ enum OpKind { OP_STEM = 0, OP_CONV = 1, OP_FUSE = 2, OP_BLOCK = 3, OP_HEAD = 4 }
 struct TensorDesc {
   int C, ds;       // channels, log2 spatial downscale w.r.t. the network input
   int last_use;    // index of the last op reading it
-  size_t off;      // byte offset in the workspace (planned per batch shape)
 };
 
 struct Op {
@@ -88,9 +87,20 @@ struct Op {
   int relu, out_f32;
   int nterms, term[4], shift[4];
   int head;          // OP_HEAD: index into head_bias; in = tap map, res = coarser level (f32) or -1
+  // Concurrency classes for the captured (hipGraph) forward: ops of one epoch on different lanes are independent
+  // (the branches of a HighResolutionModule, pose_hrnet.py:247-253; the fuse rows :254-265; the transition convs
+  // :333-372); epochs are separated by a join of all lanes.  The serial forward ignores both.
+  int epoch, lane;
 };
 
 }  // namespace scpose
+
+// Streams and events of a forward whose independent ops run side by side (only used while capturing a hipGraph).
+struct scpose_hrnet_lanes {
+  hipStream_t side[3] = {nullptr, nullptr, nullptr};   // lanes 1..3 (lane 0 is the stream the forward is launched on)
+  std::vector<hipEvent_t> fork;                         // one per parallel epoch, recorded on lane 0
+  std::vector<hipEvent_t> join;                         // three per parallel epoch, recorded on lanes 1..3
+};
 
 struct scpose_hrnet {
   scpose_hrnet_desc desc;
@@ -103,9 +113,10 @@ struct scpose_hrnet {
   int head_k = 0, head_s = 1;   // transposed-conv kernel / stride of the heads (heat-map = S * branch-0 size)
   std::vector<scpose::TensorDesc> tensors;
   std::vector<scpose::Op> ops;
-  // cached arena plan
-  int plan_n = -1, plan_h = -1, plan_w = -1;
-  size_t plan_bytes = 0;
+  std::vector<std::pair<std::string, int>> taps;   // named intermediate tensors (scpose_hrnet_forward_tap): name -> tensor id
+  // cached arena plans: [0] serial forward (a tensor is released right after its last reader), [1] captured forward
+  // (releases deferred to the end of the epoch, so that ops running side by side never share memory)
+  struct Plan { int n = -1, h = -1, w = -1; size_t bytes = 0; std::vector<size_t> off; } plan[2];
   // per-op HIP events of the last profiled forward (ops.size()+1, created by scpose_hrnet_create)
   std::vector<hipEvent_t> events;
   bool events_valid = false;
@@ -117,9 +128,18 @@ struct Builder {
   scpose_hrnet* net;
   Weights* W;
   int32_t status = SCPOSE_OK;
+  int epoch = 0, lane = 0;        // stamped on every op pushed (see Op::epoch)
+  bool serial = true;             // true: every op opens its own epoch (stem, layer1, heads)
+  void push(Op op) {
+    if (serial) ++epoch;
+    op.epoch = epoch; op.lane = serial ? 0 : lane;
+    net->ops.push_back(op);
+  }
+  void parallel_begin() { ++epoch; serial = false; lane = 0; }   // the ops pushed until parallel_end() share one epoch
+  void parallel_end() { serial = true; lane = 0; }
 
   int new_tensor(int C, int ds) {
-    net->tensors.push_back(TensorDesc{C, ds, -1, 0});
+    net->tensors.push_back(TensorDesc{C, ds, -1});
     return (int)net->tensors.size() - 1;
   }
   // y = [relu](conv_bn(x) [+ res]);  returns output tensor id (or -2 for heatmaps)
@@ -138,7 +158,7 @@ struct Builder {
     op.kind = OP_CONV; op.in = x; op.res = res; op.conv = (int)net->convs.size() - 1;
     op.relu = relu; op.out_f32 = to_heatmaps;
     op.out = to_heatmaps ? -2 : new_tensor(cout, ds);
-    net->ops.push_back(op);
+    push(op);
     return op.out;
   }
   // y = relu(conv_bn_a(xa) + conv_bn_b(xb)), both 1x1: ONE convolution over the concatenated input channels
@@ -169,7 +189,7 @@ struct Builder {
     op.kind = OP_CONV; op.in = xa; op.in2 = xb + 1; op.res = -1; op.conv = (int)net->convs.size() - 1;
     op.relu = relu; op.out_f32 = 0;
     op.out = new_tensor(cout, net->tensors[xa].ds);
-    net->ops.push_back(op);
+    push(op);
     return op.out;
   }
   // BasicBlock relu(conv2(relu(conv1(x))) + x): one fused launch when the pair qualifies, else two convolutions
@@ -182,10 +202,11 @@ struct Builder {
     if (!block_fusable(net->convs[first], net->convs[first + 1])) return t;
     // replace the two ops by one; the intermediate tensor u stays unused (never planned: last_use < 0)
     net->ops.resize(first_op);
+    if (serial) epoch -= 2;   // the two replaced ops' epochs
     Op op{};
     op.kind = OP_BLOCK; op.in = x; op.res = -1; op.conv = (int)first; op.conv2 = (int)first + 1; op.relu = 1;
     op.out = t;
-    net->ops.push_back(op);
+    push(op);
     return t;
   }
   // x_b = Conv2d(32->J,1x1)(ConvTranspose2d(C->32,K,S,p1,op1)(y)) [+ bilinear_x2(prev)]  (hrnet_cms.py:353-368, :551-557)
@@ -225,12 +246,12 @@ struct Builder {
     Op cv{};
     cv.kind = OP_CONV; cv.in = y; cv.res = -1; cv.conv = (int)net->convs.size() - 1;
     cv.out = new_tensor(cout, net->tensors[y].ds);
-    net->ops.push_back(cv);
+    push(cv);
     Op op{};
     op.kind = OP_HEAD; op.in = cv.out; op.res = prev; op.conv = -1; op.head = b;
     // an f32 map of J x (S*h) x (S*w) occupies as many bytes as 2*J*S*S 16-bit channels at the branch resolution
     op.out = to_heatmaps ? -2 : new_tensor(2 * J * S * S, net->tensors[y].ds);
-    net->ops.push_back(op);
+    push(op);
     return op.out;
   }
   int fuse(const std::vector<int>& terms, const std::vector<int>& shifts, int C, int ds) {
@@ -240,7 +261,7 @@ struct Builder {
     op.nterms = (int)terms.size();
     for (int k = 0; k < op.nterms; ++k) { op.term[k] = terms[k]; op.shift[k] = shifts[k]; }
     op.out = new_tensor(C, ds);
-    net->ops.push_back(op);
+    push(op);
     return op.out;
   }
 };
@@ -273,9 +294,11 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
   Op stem{};
   stem.kind = OP_STEM; stem.in = -2; stem.res = -1; stem.conv = -1; stem.relu = 1;
   stem.out = B.new_tensor(64, 1);
-  net->ops.push_back(stem);
+  B.push(stem);
   int x = stem.out;
+  net->taps.emplace_back("stem1", x);
   x = B.conv(x, "conv2", "bn2", 64, 3, 2, true);
+  net->taps.emplace_back("stem2", x);
 
   // ---- layer1: 4 Bottlenecks (64 -> 256) ----
   for (int b = 0; b < 4; ++b) {
@@ -295,6 +318,7 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
     x = nx;
   }
 
+  net->taps.emplace_back("layer1", x);
   std::vector<int> ylist{x};
   std::vector<int> pre{256};
   for (int si = 0; si < 3; ++si) {
@@ -302,7 +326,9 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
     std::vector<int> cur(d.num_channels[si], d.num_channels[si] + nb);
     const std::string tname = fmt("transition%d", si + 1);
     std::vector<int> xs;
+    B.parallel_begin();   // transition convs: independent of each other (lane = branch they create)
     for (int i = 0; i < nb; ++i) {
+      B.lane = i;
       if (i < (int)pre.size()) {
         if (cur[i] != pre[i])
           xs.push_back(B.conv(ylist.back(), fmt("%s.%d.0", tname.c_str(), i), fmt("%s.%d.1", tname.c_str(), i), cur[i], 3, 1, true));
@@ -317,10 +343,13 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
         xs.push_back(t);
       }
     }
+    B.parallel_end();
     for (int m = 0; m < d.num_modules[si]; ++m) {
       const bool multi = d.head != SCPOSE_HEAD_FINAL_LAYER || !(si == 2 && m == d.num_modules[si] - 1);
       const std::string mp = fmt("stage%d.%d", si + 2, m);
+      B.parallel_begin();   // the branches of the module: one lane each
       for (int b = 0; b < nb; ++b) {
+        B.lane = b;
         int t = xs[b];
         for (int k = 0; k < d.num_blocks[si][b]; ++k) {
           const std::string p = fmt("%s.branches.%d.%d", mp.c_str(), b, k);
@@ -328,8 +357,11 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
         }
         xs[b] = t;
       }
+      B.parallel_end();
       std::vector<int> outs;
+      B.parallel_begin();   // the fuse rows: row i (its up / down paths, then its sum) on lane i
       for (int i = 0; i < (multi ? nb : 1); ++i) {
+        B.lane = i;
         std::vector<int> terms, shifts;
         for (int j = 0; j < nb; ++j) {
           const std::string fp = fmt("%s.fuse_layers.%d.%d", mp.c_str(), i, j);
@@ -350,8 +382,10 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
         if (B.status != SCPOSE_OK) break;
         outs.push_back(B.fuse(terms, shifts, cur[i], net->tensors[xs[i]].ds));
       }
+      B.parallel_end();
       xs = outs;
       if (B.status != SCPOSE_OK) break;
+      net->taps.emplace_back(mp + ".out0", xs[0]);
     }
     if (B.status != SCPOSE_OK) break;
     ylist = xs;
@@ -392,9 +426,11 @@ static size_t tensor_bytes(const TensorDesc& t, int n, int h, int w) {
   return (b + 255) & ~(size_t)255;
 }
 
-// Greedy first-fit arena: an output is placed when its producer runs, freed after its last reader.
-size_t hrnet_plan(scpose_hrnet* net, int n, int h, int w) {
-  if (net->plan_n == n && net->plan_h == h && net->plan_w == w) return net->plan_bytes;
+// Greedy first-fit arena: an output is placed when its producer runs and freed after its last reader (mode 0, the
+// serial forward) or at the end of the epoch of its last reader (mode 1, the captured forward whose lanes run side by side).
+size_t hrnet_plan(scpose_hrnet* net, int n, int h, int w, int mode = 0) {
+  scpose_hrnet::Plan& P = net->plan[mode];
+  if (P.n == n && P.h == h && P.w == w) return P.bytes;
   struct Blk { size_t off, size; };
   std::vector<Blk> freel;
   size_t top = 0;
@@ -434,41 +470,80 @@ size_t hrnet_plan(scpose_hrnet* net, int n, int h, int w) {
           }
     }
   };
+  P.off.assign(net->tensors.size(), 0);
+  std::vector<char> released(net->tensors.size(), 0);
+  std::vector<int> pending;   // mode 1: tensors whose last reader ran in the current epoch
+  int cur_epoch = net->ops.empty() ? 0 : net->ops[0].epoch;
   for (size_t i = 0; i < net->ops.size(); ++i) {
     const Op& op = net->ops[i];
-    if (op.out >= 0) net->tensors[op.out].off = alloc(tensor_bytes(net->tensors[op.out], n, h, w));
+    if (mode == 1 && op.epoch != cur_epoch) {
+      for (int t : pending) release(P.off[t], tensor_bytes(net->tensors[t], n, h, w));
+      pending.clear();
+      cur_epoch = op.epoch;
+    }
+    if (op.out >= 0) P.off[op.out] = alloc(tensor_bytes(net->tensors[op.out], n, h, w));
     auto done = [&](int t) {
-      if (t >= 0 && net->tensors[t].last_use == (int)i) {
-        release(net->tensors[t].off, tensor_bytes(net->tensors[t], n, h, w));
-        net->tensors[t].last_use = -100 - (int)i;  // guard against double release (same tensor twice)
+      if (t >= 0 && net->tensors[t].last_use == (int)i && !released[t]) {
+        released[t] = 1;   // guard against double release (same tensor twice in one op)
+        if (mode == 1) pending.push_back(t);
+        else release(P.off[t], tensor_bytes(net->tensors[t], n, h, w));
       }
     };
     done(op.in); done(op.res); done(op.in2 - 1);
     for (int k = 0; k < op.nterms; ++k) done(op.term[k]);
     // an output nobody reads (cannot happen in a well-formed net) is simply never reused
   }
-  // restore last_use for the next plan
-  for (auto& t : net->tensors)
-    if (t.last_use <= -100) t.last_use = -(t.last_use + 100);
-  net->plan_n = n; net->plan_h = h; net->plan_w = w; net->plan_bytes = top;
+  P.n = n; P.h = h; P.w = w; P.bytes = top;
   return top;
 }
 
 int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int h, int w,
-                      float* heatmaps, void* ws, size_t ws_bytes, hipStream_t st, bool profile) {
+                      float* heatmaps, void* ws, size_t ws_bytes, hipStream_t st, bool profile, int stop_tensor = -1,
+                      int mode = 0, const scpose_hrnet_lanes* lanes = nullptr) {
   SCP_REQUIRE(n > 0, "hrnet_forward: batch %d", n);
   SCP_REQUIRE(h % 32 == 0 && w % 32 == 0 && h > 0 && w > 0, "hrnet_forward: H=%d W=%d must be multiples of 32", h, w);
-  const size_t need = hrnet_plan(net, n, h, w);
+  const size_t need = hrnet_plan(net, n, h, w, mode);
   if (ws_bytes < need || !ws) {
     set_error("hrnet_forward: workspace %zu bytes < required %zu", ws_bytes, need);
     return SCPOSE_E_WORKSPACE;
   }
   char* base = static_cast<char*>(ws);
-  auto ptr = [&](int t) -> void* { return t >= 0 ? base + net->tensors[t].off : nullptr; };
+  const std::vector<size_t>& off = net->plan[mode].off;
+  auto ptr = [&](int t) -> void* { return t >= 0 ? base + off[t] : nullptr; };
   SCP_REQUIRE(!profile || net->events.size() == net->ops.size() + 1, "hrnet_forward: profiling events missing");
   net->events_valid = false;
   size_t opi = 0;
-  for (const Op& op : net->ops) {
+  hipStream_t const st0 = st;
+  int cur_epoch = -1, par_index = -1;
+  unsigned open_lanes = 0;   // side lanes forked in the current epoch
+  auto join_lanes = [&]() -> int32_t {
+    for (int l = 1; l < 4; ++l)
+      if (open_lanes & (1u << l)) {
+        hipEvent_t e = lanes->join[(size_t)par_index * 3 + (l - 1)];
+        SCP_CHECK_HIP(hipEventRecord(e, lanes->side[l - 1]));
+        SCP_CHECK_HIP(hipStreamWaitEvent(st0, e, 0));
+      }
+    open_lanes = 0;
+    return SCPOSE_OK;
+  };
+  for (size_t oi = 0; oi < net->ops.size(); ++oi) {
+    const Op& op = net->ops[oi];
+    if (lanes && op.epoch != cur_epoch) {   // epoch boundary: join the lanes of the previous epoch, fork those of this one
+      { const int32_t rc = join_lanes(); if (rc != SCPOSE_OK) return rc; }
+      cur_epoch = op.epoch;
+      unsigned used = 0;
+      for (size_t k = oi; k < net->ops.size() && net->ops[k].epoch == cur_epoch; ++k) used |= 1u << net->ops[k].lane;
+      used &= ~1u;
+      if (used) {
+        ++par_index;
+        SCP_REQUIRE((size_t)par_index < lanes->fork.size(), "hrnet_forward: lane events missing");
+        SCP_CHECK_HIP(hipEventRecord(lanes->fork[par_index], st0));
+        for (int l = 1; l < 4; ++l)
+          if (used & (1u << l)) SCP_CHECK_HIP(hipStreamWaitEvent(lanes->side[l - 1], lanes->fork[par_index], 0));
+        open_lanes = used;
+      }
+    }
+    st = (lanes && op.lane > 0) ? lanes->side[op.lane - 1] : st0;
     if (profile) SCP_CHECK_HIP(hipEventRecord(net->events[opi], st));
     ++opi;
     int32_t rc = SCPOSE_OK;
@@ -498,7 +573,10 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
                            net->desc.dtype, ptr(op.out), st);
     }
     if (rc != SCPOSE_OK) return rc;
+    if (stop_tensor >= 0 && op.out == stop_tensor) break;   // scpose_hrnet_forward_tap: the tensor is still intact in the arena
   }
+  if (lanes) { const int32_t rc = join_lanes(); if (rc != SCPOSE_OK) return rc; }
+  st = st0;
   if (profile) {
     SCP_CHECK_HIP(hipEventRecord(net->events[opi], st));
     net->events_valid = true;
@@ -663,6 +741,113 @@ extern "C" int32_t scpose_hrnet_forward(scpose_hrnet_t h, const void* in, int32_
   SCP_REQUIRE(h && in && heatmaps, "hrnet_forward: null argument");
   return hrnet_forward(h, in, in_fmt, n, height, width, heatmaps, workspace, workspace_bytes,
                        static_cast<hipStream_t>(stream), false);
+}
+
+struct scpose_hrnet_graph {
+  scpose_hrnet* net = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  hipStream_t cap = nullptr;
+  scpose_hrnet_lanes lanes;
+  int nodes = 0;
+};
+
+static void graph_free(scpose_hrnet_graph* g) {
+  if (!g) return;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  for (auto& e : g->lanes.fork) if (e) (void)hipEventDestroy(e);
+  for (auto& e : g->lanes.join) if (e) (void)hipEventDestroy(e);
+  for (auto& st : g->lanes.side) if (st) (void)hipStreamDestroy(st);
+  if (g->cap) (void)hipStreamDestroy(g->cap);
+  delete g;
+}
+
+extern "C" int32_t scpose_hrnet_graph_workspace_bytes(scpose_hrnet_t h, int32_t n, int32_t height, int32_t width, size_t* bytes) {
+  SCP_REQUIRE(h && bytes, "hrnet_graph_workspace_bytes: null argument");
+  SCP_REQUIRE(n > 0 && height > 0 && width > 0 && height % 32 == 0 && width % 32 == 0,
+              "hrnet_graph_workspace_bytes: n=%d H=%d W=%d (H, W multiples of 32)", n, height, width);
+  *bytes = hrnet_plan(h, n, height, width, 1);
+  return SCPOSE_OK;
+}
+
+extern "C" int32_t scpose_hrnet_graph_create(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n, int32_t height,
+                                             int32_t width, float* heatmaps, void* workspace, size_t workspace_bytes,
+                                             int32_t concurrent, scpose_hrnet_graph_t* out) {
+  SCP_REQUIRE(h && in && heatmaps && workspace && out, "hrnet_graph_create: null argument");
+  scpose_hrnet_graph* g = new (std::nothrow) scpose_hrnet_graph();
+  if (!g) { set_error("hrnet_graph_create: out of host memory"); return SCPOSE_E_NOMEM; }
+  g->net = h;
+  auto fail = [&](int32_t rc) { graph_free(g); return rc; };
+#define GC(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return fail(SCPOSE_E_HIP); } } while (0)
+  GC(hipStreamCreateWithFlags(&g->cap, hipStreamNonBlocking));
+  if (concurrent) {
+    int npar = 0, last = -1;
+    for (const Op& op : h->ops) if (op.lane > 0 && op.epoch != last) { ++npar; last = op.epoch; }
+    for (auto& st : g->lanes.side) GC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    g->lanes.fork.assign(npar, nullptr);
+    g->lanes.join.assign((size_t)npar * 3, nullptr);
+    for (auto& e : g->lanes.fork) GC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : g->lanes.join) GC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  // one eager forward on this device first: per-device kernel attributes, zero page and tile tables exist before capture
+  int32_t rc = hrnet_forward(h, in, in_fmt, n, height, width, heatmaps, workspace, workspace_bytes, g->cap, false, -1, 1, nullptr);
+  if (rc != SCPOSE_OK) return fail(rc);
+  GC(hipStreamSynchronize(g->cap));
+  GC(hipStreamBeginCapture(g->cap, hipStreamCaptureModeThreadLocal));
+  rc = hrnet_forward(h, in, in_fmt, n, height, width, heatmaps, workspace, workspace_bytes, g->cap, false, -1, 1,
+                     concurrent ? &g->lanes : nullptr);
+  const hipError_t ce = hipStreamEndCapture(g->cap, &g->graph);
+  if (rc != SCPOSE_OK) return fail(rc);
+  if (ce != hipSuccess) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ce)); return fail(SCPOSE_E_HIP); }
+  GC(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
+  size_t nn = 0;
+  if (hipGraphGetNodes(g->graph, nullptr, &nn) == hipSuccess) g->nodes = (int)nn;
+#undef GC
+  *out = g;
+  return SCPOSE_OK;
+}
+
+extern "C" int32_t scpose_hrnet_graph_launch(scpose_hrnet_graph_t g, void* stream) {
+  SCP_REQUIRE(g && g->exec, "hrnet_graph_launch: null graph");
+  SCP_CHECK_HIP(hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream)));
+  return SCPOSE_OK;
+}
+
+extern "C" int32_t scpose_hrnet_graph_nodes(scpose_hrnet_graph_t g, int32_t* nodes) {
+  SCP_REQUIRE(g && nodes, "hrnet_graph_nodes: null argument");
+  *nodes = g->nodes;
+  return SCPOSE_OK;
+}
+
+extern "C" int32_t scpose_hrnet_graph_destroy(scpose_hrnet_graph_t g) {
+  graph_free(g);
+  return SCPOSE_OK;
+}
+
+extern "C" int32_t scpose_hrnet_forward_tap(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n, int32_t height,
+                                            int32_t width, const char* tap, float* out, int32_t* channels, int32_t* out_h,
+                                            int32_t* out_w, void* workspace, size_t workspace_bytes, void* stream) {
+  SCP_REQUIRE(h && tap, "hrnet_forward_tap: null argument");
+  int tid = -1;
+  for (const auto& t : h->taps) if (t.first == tap) tid = t.second;
+  if (tid < 0) {
+    std::string names;
+    for (const auto& t : h->taps) names += (names.empty() ? "" : ", ") + t.first;
+    set_error("hrnet_forward_tap: unknown tap '%s' (available: %s)", tap, names.c_str());
+    return SCPOSE_E_INVALID;
+  }
+  const TensorDesc& td = h->tensors[tid];
+  if (channels) *channels = td.C;
+  if (out_h) *out_h = height >> td.ds;
+  if (out_w) *out_w = width >> td.ds;
+  if (!out) return SCPOSE_OK;   // shape query
+  SCP_REQUIRE(in, "hrnet_forward_tap: null input");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int32_t rc = hrnet_forward(h, in, in_fmt, n, height, width, nullptr, workspace, workspace_bytes, st, false, tid);
+  if (rc != SCPOSE_OK) return rc;
+  return blocked_to_nchw_launch(static_cast<const char*>(workspace) + h->plan[0].off[tid], n, td.C, height >> td.ds, width >> td.ds,
+                                h->desc.dtype, out, st);
 }
 
 extern "C" int32_t scpose_hrnet_forward_profiled(scpose_hrnet_t h, const void* in, int32_t in_fmt,

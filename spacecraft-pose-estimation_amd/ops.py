@@ -337,6 +337,54 @@ class HrnetEngine:
         self._last_hw = (h, w)
         return out
 
+    def capture(self, x, out=None, concurrent=True):
+        """Record the forward of the input BUFFER x (uint8 NHWC or float32 NCHW, fixed shape) into a hipGraph and return
+        an HrnetGraph: refill x in place (x.copy_(...)), call .replay(), read .out.  concurrent=True records the
+        independent ops (module branches, fuse rows, transition convs) on parallel graph branches."""
+        _need_cuda(x)
+        if not x.is_contiguous():
+            raise nat.NativeError("capture: the input buffer must be contiguous (it is bound by address)")
+        if x.dtype == torch.uint8:
+            n, h, w, c = x.shape
+            fmt = nat.IN_U8_NHWC
+        elif x.dtype == torch.float32:
+            n, c, h, w = x.shape
+            fmt = nat.IN_F32_NCHW
+        else:
+            raise nat.NativeError("capture: input must be uint8 NHWC or float32 NCHW")
+        if c != 3:
+            raise nat.NativeError("HRNet input must have 3 channels, got %d" % c)
+        oh, ow = self.heatmap_size(h, w)
+        if out is None:
+            out = torch.empty((n, self.num_joints, oh, ow), dtype=torch.float32, device=x.device)
+        elif tuple(out.shape) != (n, self.num_joints, oh, ow) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise nat.NativeError("capture: out must be contiguous float32 %s" % ((n, self.num_joints, oh, ow),))
+        return HrnetGraph(self, x, fmt, (n, h, w), out, concurrent)
+
+    def forward_tap(self, x, tap):
+        """Intermediate tensor `tap` ("stem1", "stem2", "layer1", "stage3.1.out0", ...) of the forward of x as float32
+        (N, C, h, w): the forward is run up to the op that produces it (unit-level parity against the oracle's taps)."""
+        _need_cuda(x)
+        x = x.contiguous()
+        if x.dtype == torch.uint8:
+            n, h, w, _ = x.shape
+            fmt = nat.IN_U8_NHWC
+        else:
+            x = x.float()
+            n, _, h, w = x.shape
+            fmt = nat.IN_F32_NCHW
+        need = self.workspace_bytes(n, h, w)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        c = c_int32(); oh = c_int32(); ow = c_int32()
+        fn = nat.lib().scpose_hrnet_forward_tap
+        nat.check(fn(self._h, None, fmt, n, h, w, tap.encode(), None, ctypes.byref(c), ctypes.byref(oh), ctypes.byref(ow), None, 0, None),
+                  "hrnet_forward_tap")
+        out = torch.empty((n, c.value, oh.value, ow.value), dtype=torch.float32, device=x.device)
+        nat.check(fn(self._h, _ptr(x), fmt, n, h, w, tap.encode(), _ptr(out), None, None, None, _ptr(self._ws), self._ws.numel(), _stream()),
+                  "hrnet_forward_tap")
+        return out
+
     def profile_read(self):
         """Per-launch records of the last profiled forward: list of dicts
         {ms, flops_per_frame, bytes_per_frame, kind, a, cin, cout}."""
@@ -358,6 +406,42 @@ class HrnetEngine:
             nat.lib().scpose_hrnet_destroy(self._h)
             self._h = None
         self._ws = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HrnetGraph:
+    """A captured forward (scpose_hrnet_graph_*): fixed input / output / workspace buffers, one launch per replay."""
+
+    def __init__(self, engine, x, fmt, nhw, out, concurrent):
+        n, h, w = nhw
+        b = c_size_t()
+        nat.check(nat.lib().scpose_hrnet_graph_workspace_bytes(engine._h, n, h, w, ctypes.byref(b)), "hrnet_graph_workspace_bytes")
+        self.engine, self.x, self.out = engine, x, out
+        self._ws = torch.empty(b.value, dtype=torch.uint8, device=x.device)       # owned by the graph: addresses are baked in
+        torch.cuda.current_stream().synchronize()                                  # x must be valid: create runs one eager forward
+        g = c_void_p()
+        with torch.cuda.device(x.device):
+            nat.check(nat.lib().scpose_hrnet_graph_create(engine._h, _ptr(x), fmt, n, h, w, _ptr(out), _ptr(self._ws), self._ws.numel(),
+                                                          int(bool(concurrent)), ctypes.byref(g)), "hrnet_graph_create")
+        self._g = g
+        k = c_int32()
+        nat.check(nat.lib().scpose_hrnet_graph_nodes(self._g, ctypes.byref(k)), "hrnet_graph_nodes")
+        self.nodes = k.value
+
+    def replay(self):
+        """Enqueue the captured forward on the current stream; returns the (bound) heat-map buffer."""
+        nat.check(nat.lib().scpose_hrnet_graph_launch(self._g, _stream()), "hrnet_graph_launch")
+        return self.out
+
+    def close(self):
+        if getattr(self, "_g", None):
+            nat.lib().scpose_hrnet_graph_destroy(self._g)
+            self._g = None
 
     def __del__(self):
         try:

@@ -44,14 +44,14 @@ def test_module_api_matches_oracle(pk):
         y = model(x.cuda())
         ref = R.forward(sd, cfg, x, emulate="bf16")
     assert y.shape == (3, 11, 16, 16) and y.dtype == torch.float32 and y.is_cuda
-    assert ((y.cpu() - ref).norm() / ref.norm()).item() < 1.5e-2
+    assert ((y.cpu() - ref).norm() / ref.norm()).item() < 1.3e-2
     # parameters changed -> engine re-packed, result follows
     sd2 = R.make_state_dict(cfg, seed=13)
     model.load_state_dict(sd2)
     with torch.no_grad():
         y2 = model(x.cuda())
         ref2 = R.forward(sd2, cfg, x, emulate="bf16")
-    assert ((y2.cpu() - ref2).norm() / ref2.norm()).item() < 1.5e-2
+    assert ((y2.cpu() - ref2).norm() / ref2.norm()).item() < 1.3e-2
     model.train()
     with pytest.raises(RuntimeError, match="inference-only"):
         model(x.cuda())
@@ -71,15 +71,16 @@ def test_inference_numpy_signatures(pk):
     assert np.array_equal(coords, rc) and np.array_equal(mv, rmv)
 
 
-def test_margin_gated_keypoint_parity_w32(pk):
-    cfg = R.w32_cfg(11, 128)
+@pytest.mark.parametrize("model,size,n", [("w32", 128, 8), ("w48", 384, 4)])     # w48 384x384: BASELINE configs[2] geometry
+def test_margin_gated_keypoint_parity(pk, model, size, n):
+    cfg = R.w32_cfg(11, size) if model == "w32" else R.w48_cfg(11, size)
     sd = R.make_state_dict(cfg, seed=21)
-    x = torch.randn(8, 3, 128, 128, generator=torch.Generator().manual_seed(22))
+    x = torch.randn(n, 3, size, size, generator=torch.Generator().manual_seed(22))
     eng = pk.ops.HrnetEngine(cfg, sd)
     hm_gpu = eng(x.cuda())
     with torch.no_grad():
         hm_ref = R.forward(sd, cfg, x)
-    c = torch.full((8, 2), 700.0); s = torch.full((8, 2), 1.3)
+    c = torch.full((n, 2), 700.0); s = torch.full((n, 2), 1.3)
     kp_gpu = pk.ops.decode(hm_gpu, c.cuda(), s.cuda(), True).cpu().numpy()
     kp_ref = D.decode_xyc(True, hm_ref.numpy(), c.numpy(), s.numpy())
     dev = (hm_gpu.cpu() - hm_ref).abs().flatten(2).amax(2).numpy()               # (N,J) max |bf16 deviation| per map
@@ -96,9 +97,10 @@ def test_margin_gated_keypoint_parity_w32(pk):
                 dy = hr[n, j, py + 1, px] - hr[n, j, py - 1, px]
                 stable[n, j] &= abs(dx) > 2 * dev[n, j] and abs(dy) > 2 * dev[n, j]
     err = np.linalg.norm(kp_gpu[:, :, :2] - kp_ref[:, :, :2], axis=2)
-    step = 1.3 * 200 / 32
+    step = 1.3 * 200 / (size // 4)
     print("stable joints %d/%d, max err on stable %.3f px (one heatmap px = %.2f image px)" % (stable.sum(), stable.size, err[stable].max() if stable.any() else 0, step))
-    assert stable.sum() >= stable.size // 4
+    # random-init heat-maps are flat: on 96x96 maps (w48, 384 px) only ~1 joint in 7 has a provably stable argmax
+    assert stable.sum() >= (stable.size // 4 if model == "w32" else 4)
     assert (err[stable] <= 0.5).all()
     eng.close()
 

@@ -1,0 +1,37 @@
+"""Eager vs captured (hipGraph) vs captured + concurrent-branch forward: python tools_dev/time_graph.py [w48|w32] [N] [size] [dtype]"""
+import _dev  # noqa: F401
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, scpose
+from importlib import import_module
+ops = import_module("spacecraft-pose-estimation_amd.ops")
+from oracle import hrnet_ref as R
+
+which = sys.argv[1] if len(sys.argv) > 1 else "w32"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+size = int(sys.argv[3]) if len(sys.argv) > 3 else (384 if which == "w48" else 256)
+dtype = sys.argv[4] if len(sys.argv) > 4 else "bf16"
+cfg = R.w48_cfg() if which == "w48" else R.w32_cfg()
+sd = R.make_state_dict(cfg, seed=0)
+eng = ops.HrnetEngine(cfg, sd, dtype=dtype)
+x = torch.randint(0, 256, (n, size, size, 3), dtype=torch.uint8, device="cuda")
+
+
+def bench(fn, iters=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(iters): fn()
+    torch.cuda.synchronize()
+    return (time.time() - t) / iters * 1e3
+
+
+ref = eng(x).clone()
+print("%s N=%d %dx%d %s" % (which, n, size, size, dtype))
+print("  eager               %.3f ms" % bench(lambda: eng(x)))
+for conc in (False, True):
+    g = eng.capture(x, concurrent=conc)
+    ms = bench(g.replay)
+    print("  graph%s %.3f ms  (%d nodes, bit-identical: %s, workspace %.2f GB vs %.2f GB)" % (
+        " + concurrent" if conc else "             ", ms, g.nodes, torch.equal(g.replay(), ref), g._ws.numel() / 1e9, eng.workspace_bytes(n, size, size) / 1e9))
+    g.close()
