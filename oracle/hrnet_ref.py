@@ -272,8 +272,9 @@ def forward(sd, cfg, x, emulate=None, taps=None):
         return t
 
     x = x.float()
-    # the HIP stem (csrc/stem.hip) runs conv1 in f32 on the unrounded input and folded weights
-    x = tap("stem1", A.conv_bn(x, "conv1", "bn1", 2, relu=True, round_w=False))
+    # the HIP stem (csrc/stem_fused.hip) runs conv1 on MFMA like every other layer: the normalised input and the folded
+    # weights are rounded to the 16-bit operand type, the sum is fp32, the stored result is rounded
+    x = tap("stem1", A.conv_bn(A.rnd(x), "conv1", "bn1", 2, relu=True))
     x = tap("stem2", A.conv_bn(x, "conv2", "bn2", 2, relu=True))
     for b in range(4):
         p = "layer1.%d" % b

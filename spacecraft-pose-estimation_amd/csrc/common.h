@@ -169,6 +169,12 @@ int32_t stem_launch(const void* in, int in_fmt, const float* w_folded /*dev [8][
                     const float* bias /*dev [64]*/, const float* mean_std /*dev [6] or null*/,
                     int N, int H, int W, int dtype, void* out, hipStream_t stream);
 
+// fused stem (stem_fused.hip): conv1 + bn1 + relu + conv2 + bn2 + relu in one launch, both on MFMA
+void stem_fused_pack(const float* w1, const float* b1, const float* w2, const float* b2, int dtype, std::vector<uint16_t>* pw1,
+                     std::vector<uint16_t>* pw2, std::vector<float>* pb1, std::vector<float>* pb2);
+int32_t stem_fused_launch(const void* in, int in_fmt, const void* w1, const void* w2, const float* b1, const float* b2,
+                          const float* mean_std, int N, int H, int W, int dtype, void* out, hipStream_t stream);
+
 // ---- elementwise ---------------------------------------------------------------------------
 int32_t fuse_sum_launch(const void* const* terms, const int32_t* shifts, int nterms, int N, int C,
                         int H, int W, int dtype, void* out, hipStream_t stream);

@@ -71,7 +71,7 @@ static bool fold(Weights& W, const std::string& conv, const std::string& bn, int
   return true;
 }
 
-enum OpKind { OP_STEM = 0, OP_CONV = 1, OP_FUSE = 2, OP_BLOCK = 3, OP_HEAD = 4 };   // OP_BLOCK: fused BasicBlock (conv_block_kernel.h); OP_HEAD: head.hip
+enum OpKind { OP_STEM = 0, OP_CONV = 1, OP_FUSE = 2, OP_BLOCK = 3, OP_HEAD = 4, OP_STEM2 = 5 };   // OP_STEM2: fused stem (stem_fused.hip)   // OP_BLOCK: fused BasicBlock (conv_block_kernel.h); OP_HEAD: head.hip
 
 struct TensorDesc {
   int C, ds;       // channels, log2 spatial downscale w.r.t. the network input
@@ -109,6 +109,10 @@ struct scpose_hrnet {
   float* d_stem_w = nullptr;   // folded, [8][27][8] (channel group, tap, channel in group)
   float* d_stem_b = nullptr;   // [64]
   float* d_mean_std = nullptr; // [6]
+  void* d_stemf_w1 = nullptr;  // fused stem (stem_fused.hip): packed conv1 / conv2 weights and biases
+  void* d_stemf_w2 = nullptr;
+  float* d_stemf_b1 = nullptr;
+  float* d_stemf_b2 = nullptr;
   float* d_head_bias = nullptr; // [4][16] folded biases of the hrnet_cms heads
   int head_k = 0, head_s = 1;   // transposed-conv kernel / stride of the heads (heat-map = S * branch-0 size)
   std::vector<scpose::TensorDesc> tensors;
@@ -291,13 +295,37 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
     float ms[6] = {d.mean[0], d.mean[1], d.mean[2], d.std[0], d.std[1], d.std[2]};
     SCP_CHECK_HIP(hipMemcpy(net->d_mean_std, ms, sizeof(ms), hipMemcpyHostToDevice));
   }
-  Op stem{};
-  stem.kind = OP_STEM; stem.in = -2; stem.res = -1; stem.conv = -1; stem.relu = 1;
-  stem.out = B.new_tensor(64, 1);
-  B.push(stem);
-  int x = stem.out;
-  net->taps.emplace_back("stem1", x);
-  x = B.conv(x, "conv2", "bn2", 64, 3, 2, true);
+  int x;
+  static const char* stemf_env = dev_env("SCPOSE_STEM_FUSED");
+  if (!(stemf_env && atoi(stemf_env) == 0)) {
+    // conv1 + conv2 as one launch: the 64 x H/2 x W/2 tensor between them never reaches HBM (stem_fused.hip)
+    std::vector<float> w1, b1, w2, b2;
+    if (!fold(W, "conv1", "bn1", 64, 3, 3, false, &w1, &b1) || !fold(W, "conv2", "bn2", 64, 64, 3, false, &w2, &b2)) return SCPOSE_E_MISSING;
+    std::vector<uint16_t> pw1, pw2;
+    std::vector<float> pb1, pb2;
+    stem_fused_pack(w1.data(), b1.data(), w2.data(), b2.data(), d.dtype, &pw1, &pw2, &pb1, &pb2);
+    SCP_CHECK_HIP(hipMalloc(&net->d_stemf_w1, pw1.size() * 2));
+    SCP_CHECK_HIP(hipMalloc(&net->d_stemf_w2, pw2.size() * 2));
+    SCP_CHECK_HIP(hipMalloc(&net->d_stemf_b1, 64 * 4));
+    SCP_CHECK_HIP(hipMalloc(&net->d_stemf_b2, 64 * 4));
+    SCP_CHECK_HIP(hipMemcpy(net->d_stemf_w1, pw1.data(), pw1.size() * 2, hipMemcpyHostToDevice));
+    SCP_CHECK_HIP(hipMemcpy(net->d_stemf_w2, pw2.data(), pw2.size() * 2, hipMemcpyHostToDevice));
+    SCP_CHECK_HIP(hipMemcpy(net->d_stemf_b1, pb1.data(), 64 * 4, hipMemcpyHostToDevice));
+    SCP_CHECK_HIP(hipMemcpy(net->d_stemf_b2, pb2.data(), 64 * 4, hipMemcpyHostToDevice));
+    Op stem{};
+    stem.kind = OP_STEM2; stem.in = -2; stem.res = -1; stem.conv = -1; stem.relu = 1;
+    stem.out = B.new_tensor(64, 2);
+    B.push(stem);
+    x = stem.out;
+  } else {
+    Op stem{};
+    stem.kind = OP_STEM; stem.in = -2; stem.res = -1; stem.conv = -1; stem.relu = 1;
+    stem.out = B.new_tensor(64, 1);
+    B.push(stem);
+    x = stem.out;
+    net->taps.emplace_back("stem1", x);
+    x = B.conv(x, "conv2", "bn2", 64, 3, 2, true);
+  }
   net->taps.emplace_back("stem2", x);
 
   // ---- layer1: 4 Bottlenecks (64 -> 256) ----
@@ -550,6 +578,9 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
     if (op.kind == OP_STEM) {
       rc = stem_launch(in, in_fmt, net->d_stem_w, net->d_stem_b, net->d_mean_std, n, h, w,
                        net->desc.dtype, ptr(op.out), st);
+    } else if (op.kind == OP_STEM2) {
+      rc = stem_fused_launch(in, in_fmt, net->d_stemf_w1, net->d_stemf_w2, net->d_stemf_b1, net->d_stemf_b2, net->d_mean_std,
+                             n, h, w, net->desc.dtype, ptr(op.out), st);
     } else if (op.kind == OP_CONV) {
       const TensorDesc& ti = net->tensors[op.in];
       void* out = op.out == -2 ? static_cast<void*>(heatmaps) : ptr(op.out);
@@ -594,6 +625,12 @@ static void op_work(const scpose_hrnet* net, const Op& op, int h, int w, double*
     *f = 2.0 * 27 * 64 * (h / 2) * (w / 2);
     *by = (double)64 * (h / 2) * (w / 2) * 2 + 3.0 * h * w;   // u8 in (f32 in: 4x) + 16-bit out
     sig[1] = 32; sig[2] = 3; sig[3] = 64;
+  } else if (op.kind == OP_STEM2) {
+    // both stem convolutions; bytes: the launch reads the image and writes the H/4 x W/4 result (unfused accounting:
+    // + the H/2 x W/2 tensor written once and read once)
+    *f = 2.0 * 27 * 64 * (h / 2) * (w / 2) + 2.0 * 64 * 64 * 9 * (h / 4) * (w / 4);
+    *by = (double)64 * (h / 4) * (w / 4) * 2 + 3.0 * h * w + (unfused ? 2.0 * 64 * (h / 2) * (w / 2) * 2 : 0.0);
+    sig[0] = OP_STEM; sig[1] = 32; sig[2] = 3; sig[3] = 64;
   } else if (op.kind == OP_CONV) {
     const PackedConv& pc = net->convs[op.conv];
     const TensorDesc& ti = net->tensors[op.in];
@@ -631,7 +668,7 @@ void hrnet_stats(scpose_hrnet* net, int h, int w, int* launches, double* flops, 
   for (const Op& op : net->ops) {
     double of, ob; int32_t sig[4];
     op_work(net, op, h, w, &of, &ob, sig, true);   // whole-net figure in SURVEY.md 8(d)'s accounting (422 MB for W48 384^2)
-    if (op.kind == OP_STEM) ob -= 3.0 * h * w;   // network input is not an inter-layer activation
+    if (op.kind == OP_STEM || op.kind == OP_STEM2) ob -= 3.0 * h * w;   // network input is not an inter-layer activation
     f += of; by += ob;
   }
   if (launches) *launches = (int)net->ops.size();
@@ -644,6 +681,10 @@ void hrnet_free(scpose_hrnet* net) {
   if (net->d_stem_w) (void)hipFree(net->d_stem_w);
   if (net->d_stem_b) (void)hipFree(net->d_stem_b);
   if (net->d_mean_std) (void)hipFree(net->d_mean_std);
+  if (net->d_stemf_w1) (void)hipFree(net->d_stemf_w1);
+  if (net->d_stemf_w2) (void)hipFree(net->d_stemf_w2);
+  if (net->d_stemf_b1) (void)hipFree(net->d_stemf_b1);
+  if (net->d_stemf_b2) (void)hipFree(net->d_stemf_b2);
   if (net->d_head_bias) (void)hipFree(net->d_head_bias);
   for (auto& e : net->events) if (e) (void)hipEventDestroy(e);
   net->events.clear();

@@ -303,3 +303,32 @@ def test_captured_forward_is_bit_identical(gpu_ops, name):
         gr.close()
     assert torch.equal(eng(xa), ya)          # the eager path is unaffected by the captured one
     eng.close()
+
+
+@pytest.mark.parametrize("h,w,n,dt", [(64, 64, 3, "bf16"), (96, 160, 2, "bf16"), (128, 32, 2, "f16"), (384, 384, 1, "bf16"), (32, 32, 1, "bf16")])
+def test_fused_stem_matches_oracle(gpu_ops, h, w, n, dt):
+    """csrc/stem_fused.hip (conv1 + bn1 + relu + conv2 + bn2 + relu in one launch, pose_hrnet.py:426-431) through the
+    "stem2" tap, element-wise against the oracle's storage model: ragged tiles (W/4 not a multiple of the 16-pixel
+    tile), image borders (zero padding of BOTH convolutions), uint8 and float32 input, both operand types."""
+    cfg = R.tiny_cfg()
+    sd = R.make_state_dict(cfg, seed=17)
+    g = torch.Generator().manual_seed(h * 7 + w)
+    u8 = torch.randint(0, 256, (n, h, w, 3), generator=g, dtype=torch.uint8)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    x = (u8.permute(0, 3, 1, 2).float() / 255.0 - mean) / std
+    taps = {}
+    with torch.no_grad():
+        R.forward(sd, cfg, x, emulate=dt, taps=taps)
+    ref = taps["stem2"]
+    eng = gpu_ops.HrnetEngine(cfg, sd, dtype=dt)
+    a = eng.forward_tap(u8.cuda(), "stem2").cpu()
+    b = eng.forward_tap(x.cuda(), "stem2").cpu()
+    assert a.shape == ref.shape == (n, 64, h // 4, w // 4)
+    assert torch.equal(a, b), "uint8 and normalised-float32 inputs must give the same stem output"
+    eps = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+    ulp = eps * torch.maximum(ref.abs(), torch.full_like(ref, float(ref.abs().mean())))
+    u = (a - ref).abs() / ulp
+    print("stem %dx%d %s: max %.2f ulps, %.5f of the elements off by > 0.5 ulp" % (h, w, dt, u.max().item(), (u > 0.5).float().mean().item()))
+    assert u.max().item() <= 2.5 and (u > 0.5).float().mean().item() <= 2e-3
+    eng.close()
