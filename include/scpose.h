@@ -142,6 +142,8 @@ int32_t scpose_hrnet_graph_destroy(scpose_hrnet_graph_t g);
  * and writes it as float32 N x C x h x w (converted from the 16-bit blocked layout).  Names follow the forward of
  * pose_hrnet.py:425-460: "stem1" (:426-428), "stem2" (:429-431), "layer1" (:432), "stage<S>.<M>.out0" = y_list[0]
  * after module M of stage S (:247-265).  With out == NULL only *channels / *out_h / *out_w are filled (shape query). */
+int32_t scpose_hrnet_tap_names(scpose_hrnet_t h, char* buf, int32_t cap);   /* comma-separated names this handle offers ("stem1"
+                                                                              exists only when the stem runs as two layers) */
 int32_t scpose_hrnet_forward_tap(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n, int32_t height,
                                  int32_t width, const char* tap, float* out, int32_t* channels, int32_t* out_h,
                                  int32_t* out_w, void* workspace, size_t workspace_bytes, void* stream);

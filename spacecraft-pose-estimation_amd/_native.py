@@ -53,6 +53,7 @@ SYMBOLS = {
     "scpose_hrnet_graph_launch": (c_int32, [c_void_p, c_void_p]),
     "scpose_hrnet_graph_nodes": (c_int32, [c_void_p, POINTER(c_int32)]),
     "scpose_hrnet_graph_destroy": (c_int32, [c_void_p]),
+    "scpose_hrnet_tap_names": (c_int32, [c_void_p, c_char_p, c_int32]),
     "scpose_hrnet_forward_tap": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_char_p, c_void_p,
                                            POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), c_void_p, c_size_t, c_void_p]),
     "scpose_hrnet_forward_profiled": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,

@@ -124,7 +124,14 @@ struct PackedConv {
   float* d_b1 = nullptr;
   size_t w1_bytes = 0;
   int cout_pad1 = 0;
+  // register-weight stride-2 kernel (conv_s2r.hip): weights [k-step][cout block][k-group][row][8], bias in MFMA row order
+  void* d_ws2 = nullptr;
+  float* d_bs2 = nullptr;
 };
+bool conv_s2r_config(int cin, int cout, int* planes, int* nblk, int* g);
+size_t conv_s2r_pack(const float* w, int cout, int cin, int dtype, uint16_t* dst);
+void conv_s2r_pack_bias(const float* bias, int cout, float* dst);
+int32_t conv_s2r_launch(const PackedConv& pc, const void* in, int N, int H, int W, int relu, void* out, hipStream_t stream);
 bool conv1x1_stream_eligible(const PackedConv& pc);
 int32_t conv1x1_stream_launch(const PackedConv& pc, const void* in, int N, int H, int W, const void* res, int relu,
                               void* out, hipStream_t stream, const void* in2 = nullptr, int split_planes = 0);

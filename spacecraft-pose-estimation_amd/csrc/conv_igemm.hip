@@ -191,6 +191,20 @@ int32_t conv_upload(const float* w, const float* bias, int cout, int cin, int ks
       pc->w1_bytes = wb; pc->cout_pad1 = cpad;
     }
   }
+  {   // 3x3 stride-2 layers with Cin = 32 / 48 / 64: register-weight kernel (conv_s2r.hip)
+    static const char* e = dev_env("SCPOSE_S2R");
+    int planes, nblk, g;
+    if (ks == 3 && stride == 2 && !(e && atoi(e) == 0) && conv_s2r_config(cin, cout, &planes, &nblk, &g)) {
+      std::vector<uint16_t> h2(conv_s2r_pack(w, cout, cin, dtype, nullptr) / 2);
+      conv_s2r_pack(w, cout, cin, dtype, h2.data());
+      std::vector<float> b2(cout);
+      conv_s2r_pack_bias(bias, cout, b2.data());
+      SCP_CHECK_HIP(hipMalloc(&pc->d_ws2, h2.size() * 2));
+      SCP_CHECK_HIP(hipMalloc(&pc->d_bs2, b2.size() * sizeof(float)));
+      SCP_CHECK_HIP(hipMemcpy(pc->d_ws2, h2.data(), h2.size() * 2, hipMemcpyHostToDevice));
+      SCP_CHECK_HIP(hipMemcpy(pc->d_bs2, b2.data(), b2.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+  }
   SCP_REQUIRE(conv_zero_page() != nullptr, "conv: cannot allocate the zero page");  // create-time, not in the launch path
   SCP_CHECK_HIP(hipMalloc(&pc->d_w, pc->wbytes));
   SCP_CHECK_HIP(hipMalloc(&pc->d_bias, hb.size() * sizeof(float)));
@@ -204,7 +218,9 @@ void conv_free(PackedConv* pc) {
   if (pc->d_bias) (void)hipFree(pc->d_bias);
   if (pc->d_w1) (void)hipFree(pc->d_w1);
   if (pc->d_b1) (void)hipFree(pc->d_b1);
-  pc->d_w = nullptr; pc->d_bias = nullptr; pc->d_w1 = nullptr; pc->d_b1 = nullptr;
+  if (pc->d_ws2) (void)hipFree(pc->d_ws2);
+  if (pc->d_bs2) (void)hipFree(pc->d_bs2);
+  pc->d_w = nullptr; pc->d_bias = nullptr; pc->d_w1 = nullptr; pc->d_b1 = nullptr; pc->d_ws2 = nullptr; pc->d_bs2 = nullptr;
 }
 
 int plane_stride_for(int stride, int halo_h, int halo_w) {
@@ -235,6 +251,8 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
   L.Wo = (W - 1) / pc.stride + 1;
   L.cin_planes = pc.cin / 8;
   L.cout = pc.cout;
+  if (pc.d_ws2 && !res && !in2 && !out_nchw_f32 && (size_t)N * L.cin_planes * H * W * 16 < 0xfffffff0ull)
+    return conv_s2r_launch(pc, in, N, H, W, relu, out, stream);
   if (pc.variant == 1) {
     SCP_REQUIRE(!out_nchw_f32, "conv m32: float32 NCHW output unsupported");
     L.relu = relu; L.out_nchw_f32 = 0;

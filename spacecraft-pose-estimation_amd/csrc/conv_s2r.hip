@@ -1,0 +1,253 @@
+// 3x3 stride-2 convolution (+ folded BN, optional ReLU) with the weights held in REGISTERS, on
+// v_mfma_f32_16x16x32_{bf16,f16}: the fuse-layer down paths (pose_hrnet.py:211-239) and the transition convolutions
+// that open a new branch (:355-369) for Cin = 32 / 48 / 64.
+//
+// Why a third kernel family for these layers: they read four input pixels per output pixel and have little K
+// (Cin = 48: 14 k-steps), so on the producer/consumer kernel (conv_m32p_kernel.h) a stage holds 27-54 MFMAs against
+// ~1 000 cycles of fixed stage cost (barrier, pipeline restart, weight-chunk staging): 2-3 TB/s and 0.15-0.28 MFMA
+// utilisation (profiles/round1_final_*).  Here the whole K of a wave's output channels sits in its registers
+// (Cin = 48: 3 blocks x 14 k-steps x 4 VGPRs = 168), LDS holds nothing but the input tile (double-buffered, filled
+// by LDS-DMA), and a tile costs ONE workgroup barrier.
+//
+// One 512-thread workgroup per CU, persistent over tiles of 8 x 16 output pixels.  Waves split G ways over the
+// output channels (16 * NBLK each) and 8 / G ways over the tile's rows; a wave therefore computes NBLK blocks x G rows.
+// Input tile: [Cin / 8 planes][17 x 33 pixels][16 B]; 561 slots per plane is odd, so the stride-2 fragment reads of
+// two k-groups that share a ds_read_b128 lane group never collide (MI355X_MICROARCH.md, LDS).
+#include "common.h"
+#include "conv_device.h"
+#include "conv_pipe_kernel.h"   // dma16_buf, make_buf, BUF_OOB
+
+namespace scpose {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+constexpr int kTH = 8, kTW = 16;
+constexpr int kMH = 2 * kTH + 1, kMW = 2 * kTW + 1, kMPix = kMH * kMW;   // 17 x 33 = 561 input pixels per tile
+constexpr int kMS = kMPix * 16;
+
+struct S2rLaunch {
+  const void* in;
+  const void* w;         // [k-step][cout block][4 k-groups][16 rows][8]
+  const float* bias;     // MFMA row order
+  void* out;
+  uint32_t in_bytes;
+  int32_t N, H, W, Ho, Wo, cout_planes, relu;
+  int32_t tiles_x, tiles_y, tiles_total, tiles_per_wg, grid;
+};
+
+inline int s2r_row_channel(int row) {
+  const int q = row >> 2, reg = row & 3;
+  return (q & 1) * 8 + (q >> 1) * 4 + reg;
+}
+
+}  // namespace
+
+template <int DT, int PLANES, int NBLK, int G>
+__global__ __launch_bounds__(512, 2) void conv_s2r_kernel(const S2rLaunch p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename DtOf<DT>::type T;
+  typedef typename FragOf<T>::type frag_t;
+  constexpr int NPT = 9 * PLANES;              // (tap, plane) pairs
+  constexpr int KS = (NPT + 3) / 4;            // 32-deep k-steps
+  constexpr int NCOL = G;                      // tile rows per wave
+  constexpr int XB = PLANES * kMS;             // bytes of one input-tile buffer
+  constexpr int NSLOT = (kMPix + 63) / 64;     // 64-pixel DMA pieces per plane
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, r = lane & 15, half = lane >> 5, psel = q & 1;
+  const int g = wave % G, rset = wave / G;     // output-channel group, row set
+  const int HW = p.H * p.W;
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+
+  // ---- this wave's weights: NBLK blocks x KS k-steps ----
+  frag_t wf[KS][NBLK];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int mb = 0; mb < NBLK; ++mb)
+      wf[s][mb] = *reinterpret_cast<const frag_t*>(static_cast<const char*>(p.w) + ((((size_t)s * (NBLK * G) + g * NBLK + mb) * 4 + q) * 16 + r) * 16);
+  float4 bs[NBLK];
+#pragma unroll
+  for (int mb = 0; mb < NBLK; ++mb) bs[mb] = *reinterpret_cast<const float4*>(p.bias + (g * NBLK + mb) * 16 + q * 4);
+  // operand addressing: k-step s, k-group q -> pair t = 4 s + q = (tap, plane); padding pairs read slot 0 (finite, weight 0)
+  int koff[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int t = 4 * s + q, tap = t / PLANES, plane = t - tap * PLANES, ky = tap / 3, kx = tap - 3 * ky;
+    koff[s] = t < NPT ? plane * kMS + (ky * kMW + kx) * 16 : 0;
+  }
+
+  const int wg = xcd_remap(blockIdx.x, p.grid);
+  const int t_begin = wg * p.tiles_per_wg;
+  const int t_end = min(p.tiles_total, t_begin + p.tiles_per_wg);
+  auto decode = [&](int t, int& img, int& oy0, int& ox0) {
+    img = t / tiles_per_img;
+    const int rem = t - img * tiles_per_img;
+    const int ty = rem / p.tiles_x;
+    oy0 = ty * kTH; ox0 = (rem - ty * p.tiles_x) * kTW;
+  };
+  const buf_rsrc_t rs_in = make_buf(p.in, p.in_bytes);
+  // LDS-DMA of tile t into buffer b: piece = 64 pixel slots of one plane; wave w takes pieces w, w + 8, ...
+  auto issue_x = [&](int t, int b) {
+    int img, oy0, ox0;
+    decode(t, img, oy0, ox0);
+    char* xl = smem + b * XB;
+#pragma unroll 1
+    for (int piece = wave; piece < NSLOT; piece += 8) {
+      const int slot = piece * 64 + lane;
+      const int my = slot / kMW, mx = slot - my * kMW;
+      const int iy = 2 * oy0 - 1 + my, ix = 2 * ox0 - 1 + mx;
+      const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const uint32_t voff = ok ? (uint32_t)(img * PLANES * HW + iy * p.W + ix) * 16u : BUF_OOB;   // padding: read as zeros
+      if (slot < kMPix) {   // lanes past the plane's last slot stay inactive: their LDS write would land in the next plane
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl) dma16_buf(rs_in, voff, (uint32_t)(pl * HW) * 16u, xl + pl * kMS + piece * 1024);
+      }
+    }
+  };
+
+  if (t_begin < t_end) issue_x(t_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const size_t plane_sz = (size_t)p.Ho * p.Wo;
+  int buf = 0;
+  for (int t = t_begin; t < t_end; ++t, buf ^= 1) {
+    int img, oy0, ox0;
+    decode(t, img, oy0, ox0);
+    if (t + 1 < t_end) issue_x(t + 1, buf ^ 1);            // streams in under this tile's MFMAs
+    const char* xl = smem + buf * XB;
+
+    // columns (tile rows) of this wave: rset * NCOL + c; processed two at a time (one when NCOL == 1)
+    constexpr int CSTEP = NCOL >= 2 ? 2 : 1;
+#pragma unroll 1
+    for (int c0 = 0; c0 < NCOL; c0 += CSTEP) {
+      f32x4 acc[NBLK][CSTEP];
+#pragma unroll
+      for (int mb = 0; mb < NBLK; ++mb)
+#pragma unroll
+        for (int c = 0; c < CSTEP; ++c) acc[mb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int py0 = rset * NCOL + c0;
+      const char* bcol = xl + ((2 * py0) * kMW + 2 * r) * 16;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        frag_t bf[CSTEP];
+#pragma unroll
+        for (int c = 0; c < CSTEP; ++c) bf[c] = *reinterpret_cast<const frag_t*>(bcol + c * (2 * kMW * 16) + koff[s]);
+#pragma unroll
+        for (int mb = 0; mb < NBLK; ++mb)
+#pragma unroll
+          for (int c = 0; c < CSTEP; ++c) acc[mb][c] = mfma16<T>(wf[s][mb], bf[c], acc[mb][c]);
+      }
+      // epilogue: v_permlane32_swap gives the lower half-wave the 8 channels (plane 2 * block + psel) of column 0's
+      // pixel and the upper half-wave those of column 1's (one column: the lower half-wave stores, the upper idles)
+      const uint32_t relu_floor = p.relu ? 0u : 0x80008000u;
+      const int oy = oy0 + py0 + (CSTEP == 2 ? half : 0), ox = ox0 + r;
+      const bool store_ok = oy < p.Ho && ox < p.Wo && (CSTEP == 2 || half == 0);
+#pragma unroll
+      for (int mb = 0; mb < NBLK; ++mb) {
+        const float4 b4 = bs[mb];
+        uint32_t a[4], b[4];
+        a[0] = __float_as_uint(acc[mb][0][0] + b4.x); a[1] = __float_as_uint(acc[mb][0][1] + b4.y);
+        a[2] = __float_as_uint(acc[mb][0][2] + b4.z); a[3] = __float_as_uint(acc[mb][0][3] + b4.w);
+        if constexpr (CSTEP == 2) {
+          b[0] = __float_as_uint(acc[mb][1][0] + b4.x); b[1] = __float_as_uint(acc[mb][1][1] + b4.y);
+          b[2] = __float_as_uint(acc[mb][1][2] + b4.z); b[3] = __float_as_uint(acc[mb][1][3] + b4.w);
+        } else {
+          b[0] = b[1] = b[2] = b[3] = 0u;
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(a[jj], b[jj], false, false);
+          a[jj] = sw[0]; b[jj] = sw[1];
+        }
+        u32x4_t ov;
+        ov[0] = relu2_16(pack2<T>(__uint_as_float(a[0]), __uint_as_float(a[1])), relu_floor);
+        ov[1] = relu2_16(pack2<T>(__uint_as_float(a[2]), __uint_as_float(a[3])), relu_floor);
+        ov[2] = relu2_16(pack2<T>(__uint_as_float(b[0]), __uint_as_float(b[1])), relu_floor);
+        ov[3] = relu2_16(pack2<T>(__uint_as_float(b[2]), __uint_as_float(b[3])), relu_floor);
+        const int plane = 2 * (g * NBLK + mb) + psel;
+        if (store_ok && plane < p.cout_planes)
+          *reinterpret_cast<u32x4_t*>(static_cast<char*>(p.out) + (((size_t)img * p.cout_planes + plane) * plane_sz + (size_t)oy * p.Wo + ox) * 16) = ov;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // next tile landed (this wave's pieces); stores retired
+    __syncthreads();                                       // ... and everybody is done with this buffer
+  }
+}
+
+// ---- host ----
+bool conv_s2r_config(int cin, int cout, int* planes, int* nblk, int* g) {
+  if (cin != 32 && cin != 48 && cin != 64) return false;
+  const int nb = cin == 48 ? 3 : 2;            // 16-channel blocks per wave: 48 / 32 output channels per group
+  if (cout % (16 * nb) != 0) return false;
+  const int groups = cout / (16 * nb);
+  if (groups != 1 && groups != 2 && groups != 4) return false;
+  *planes = cin / 8; *nblk = nb; *g = groups;
+  return true;
+}
+
+size_t conv_s2r_pack(const float* w, int cout, int cin, int dtype, uint16_t* dst) {
+  const int planes = cin / 8, npt = 9 * planes, ks = (npt + 3) / 4, nblocks = cout / 16;
+  const size_t total = (size_t)ks * nblocks * 4 * 16 * 8;
+  if (!dst) return total * 2;
+  memset(dst, 0, total * 2);
+  for (int s = 0; s < ks; ++s)
+    for (int cb = 0; cb < nblocks; ++cb)
+      for (int q = 0; q < 4; ++q) {
+        const int t = 4 * s + q;
+        if (t >= npt) continue;
+        const int tap = t / planes, plane = t % planes, ky = tap / 3, kx = tap % 3;
+        for (int r = 0; r < 16; ++r) {
+          const int co = 16 * cb + s2r_row_channel(r);
+          uint16_t* d = dst + ((((size_t)s * nblocks + cb) * 4 + q) * 16 + r) * 8;
+          for (int j = 0; j < 8; ++j) d[j] = host_f32_to_16(w[((size_t)(co * cin + plane * 8 + j) * 3 + ky) * 3 + kx], dtype);
+        }
+      }
+  return total * 2;
+}
+
+void conv_s2r_pack_bias(const float* bias, int cout, float* dst) {
+  for (int pos = 0; pos < cout; ++pos) dst[pos] = bias ? bias[(pos & ~15) + s2r_row_channel(pos & 15)] : 0.f;
+}
+
+template <int DT, int PLANES, int NBLK, int G>
+static int32_t s2r_launch_one(const S2rLaunch& L, hipStream_t st) {
+  auto kern = conv_s2r_kernel<DT, PLANES, NBLK, G>;
+  const size_t lds = 2 * (size_t)PLANES * kMS;
+  static LdsOptIn big;
+  { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(kern), (int)lds, &big); if (rc != SCPOSE_OK) return rc; }
+  hipLaunchKernelGGL(kern, dim3(L.grid), dim3(512), lds, st, L);
+  SCP_CHECK_HIP(hipGetLastError());
+  return SCPOSE_OK;
+}
+
+template <int DT>
+static int32_t s2r_dispatch(int planes, int g, const S2rLaunch& L, hipStream_t st) {
+  if (planes == 6) { if (g == 1) return s2r_launch_one<DT, 6, 3, 1>(L, st); if (g == 2) return s2r_launch_one<DT, 6, 3, 2>(L, st); return s2r_launch_one<DT, 6, 3, 4>(L, st); }
+  if (planes == 4) { if (g == 1) return s2r_launch_one<DT, 4, 2, 1>(L, st); if (g == 2) return s2r_launch_one<DT, 4, 2, 2>(L, st); return s2r_launch_one<DT, 4, 2, 4>(L, st); }
+  if (g == 1) return s2r_launch_one<DT, 8, 2, 1>(L, st);
+  if (g == 2) return s2r_launch_one<DT, 8, 2, 2>(L, st);
+  return s2r_launch_one<DT, 8, 2, 4>(L, st);
+}
+
+int32_t conv_s2r_launch(const PackedConv& pc, const void* in, int N, int H, int W, int relu, void* out, hipStream_t stream) {
+  int planes, nblk, g;
+  SCP_REQUIRE(conv_s2r_config(pc.cin, pc.cout, &planes, &nblk, &g) && pc.d_ws2, "conv s2r: %d->%d not eligible", pc.cin, pc.cout);
+  S2rLaunch L{};
+  L.in = in; L.w = pc.d_ws2; L.bias = pc.d_bs2; L.out = out;
+  L.in_bytes = (uint32_t)((size_t)N * planes * H * W * 16);
+  L.N = N; L.H = H; L.W = W; L.Ho = (H - 1) / 2 + 1; L.Wo = (W - 1) / 2 + 1;
+  L.cout_planes = pc.cout / 8; L.relu = relu;
+  L.tiles_x = (L.Wo + kTW - 1) / kTW; L.tiles_y = (L.Ho + kTH - 1) / kTH;
+  L.tiles_total = N * L.tiles_x * L.tiles_y;
+  int grid = conv_device_cus();
+  if (grid > L.tiles_total) grid = L.tiles_total;
+  L.tiles_per_wg = (L.tiles_total + grid - 1) / grid;
+  L.grid = (L.tiles_total + L.tiles_per_wg - 1) / L.tiles_per_wg;
+  if (pc.dtype == SCPOSE_DT_BF16) return s2r_dispatch<0>(planes, g, L, stream);
+  return s2r_dispatch<1>(planes, g, L, stream);
+}
+
+}  // namespace scpose

@@ -866,6 +866,15 @@ extern "C" int32_t scpose_hrnet_graph_destroy(scpose_hrnet_graph_t g) {
   return SCPOSE_OK;
 }
 
+extern "C" int32_t scpose_hrnet_tap_names(scpose_hrnet_t h, char* buf, int32_t cap) {
+  SCP_REQUIRE(h && buf && cap > 0, "hrnet_tap_names: null argument");
+  std::string names;
+  for (const auto& t : h->taps) names += (names.empty() ? "" : ",") + t.first;
+  SCP_REQUIRE((int)names.size() < cap, "hrnet_tap_names: buffer of %d bytes too small (%zu needed)", cap, names.size() + 1);
+  memcpy(buf, names.c_str(), names.size() + 1);
+  return SCPOSE_OK;
+}
+
 extern "C" int32_t scpose_hrnet_forward_tap(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n, int32_t height,
                                             int32_t width, const char* tap, float* out, int32_t* channels, int32_t* out_h,
                                             int32_t* out_w, void* workspace, size_t workspace_bytes, void* stream) {

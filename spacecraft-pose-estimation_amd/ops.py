@@ -361,6 +361,11 @@ class HrnetEngine:
             raise nat.NativeError("capture: out must be contiguous float32 %s" % ((n, self.num_joints, oh, ow),))
         return HrnetGraph(self, x, fmt, (n, h, w), out, concurrent)
 
+    def tap_names(self):
+        buf = ctypes.create_string_buffer(4096)
+        nat.check(nat.lib().scpose_hrnet_tap_names(self._h, buf, 4096), "hrnet_tap_names")
+        return buf.value.decode().split(",")
+
     def forward_tap(self, x, tap):
         """Intermediate tensor `tap` ("stem1", "stem2", "layer1", "stage3.1.out0", ...) of the forward of x as float32
         (N, C, h, w): the forward is run up to the op that produces it (unit-level parity against the oracle's taps)."""

@@ -47,6 +47,15 @@ CASES = [
     (32, 96, 3, 1, 12, 12, 7, True, True),      # 2 K-chunks only: single-role kernel, not producer/consumer
     (384, 384, 3, 1, 5, 5, 9, True, True),
     (96, 96, 3, 1, 1, 1, 4, True, True),
+    # register-weight stride-2 kernel (conv_s2r.hip): every (Cin, channel-group) variant, ragged / odd maps, one-row maps
+    (48, 192, 3, 2, 48, 48, 2, False, True),
+    (48, 48, 3, 2, 18, 50, 3, False, False),
+    (48, 96, 3, 2, 9, 7, 2, False, True),
+    (32, 32, 3, 2, 64, 64, 1, False, True),
+    (32, 128, 3, 2, 34, 22, 2, False, False),
+    (64, 128, 3, 2, 32, 32, 2, False, True),
+    (64, 32, 3, 2, 5, 33, 1, False, True),
+    (64, 64, 3, 2, 1, 1, 5, False, False),
 ]
 
 
