@@ -75,8 +75,10 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--events", action="store_true",
                     help="BASELINE configs[4] side line: HRNet-W32 256x256, f16 MFMA kernels, mixed RGB + event-frame batch")
-    ap.add_argument("--graph", type=int, default=1,
-                    help="1: un-profiled steps replay the forward from a hipGraph with concurrent branches (scpose_hrnet_graph_*); 0: eager launches")
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="1: un-profiled steps replay the forward from a hipGraph with concurrent branches (scpose_hrnet_graph_*); "
+                         "0: eager launches; default: 1 for batches <= 64 (launch-bound; -33 %% at W32 batch 64), 0 above "
+                         "(at batch 256 every kernel fills the chip and concurrent lanes only contend: measured +0.4 ms)")
     ap.add_argument("--chained", action="store_true",
                     help="feed the PnP stage with the decoded (random-weight) keypoints instead of synthetic ones")
     return ap.parse_args()
@@ -160,6 +162,8 @@ def main():
     sd = syn.random_checkpoint(cfg, seed=0)
     eng = ops.HrnetEngine(cfg, sd, dtype=args.dtype, device=dev)
     B = args.batch
+    if args.graph < 0:
+        args.graph = 1 if B <= 64 else 0
     hh = image // 4
 
     # ---- synthetic inputs, resident in HBM before the timed region (shard = rank's slice) ----

@@ -251,7 +251,8 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
   L.Wo = (W - 1) / pc.stride + 1;
   L.cin_planes = pc.cin / 8;
   L.cout = pc.cout;
-  if (pc.d_ws2 && !res && !in2 && !out_nchw_f32 && (size_t)N * L.cin_planes * H * W * 16 < 0xfffffff0ull)
+  if (pc.d_ws2 && !res && !in2 && !out_nchw_f32 && (size_t)N * L.cin_planes * H * W * 16 < 0xfffffff0ull &&
+      (size_t)N * (pc.cout / 8) * L.Ho * L.Wo * 16 < 0xfffffff0ull)
     return conv_s2r_launch(pc, in, N, H, W, relu, out, stream);
   if (pc.variant == 1) {
     SCP_REQUIRE(!out_nchw_f32, "conv m32: float32 NCHW output unsupported");

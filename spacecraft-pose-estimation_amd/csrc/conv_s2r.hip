@@ -31,7 +31,7 @@ struct S2rLaunch {
   const void* w;         // [k-step][cout block][4 k-groups][16 rows][8]
   const float* bias;     // MFMA row order
   void* out;
-  uint32_t in_bytes;
+  uint32_t in_bytes, out_bytes;
   int32_t N, H, W, Ho, Wo, cout_planes, relu;
   int32_t tiles_x, tiles_y, tiles_total, tiles_per_wg, grid;
 };
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2r_kernel(const S2rLaunch p) {
     const int ty = rem / p.tiles_x;
     oy0 = ty * kTH; ox0 = (rem - ty * p.tiles_x) * kTW;
   };
-  const buf_rsrc_t rs_in = make_buf(p.in, p.in_bytes);
+  const buf_rsrc_t rs_in = make_buf(p.in, p.in_bytes), rs_out = make_buf(p.out, p.out_bytes);
   // LDS-DMA of tile t into buffer b: piece = 64 pixel slots of one plane; wave w takes pieces w, w + 8, ...
   auto issue_x = [&](int t, int b) {
     int img, oy0, ox0;
@@ -167,13 +167,17 @@ __global__ __launch_bounds__(512, 2) void conv_s2r_kernel(const S2rLaunch p) {
         ov[1] = relu2_16(pack2<T>(__uint_as_float(a[2]), __uint_as_float(a[3])), relu_floor);
         ov[2] = relu2_16(pack2<T>(__uint_as_float(b[0]), __uint_as_float(b[1])), relu_floor);
         ov[3] = relu2_16(pack2<T>(__uint_as_float(b[2]), __uint_as_float(b[3])), relu_floor);
+        // buffer store: every wave issues exactly one store instruction per block (pixels outside the map get an
+        // out-of-range offset and are dropped by the hardware), which the counted wait below relies on
         const int plane = 2 * (g * NBLK + mb) + psel;
-        if (store_ok && plane < p.cout_planes)
-          *reinterpret_cast<u32x4_t*>(static_cast<char*>(p.out) + (((size_t)img * p.cout_planes + plane) * plane_sz + (size_t)oy * p.Wo + ox) * 16) = ov;
+        const uint32_t voff = store_ok ? (uint32_t)(((size_t)img * p.cout_planes + plane) * plane_sz + (size_t)oy * p.Wo + ox) * 16u : BUF_OOB;
+        store16_buf(rs_out, voff, 0u, __builtin_bit_cast(u32x4, ov));
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // next tile landed (this wave's pieces); stores retired
-    __syncthreads();                                       // ... and everybody is done with this buffer
+    // next tile landed (this wave's pieces): the DMA was issued before this tile's NBLK * NCOL / CSTEP output stores and
+    // vector-memory operations retire in issue order, so the stores themselves need not be waited for
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NBLK * (NCOL / CSTEP)) : "memory");
+    __builtin_amdgcn_s_barrier();                          // ... and everybody is done with this buffer (LDS reads are consumed)
   }
 }
 
@@ -238,6 +242,7 @@ int32_t conv_s2r_launch(const PackedConv& pc, const void* in, int N, int H, int 
   S2rLaunch L{};
   L.in = in; L.w = pc.d_ws2; L.bias = pc.d_bs2; L.out = out;
   L.in_bytes = (uint32_t)((size_t)N * planes * H * W * 16);
+  L.out_bytes = (uint32_t)((size_t)N * (pc.cout / 8) * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * 16);
   L.N = N; L.H = H; L.W = W; L.Ho = (H - 1) / 2 + 1; L.Wo = (W - 1) / 2 + 1;
   L.cout_planes = pc.cout / 8; L.relu = relu;
   L.tiles_x = (L.Wo + kTW - 1) / kTW; L.tiles_y = (L.Ho + kTH - 1) / kTH;

@@ -42,6 +42,7 @@ struct PnpArgs {
   double conf_thr0, thr_decay;
   int min_pts, thr_iters, max_iters;
   double reproj_err, confidence;
+  int dbg_no_spec;          // development (SCPOSE_PNP_SPEC=0): ignore the speculative final fits
 };
 
 struct Cam { double fx, fy, cx, cy, k[5]; };
@@ -716,8 +717,22 @@ __global__ __launch_bounds__(64) void pnp_kernel(const PnpArgs a) {
     double best_r[3] = {0, 0, 0}, best_t[3] = {0, 0, 0};
     CvRng rng{~0ULL};
     const float t2 = (float)(a.reproj_err * a.reproj_err);
+    // Speculative final fit.  solvePnPRansac ends with one more EPnP over the inlier set (export_predicted_poses_real.py:199,
+    // OpenCV solvepnp.cpp), a serial tail as long as a whole hypothesis batch.  The inlier set is almost always "every
+    // point" or "every point but one", so in the FIRST batch the top n + 1 lanes solve exactly those sets (same
+    // function, same points in the same order, s_u64 image points) beside the 5-point hypotheses of the other lanes.
+    // If RANSAC ends on one of them, that lane's pose IS the final fit, bit for bit; otherwise the fit runs as before.
+    // The hypothesis stream is unchanged: batches only group consecutive iterations, and the ordered scan below
+    // replays the sequential accept / RANSACUpdateNumIters rule whatever the group sizes are.
+    const unsigned long long full_mask = (n >= 64) ? ~0ULL : ((1ULL << n) - 1ULL);
+    const int nspec = n <= 31 ? n + 1 : 1;
+    const int sidx = 63 - lane;                                   // 0: full set, i: full set without point i - 1
+    const bool spec_lane = sidx < nspec;
+    const unsigned long long spec_mask = full_mask & ~(sidx > 0 && spec_lane ? 1ULL << (sidx - 1) : 0ULL);
+    double spec_r[3] = {0, 0, 0}, spec_t[3] = {0, 0, 0};
     for (int iter0 = 0; iter0 < niters;) {
-      const int nb = min(64, niters - iter0);
+      const bool first = iter0 == 0;
+      const int nb = min(first ? 64 - nspec : 64, niters - iter0);
       unsigned my_packed = 0;
       for (int k = 0; k < nb; k++) {   // getSubset: duplicate-free draws, one shared RNG stream
         unsigned packed = 0;
@@ -737,10 +752,14 @@ __global__ __launch_bounds__(64) void pnp_kernel(const PnpArgs a) {
       double r[3] = {0, 0, 0}, t[3] = {0, 0, 0};
       unsigned long long mask = 0;
       int good = 0;
-      if (lane < nb) {
-        PtSet ps{0ULL, my_packed, model_points, true};
-        e.us = s_u32;
+      const bool hyp_lane = lane < nb, spec_now = first && spec_lane;
+      if (hyp_lane || spec_now) {   // ONE call site: hypothesis and speculative lanes run side by side, not one after the other
+        PtSet ps{spec_now ? spec_mask : 0ULL, my_packed, spec_now ? (int)__popcll(spec_mask) : model_points, !spec_now};
+        e.us = spec_now ? s_u64 : s_u32;
         solve_epnp(e, ps, ut, r, t);
+      }
+      if (spec_now) { for (int k = 0; k < 3; k++) { spec_r[k] = r[k]; spec_t[k] = t[k]; } }
+      if (hyp_lane) {
         double R[9];
         rodrigues_vec2mat(r, R);
         for (int i = 0; i < n; i++) {   // PnPRansacCallback::computeError + findInliers
@@ -771,10 +790,17 @@ __global__ __launch_bounds__(64) void pnp_kernel(const PnpArgs a) {
     if (max_good <= 0) {
       status = -2;
     } else {
-      PtSet ps{best_mask, 0u, (int)__popcll(best_mask), false};
-      e.us = s_u64;
-      solve_epnp(e, ps, ut, rvec, tvec);   // wave-uniform
-      status = ps.n;
+      const unsigned long long hit = __ballot(spec_lane && spec_mask == best_mask);
+      if (hit != 0ULL && !(a.dbg_no_spec)) {   // the final fit has already been computed by a speculative lane
+        const int src = __builtin_ctzll(hit);
+        for (int k = 0; k < 3; k++) { rvec[k] = __shfl(spec_r[k], src, 64); tvec[k] = __shfl(spec_t[k], src, 64); }
+        status = (int)__popcll(best_mask);
+      } else {
+        PtSet ps{best_mask, 0u, (int)__popcll(best_mask), false};
+        e.us = s_u64;
+        solve_epnp(e, ps, ut, rvec, tvec);   // wave-uniform
+        status = ps.n;
+      }
     }
   }
 
@@ -798,7 +824,8 @@ int32_t pnp_launch(const float* kp_xyc, const double* landmarks, const double* K
   SCP_REQUIRE(N >= 0, "pnp: N=%d", N);
   if (N == 0) return SCPOSE_OK;
   PnpArgs a{kp_xyc, landmarks, K, dist, rot, tvec, rvec, status, N, J, conf_thr0, thr_decay, min_pts, thr_iters,
-            max_iters, reproj_err, confidence};
+            max_iters, reproj_err, confidence, 0};
+  { static const char* e = dev_env("SCPOSE_PNP_SPEC"); a.dbg_no_spec = (e && atoi(e) == 0) ? 1 : 0; }
   const size_t lds = (size_t)(144 * 64 + kMaxJ * 9) * sizeof(double);
   static LdsOptIn big_lds;   // per device (common.h)
   { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(pnp_kernel), (int)lds, &big_lds); if (rc != SCPOSE_OK) return rc; }
