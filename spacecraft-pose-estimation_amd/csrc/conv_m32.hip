@@ -39,7 +39,9 @@ bool conv_m32_choose(int cin, int cout, int ks, int stride, int* mr, int* wm, in
   // whole K in one chunk with resident weights when it fits comfortably, else stream 2-plane chunks
   const int mt = 32 * m * w;
   const size_t whole = (size_t)(planes / 2) * 9 * 2 * mt * 16;
-  *cp = (cout == mt && whole <= 60 * 1024 && planes <= 6) ? planes : 2;
+  // (stride 2 runs on the producer/consumer kernel only, which needs >= 3 K-chunks: always stream 2-plane chunks there --
+  // a single resident chunk, e.g. 48 -> 64, would pass create and then find no tiling at the first forward)
+  *cp = (stride == 1 && cout == mt && whole <= 60 * 1024 && planes <= 6) ? planes : 2;
   return true;
 }
 
@@ -110,7 +112,13 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   int p_th = 0, p_tw = 0, p_nseg = 0, p_nr = 0, p_ps = 0;   // best producer/consumer candidate (cost model)
   const int cus = conv_device_cus();
   const int tw_cand[8] = {L.Wo, 64, 48, 32, 24, 16, 12, 8};
+  // the search below depends on (layer, N, Ho, Wo) only: its result is remembered in the layer (a forward launches the
+  // same shapes every time; small batches are launch-bound on the host)
+  PackedConv::TileMemo& memo = pc.m32_memo;
+  const bool memo_hit = memo.n == L.N && memo.ho == L.Ho && memo.wo == L.Wo && !dev_env("SCPOSE_M32_OCC") && !dev_env("SCPOSE_M32_NR");
+  if (memo_hit) { found = true; b_th = memo.th; b_tw = memo.tw; b_nseg = memo.nseg; b_nr = memo.nr; b_ps = memo.ps; b_occ = memo.occ; }
   for (const M32Variant& v : kVariants) {
+    if (memo_hit) break;
     static const char* nr_env = dev_env("SCPOSE_M32_NR");   // development: restrict the search to one column count
     if (v.mr != pc.mrep || v.wm != pc.wm || (occ_only && v.occ != occ_only) || (nr_env && v.nr != atoi(nr_env))) continue;
     const int nr = v.nr;
@@ -153,10 +161,11 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
     }
   }
   // measured preference: producer/consumer for 96-row blocks and for stride 2, two workgroups per CU for 64-row blocks
-  if (found_p && (!found || pc.mrep == 3 || pc.stride == 2 || pc.cout == 48)) {
+  if (!memo_hit && found_p && (!found || pc.mrep == 3 || pc.stride == 2 || pc.cout == 48)) {
     found = true; b_th = p_th; b_tw = p_tw; b_nseg = p_nseg; b_nr = p_nr; b_ps = p_ps; b_occ = 3;
   }
   SCP_REQUIRE(found, "conv m32: no tiling for %dx%d output", L.Ho, L.Wo);
+  memo.n = L.N; memo.ho = L.Ho; memo.wo = L.Wo; memo.th = b_th; memo.tw = b_tw; memo.nseg = b_nseg; memo.nr = b_nr; memo.ps = b_ps; memo.occ = b_occ;
   L.th = b_th; L.tw = b_tw; L.nt = b_nseg;
   L.tiles_x = (L.Wo + L.tw - 1) / L.tw;
   L.tiles_y = (L.Ho + L.th - 1) / L.th;

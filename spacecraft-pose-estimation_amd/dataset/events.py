@@ -2,7 +2,7 @@
 
   _get_db      :47-91   annotations[] order defines the row order of preds
   _box2cs      :94-113  center = (x + w/2, y + h/2) f32; scale = (w/200, h/200) * 1.5 f32
-  evaluate     :116-125 scipy.io.savemat(<output_dir>/<pred_file_name>.mat, {'preds': preds})
+  evaluate     :116-125 savemat(<output_dir>/<pred_file_name>.mat, {'preds': preds}) -- written by utils/matio.py (own Level-5 writer)
 Driver quirk absorbed: stage 1 writes real_test.json while stage 2 is told
 TEST_SET=test -> fall back to real_<set>.json when <set>.json is absent; and stage 3 is pointed
 at pred.mat while tools/test.py writes pred_test.mat -> both are written.
@@ -12,7 +12,7 @@ import logging
 import os
 
 import numpy as np
-from scipy.io import savemat
+from ..utils.matio import savemat
 
 from .JointsDataset import JointsDataset
 

@@ -15,7 +15,7 @@ from pathlib import Path
 
 import numpy as np
 import torch
-from scipy.io import loadmat
+from .utils.matio import loadmat
 
 from . import ops, parallel
 

@@ -56,6 +56,10 @@ CASES = [
     (64, 128, 3, 2, 32, 32, 2, False, True),
     (64, 32, 3, 2, 5, 33, 1, False, True),
     (64, 64, 3, 2, 1, 1, 5, False, False),
+    # stride 2 with channel counts outside the register-weight kernel's grid: producer/consumer kernel, 2-plane chunks
+    (48, 64, 3, 2, 24, 24, 2, False, True),
+    (96, 96, 3, 2, 20, 12, 2, False, False),
+    (64, 96, 3, 2, 16, 16, 1, False, True),
 ]
 
 
