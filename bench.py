@@ -237,10 +237,10 @@ def main():
     t0 = time.perf_counter()
     host = None
     # per-launch HIP events cost ~2.5 ms per forward (~280 records that break back-to-back dispatch), so they are
-    # recorded on every fifth timed step (at least one); the roofline figures average over those steps
+    # recorded on ONE step in ten of the timed region (at least one); the roofline figures average over those steps
     prof_steps = 0
     for i in range(args.steps):
-        prof = (i % 5 == min(2, args.steps - 1))
+        prof = (i % 10 == min(2, args.steps - 1))
         prof_steps += int(prof)
         host = step(prof)
     barrier()
@@ -317,7 +317,7 @@ def main():
                            "; %d frames per step frame-sharded over %d GPUs%s" % (world * B, world, " = BASELINE configs[3]" if world * B == 2048 and world == 8 else "") if world > 1 else ""),
                        "frames_per_step": world * B, "parallelism": "frame-sharded x%d, all-gather of (R,t,status); PnP/gather/D2H of step i overlap the forward of step i+1" % world,
                        "pnp_input": "decoded" if args.chained else "synthetic projected landmarks, 1 px noise, 10% outliers",
-                       "forward": ("hipGraph replay with concurrent branches (%d nodes); every fifth step eager with per-launch events" % graphs[0].nodes) if graphs else "eager launches",
+                       "forward": ("hipGraph replay with concurrent branches (%d nodes); one step in ten eager with per-launch events" % graphs[0].nodes) if graphs else "eager launches",
                        "launches_per_forward": st["launches"], "gflop_per_frame": round(st["flops_per_frame"] / 1e9, 3),
                        "act_mbytes_per_frame": round(st["act_bytes_per_frame"] / 1e6, 2)},
             "hrnet_forward_ms": round(fwd_ms, 3),

@@ -131,7 +131,7 @@ struct PackedConv {
   void* d_ws2 = nullptr;
   float* d_bs2 = nullptr;
 };
-bool conv_s2r_config(int cin, int cout, int* planes, int* nblk, int* g);
+bool conv_s2r_config(int cin, int cout, int stride, int* planes, int* nblk, int* g);
 size_t conv_s2r_pack(const float* w, int cout, int cin, int dtype, uint16_t* dst);
 void conv_s2r_pack_bias(const float* bias, int cout, float* dst);
 int32_t conv_s2r_launch(const PackedConv& pc, const void* in, int N, int H, int W, int relu, void* out, hipStream_t stream);

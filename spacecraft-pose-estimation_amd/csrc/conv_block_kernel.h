@@ -310,12 +310,11 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
         *reinterpret_cast<u32x4*>(static_cast<char*>(p.out) + (((size_t)img * PLANES + 2 * m + psel) * HW + (size_t)oy * p.W + ox) * 16) = ov;
     }
     const unsigned long long t6 = now();
-    // next input tile landed (this wave's share): its LDS-DMA was issued BEFORE this tile's MREP output stores and
-    // vector-memory operations retire in issue order, so waiting until at most MREP are outstanding covers the DMA
-    // without waiting for the stores (their round trip to HBM is then hidden under the next tile's conv1)
-    // (buffer-addressed path only: there every wave issues exactly MREP store instructions, masked pixels included)
-    if (p.dbg_buf || !buf) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(MREP) : "memory");
+    // next input tile landed (this wave's share).  (A counted wait that skips this tile's output stores -- they are younger
+    // than the DMA -- was tried and is WRONG: stores may retire before older loads, so "at most MREP outstanding" does not
+    // imply that the DMA has landed; it showed up as sporadic infinities in the W48 384x384 parity test.  Deferring the
+    // conv2 epilogue of waves 4-7 into the next tile (a stagger between the two waves of a SIMD) measured no gain either.)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                   // ... and the intermediate tile is free again
     if (p.dbg_buf) {   // [conv1 loop][conv1 epilogue][barrier][DMA issue][conv2 loop][conv2 epilogue + end wait/barrier]
       const unsigned long long t7 = now();

@@ -194,7 +194,7 @@ int32_t conv_upload(const float* w, const float* bias, int cout, int cin, int ks
   {   // 3x3 stride-2 layers with Cin = 32 / 48 / 64: register-weight kernel (conv_s2r.hip)
     static const char* e = dev_env("SCPOSE_S2R");
     int planes, nblk, g;
-    if (ks == 3 && stride == 2 && !(e && atoi(e) == 0) && conv_s2r_config(cin, cout, &planes, &nblk, &g)) {
+    if (ks == 3 && !(e && atoi(e) == 0) && conv_s2r_config(cin, cout, stride, &planes, &nblk, &g)) {
       std::vector<uint16_t> h2(conv_s2r_pack(w, cout, cin, dtype, nullptr) / 2);
       conv_s2r_pack(w, cout, cin, dtype, h2.data());
       std::vector<float> b2(cout);

@@ -23,8 +23,10 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 constexpr int kTH = 8, kTW = 16;
-constexpr int kMH = 2 * kTH + 1, kMW = 2 * kTW + 1, kMPix = kMH * kMW;   // 17 x 33 = 561 input pixels per tile
-constexpr int kMS = kMPix * 16;
+// input pixels a tile needs: stride 2: 17 x 33 = 561, stride 1: 10 x 18 = 180; plane pitch in 16-byte slots kept odd
+constexpr int tile_mh(int s) { return s * (kTH - 1) + 3; }
+constexpr int tile_mw(int s) { return s * (kTW - 1) + 3; }
+constexpr int tile_pitch(int s) { return (tile_mh(s) * tile_mw(s)) | 1; }
 
 struct S2rLaunch {
   const void* in;
@@ -43,8 +45,9 @@ inline int s2r_row_channel(int row) {
 
 }  // namespace
 
-template <int DT, int PLANES, int NBLK, int G>
+template <int DT, int PLANES, int NBLK, int G, int S>
 __global__ __launch_bounds__(512, 2) void conv_s2r_kernel(const S2rLaunch p) {
+  constexpr int kMW = tile_mw(S), kMPix = tile_mh(S) * tile_mw(S), kMS = tile_pitch(S) * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename DtOf<DT>::type T;
   typedef typename FragOf<T>::type frag_t;
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2r_kernel(const S2rLaunch p) {
     for (int piece = wave; piece < NSLOT; piece += 8) {
       const int slot = piece * 64 + lane;
       const int my = slot / kMW, mx = slot - my * kMW;
-      const int iy = 2 * oy0 - 1 + my, ix = 2 * ox0 - 1 + mx;
+      const int iy = S * oy0 - 1 + my, ix = S * ox0 - 1 + mx;
       const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       const uint32_t voff = ok ? (uint32_t)(img * PLANES * HW + iy * p.W + ix) * 16u : BUF_OOB;   // padding: read as zeros
       if (slot < kMPix) {   // lanes past the plane's last slot stay inactive: their LDS write would land in the next plane
@@ -129,12 +132,12 @@ __global__ __launch_bounds__(512, 2) void conv_s2r_kernel(const S2rLaunch p) {
 #pragma unroll
         for (int c = 0; c < CSTEP; ++c) acc[mb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int py0 = rset * NCOL + c0;
-      const char* bcol = xl + ((2 * py0) * kMW + 2 * r) * 16;
+      const char* bcol = xl + ((S * py0) * kMW + S * r) * 16;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         frag_t bf[CSTEP];
 #pragma unroll
-        for (int c = 0; c < CSTEP; ++c) bf[c] = *reinterpret_cast<const frag_t*>(bcol + c * (2 * kMW * 16) + koff[s]);
+        for (int c = 0; c < CSTEP; ++c) bf[c] = *reinterpret_cast<const frag_t*>(bcol + c * (S * kMW * 16) + koff[s]);
 #pragma unroll
         for (int mb = 0; mb < NBLK; ++mb)
 #pragma unroll
@@ -174,15 +177,16 @@ __global__ __launch_bounds__(512, 2) void conv_s2r_kernel(const S2rLaunch p) {
         store16_buf(rs_out, voff, 0u, __builtin_bit_cast(u32x4, ov));
       }
     }
-    // next tile landed (this wave's pieces): the DMA was issued before this tile's NBLK * NCOL / CSTEP output stores and
-    // vector-memory operations retire in issue order, so the stores themselves need not be waited for
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NBLK * (NCOL / CSTEP)) : "memory");
+    // next tile landed (this wave's pieces) -- vmcnt(0): stores may retire before older loads, so a counted wait that
+    // skips this tile's output stores would not guarantee the DMA has landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                          // ... and everybody is done with this buffer (LDS reads are consumed)
   }
 }
 
 // ---- host ----
-bool conv_s2r_config(int cin, int cout, int* planes, int* nblk, int* g) {
+bool conv_s2r_config(int cin, int cout, int stride, int* planes, int* nblk, int* g) {
+  if (stride == 1 && !(cin == 64 && cout == 64)) return false;   // stride 1: layer1's 3x3 (Bottleneck conv2, no residual)
   if (cin != 32 && cin != 48 && cin != 64) return false;
   const int nb = cin == 48 ? 3 : 2;            // 16-channel blocks per wave: 48 / 32 output channels per group
   if (cout % (16 * nb) != 0) return false;
@@ -216,10 +220,10 @@ void conv_s2r_pack_bias(const float* bias, int cout, float* dst) {
   for (int pos = 0; pos < cout; ++pos) dst[pos] = bias ? bias[(pos & ~15) + s2r_row_channel(pos & 15)] : 0.f;
 }
 
-template <int DT, int PLANES, int NBLK, int G>
+template <int DT, int PLANES, int NBLK, int G, int S = 2>
 static int32_t s2r_launch_one(const S2rLaunch& L, hipStream_t st) {
-  auto kern = conv_s2r_kernel<DT, PLANES, NBLK, G>;
-  const size_t lds = 2 * (size_t)PLANES * kMS;
+  auto kern = conv_s2r_kernel<DT, PLANES, NBLK, G, S>;
+  const size_t lds = 2 * (size_t)PLANES * tile_pitch(S) * 16;
   static LdsOptIn big;
   { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(kern), (int)lds, &big); if (rc != SCPOSE_OK) return rc; }
   hipLaunchKernelGGL(kern, dim3(L.grid), dim3(512), lds, st, L);
@@ -228,7 +232,8 @@ static int32_t s2r_launch_one(const S2rLaunch& L, hipStream_t st) {
 }
 
 template <int DT>
-static int32_t s2r_dispatch(int planes, int g, const S2rLaunch& L, hipStream_t st) {
+static int32_t s2r_dispatch(int planes, int g, int stride, const S2rLaunch& L, hipStream_t st) {
+  if (stride == 1) return s2r_launch_one<DT, 8, 2, 2, 1>(L, st);
   if (planes == 6) { if (g == 1) return s2r_launch_one<DT, 6, 3, 1>(L, st); if (g == 2) return s2r_launch_one<DT, 6, 3, 2>(L, st); return s2r_launch_one<DT, 6, 3, 4>(L, st); }
   if (planes == 4) { if (g == 1) return s2r_launch_one<DT, 4, 2, 1>(L, st); if (g == 2) return s2r_launch_one<DT, 4, 2, 2>(L, st); return s2r_launch_one<DT, 4, 2, 4>(L, st); }
   if (g == 1) return s2r_launch_one<DT, 8, 2, 1>(L, st);
@@ -238,12 +243,12 @@ static int32_t s2r_dispatch(int planes, int g, const S2rLaunch& L, hipStream_t s
 
 int32_t conv_s2r_launch(const PackedConv& pc, const void* in, int N, int H, int W, int relu, void* out, hipStream_t stream) {
   int planes, nblk, g;
-  SCP_REQUIRE(conv_s2r_config(pc.cin, pc.cout, &planes, &nblk, &g) && pc.d_ws2, "conv s2r: %d->%d not eligible", pc.cin, pc.cout);
+  SCP_REQUIRE(conv_s2r_config(pc.cin, pc.cout, pc.stride, &planes, &nblk, &g) && pc.d_ws2, "conv s2r: %d->%d not eligible", pc.cin, pc.cout);
   S2rLaunch L{};
   L.in = in; L.w = pc.d_ws2; L.bias = pc.d_bs2; L.out = out;
   L.in_bytes = (uint32_t)((size_t)N * planes * H * W * 16);
-  L.out_bytes = (uint32_t)((size_t)N * (pc.cout / 8) * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * 16);
-  L.N = N; L.H = H; L.W = W; L.Ho = (H - 1) / 2 + 1; L.Wo = (W - 1) / 2 + 1;
+  L.out_bytes = (uint32_t)((size_t)N * (pc.cout / 8) * ((H - 1) / pc.stride + 1) * ((W - 1) / pc.stride + 1) * 16);
+  L.N = N; L.H = H; L.W = W; L.Ho = (H - 1) / pc.stride + 1; L.Wo = (W - 1) / pc.stride + 1;
   L.cout_planes = pc.cout / 8; L.relu = relu;
   L.tiles_x = (L.Wo + kTW - 1) / kTW; L.tiles_y = (L.Ho + kTH - 1) / kTH;
   L.tiles_total = N * L.tiles_x * L.tiles_y;
@@ -251,8 +256,8 @@ int32_t conv_s2r_launch(const PackedConv& pc, const void* in, int N, int H, int 
   if (grid > L.tiles_total) grid = L.tiles_total;
   L.tiles_per_wg = (L.tiles_total + grid - 1) / grid;
   L.grid = (L.tiles_total + L.tiles_per_wg - 1) / L.tiles_per_wg;
-  if (pc.dtype == SCPOSE_DT_BF16) return s2r_dispatch<0>(planes, g, L, stream);
-  return s2r_dispatch<1>(planes, g, L, stream);
+  if (pc.dtype == SCPOSE_DT_BF16) return s2r_dispatch<0>(planes, g, pc.stride, L, stream);
+  return s2r_dispatch<1>(planes, g, pc.stride, L, stream);
 }
 
 }  // namespace scpose

@@ -56,6 +56,8 @@ CASES = [
     (64, 128, 3, 2, 32, 32, 2, False, True),
     (64, 32, 3, 2, 5, 33, 1, False, True),
     (64, 64, 3, 2, 1, 1, 5, False, False),
+    (64, 64, 3, 1, 20, 12, 3, False, True),     # register-weight kernel, stride 1 (layer1's 3x3), ragged map
+    (64, 64, 3, 1, 16, 16, 2, True, False),     # ... with a residual it stays on the 32x32x16 kernel
     # stride 2 with channel counts outside the register-weight kernel's grid: producer/consumer kernel, 2-plane chunks
     (48, 64, 3, 2, 24, 24, 2, False, True),
     (96, 96, 3, 2, 20, 12, 2, False, False),
