@@ -133,15 +133,25 @@ __global__ __launch_bounds__(512, 2) void conv_s2r_kernel(const S2rLaunch p) {
         for (int c = 0; c < CSTEP; ++c) acc[mb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int py0 = rset * NCOL + c0;
       const char* bcol = xl + ((S * py0) * kMW + S * r) * 16;
+      // fragments two k-steps ahead of the MFMAs that use them (left alone, the compiler issues each read right before its
+      // use and waits for it); the scheduling barriers pin that order
+      frag_t bf[3][CSTEP];
+#pragma unroll
+      for (int s0 = 0; s0 < 2 && s0 < KS; ++s0)
+#pragma unroll
+        for (int c = 0; c < CSTEP; ++c) bf[s0][c] = *reinterpret_cast<const frag_t*>(bcol + c * (S * kMW * 16) + koff[s0]);
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        frag_t bf[CSTEP];
+        if (s + 2 < KS) {
 #pragma unroll
-        for (int c = 0; c < CSTEP; ++c) bf[c] = *reinterpret_cast<const frag_t*>(bcol + c * (S * kMW * 16) + koff[s]);
+          for (int c = 0; c < CSTEP; ++c) bf[(s + 2) % 3][c] = *reinterpret_cast<const frag_t*>(bcol + c * (S * kMW * 16) + koff[s + 2]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mb = 0; mb < NBLK; ++mb)
 #pragma unroll
-          for (int c = 0; c < CSTEP; ++c) acc[mb][c] = mfma16<T>(wf[s][mb], bf[c], acc[mb][c]);
+          for (int c = 0; c < CSTEP; ++c) acc[mb][c] = mfma16<T>(wf[s][mb], bf[s % 3][c], acc[mb][c]);
+        __builtin_amdgcn_sched_barrier(0);
       }
       // epilogue: v_permlane32_swap gives the lower half-wave the 8 channels (plane 2 * block + psel) of column 0's
       // pixel and the upper half-wave those of column 1's (one column: the lower half-wave stores, the upper idles)

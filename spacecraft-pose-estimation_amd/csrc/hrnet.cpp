@@ -71,7 +71,7 @@ static bool fold(Weights& W, const std::string& conv, const std::string& bn, int
   return true;
 }
 
-enum OpKind { OP_STEM = 0, OP_CONV = 1, OP_FUSE = 2, OP_BLOCK = 3, OP_HEAD = 4, OP_STEM2 = 5 };   // OP_STEM2: fused stem (stem_fused.hip)   // OP_BLOCK: fused BasicBlock (conv_block_kernel.h); OP_HEAD: head.hip
+enum OpKind { OP_STEM = 0, OP_CONV = 1, OP_FUSE = 2, OP_BLOCK = 3, OP_HEAD = 4, OP_STEM2 = 5, OP_BNECK = 6 };   // OP_STEM2: fused stem (stem_fused.hip); OP_BNECK: fused Bottleneck (bottleneck.hip)   // OP_BLOCK: fused BasicBlock (conv_block_kernel.h); OP_HEAD: head.hip
 
 struct TensorDesc {
   int C, ds;       // channels, log2 spatial downscale w.r.t. the network input
@@ -113,6 +113,8 @@ struct scpose_hrnet {
   void* d_stemf_w2 = nullptr;
   float* d_stemf_b1 = nullptr;
   float* d_stemf_b2 = nullptr;
+  struct Bneck { void* w1 = nullptr; void* w2 = nullptr; void* w3 = nullptr; float* bias = nullptr; };   // fused Bottlenecks (bottleneck.hip)
+  std::vector<Bneck> bnecks;
   float* d_head_bias = nullptr; // [4][16] folded biases of the hrnet_cms heads
   int head_k = 0, head_s = 1;   // transposed-conv kernel / stride of the heads (heat-map = S * branch-0 size)
   std::vector<scpose::TensorDesc> tensors;
@@ -193,6 +195,29 @@ struct Builder {
     op.kind = OP_CONV; op.in = xa; op.in2 = xb + 1; op.res = -1; op.conv = (int)net->convs.size() - 1;
     op.relu = relu; op.out_f32 = 0;
     op.out = new_tensor(cout, net->tensors[xa].ds);
+    push(op);
+    return op.out;
+  }
+  // Bottleneck with identity residual (layer1 blocks 1-3, pose_hrnet.py:78-98): one fused launch (bottleneck.hip)
+  int bottleneck(int x, const std::string& p) {
+    if (status != SCPOSE_OK) return -1;
+    std::vector<float> w1, b1, w2, b2, w3, b3;
+    if (!fold(*W, p + ".conv1", p + ".bn1", 64, 256, 1, false, &w1, &b1) || !fold(*W, p + ".conv2", p + ".bn2", 64, 64, 3, false, &w2, &b2) ||
+        !fold(*W, p + ".conv3", p + ".bn3", 256, 64, 1, false, &w3, &b3)) { status = SCPOSE_E_MISSING; return -1; }
+    std::vector<uint16_t> pw1, pw2, pw3;
+    std::vector<float> pb;
+    bottleneck_pack(w1.data(), w2.data(), w3.data(), b1.data(), b2.data(), b3.data(), net->desc.dtype, &pw1, &pw2, &pw3, &pb);
+    scpose_hrnet::Bneck bn;
+    auto up = [&](void** d, const void* h, size_t bytes) {
+      if (hipMalloc(d, bytes) != hipSuccess || hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) != hipSuccess) status = SCPOSE_E_HIP;
+    };
+    up(&bn.w1, pw1.data(), pw1.size() * 2); up(&bn.w2, pw2.data(), pw2.size() * 2); up(&bn.w3, pw3.data(), pw3.size() * 2);
+    up(reinterpret_cast<void**>(&bn.bias), pb.data(), pb.size() * 4);
+    net->bnecks.push_back(bn);
+    if (status != SCPOSE_OK) { set_error("hrnet_create: uploading the fused Bottleneck weights failed"); return -1; }
+    Op op{};
+    op.kind = OP_BNECK; op.in = x; op.res = -1; op.conv = (int)net->bnecks.size() - 1; op.relu = 1;
+    op.out = new_tensor(256, net->tensors[x].ds);
     push(op);
     return op.out;
   }
@@ -333,6 +358,11 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
     const std::string p = fmt("layer1.%d", b);
     static const char* cat_env = dev_env("SCPOSE_CAT_DOWNSAMPLE");
     const bool cat = b == 0 && !(cat_env && atoi(cat_env) == 0);
+    static const char* bn_env = dev_env("SCPOSE_BNECK_FUSED");
+    if (b > 0 && net->tensors[x].C == 256 && !(bn_env && atoi(bn_env) == 0)) {   // identity-residual Bottleneck: one launch
+      x = B.bottleneck(x, p);
+      continue;
+    }
     int res = x;
     if (b == 0 && !cat) res = B.conv(x, p + ".downsample.0", p + ".downsample.1", 256, 1, 1, false);
     int y = B.conv(x, p + ".conv1", p + ".bn1", 64, 1, 1, true);
@@ -593,6 +623,10 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
       rc = head_gather_launch(ptr(op.in), net->d_head_bias + op.head * 16, static_cast<const float*>(ptr(op.res)), n,
                               net->desc.num_joints, h >> ti.ds, w >> ti.ds, net->head_k, net->head_s,
                               net->desc.dtype, out, st);
+    } else if (op.kind == OP_BNECK) {
+      const TensorDesc& ti = net->tensors[op.in];
+      const scpose_hrnet::Bneck& bn = net->bnecks[op.conv];
+      rc = bottleneck_launch(ptr(op.in), bn.w1, bn.w2, bn.w3, bn.bias, n, h >> ti.ds, w >> ti.ds, net->desc.dtype, ptr(op.out), st);
     } else if (op.kind == OP_BLOCK) {
       const TensorDesc& ti = net->tensors[op.in];
       rc = block_launch(net->convs[op.conv], net->convs[op.conv2], ptr(op.in), n, h >> ti.ds, w >> ti.ds, ptr(op.out), st);
@@ -649,6 +683,14 @@ static void op_work(const scpose_hrnet* net, const Op& op, int h, int w, double*
     *f = 2.0 * 2.0 * pc.cin * pc.cout * 9 * hi * wi;
     *by = (unfused ? 5.0 : 2.0) * pc.cin * hi * wi * 2;
     sig[1] = 31; sig[2] = pc.cin; sig[3] = pc.cout;
+  } else if (op.kind == OP_BNECK) {
+    // flops of the three convolutions; bytes: the launch reads x once and writes y once (unfused accounting: conv1 in + out,
+    // conv2 in + out, conv3 in + residual + out)
+    const TensorDesc& ti = net->tensors[op.in];
+    const double px = (double)(h >> ti.ds) * (w >> ti.ds);
+    *f = 2.0 * px * (256.0 * 64 + 64.0 * 64 * 9 + 64.0 * 256);
+    *by = px * 2 * (unfused ? (256 + 64) + (64 + 64) + (64 + 256 + 256) : 256 + 256);
+    sig[1] = 131; sig[2] = 256; sig[3] = 256;
   } else if (op.kind == OP_HEAD) {
     const TensorDesc& ti = net->tensors[op.in];
     const double hi = h >> ti.ds, wi = w >> ti.ds, S = net->head_s, J = net->desc.num_joints;
@@ -681,6 +723,12 @@ void hrnet_free(scpose_hrnet* net) {
   if (net->d_stem_w) (void)hipFree(net->d_stem_w);
   if (net->d_stem_b) (void)hipFree(net->d_stem_b);
   if (net->d_mean_std) (void)hipFree(net->d_mean_std);
+  for (auto& bn : net->bnecks) {
+    if (bn.w1) (void)hipFree(bn.w1);
+    if (bn.w2) (void)hipFree(bn.w2);
+    if (bn.w3) (void)hipFree(bn.w3);
+    if (bn.bias) (void)hipFree(bn.bias);
+  }
   if (net->d_stemf_w1) (void)hipFree(net->d_stemf_w1);
   if (net->d_stemf_w2) (void)hipFree(net->d_stemf_w2);
   if (net->d_stemf_b1) (void)hipFree(net->d_stemf_b1);

@@ -245,15 +245,25 @@ __global__ __launch_bounds__(512, 2) void stem_fused_kernel(const StemFusedLaunc
     for (int mb = 0; mb < 2; ++mb) { acc[mb][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mb][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const char* bcol0 = mid + ((2 * (2 * cpair)) * kMW + 2 * r) * 16;
     const char* bcol1 = bcol0 + 2 * kMW * 16;
+    frag_t bq[3][2];                                       // fragments two k-steps ahead (see conv_s2r.hip)
+#pragma unroll
+    for (int s0 = 0; s0 < 2; ++s0) {
+      bq[s0][0] = *reinterpret_cast<const frag_t*>(bcol0 + k2[s0]);
+      bq[s0][1] = *reinterpret_cast<const frag_t*>(bcol1 + k2[s0]);
+    }
 #pragma unroll
     for (int s = 0; s < 18; ++s) {
-      const frag_t b0f = *reinterpret_cast<const frag_t*>(bcol0 + k2[s]);
-      const frag_t b1f = *reinterpret_cast<const frag_t*>(bcol1 + k2[s]);
+      if (s + 2 < 18) {
+        bq[(s + 2) % 3][0] = *reinterpret_cast<const frag_t*>(bcol0 + k2[s + 2]);
+        bq[(s + 2) % 3][1] = *reinterpret_cast<const frag_t*>(bcol1 + k2[s + 2]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
-        acc[mb][0] = mfma16<T>(w2f[s][mb], b0f, acc[mb][0]);
-        acc[mb][1] = mfma16<T>(w2f[s][mb], b1f, acc[mb][1]);
+        acc[mb][0] = mfma16<T>(w2f[s][mb], bq[s % 3][0], acc[mb][0]);
+        acc[mb][1] = mfma16<T>(w2f[s][mb], bq[s % 3][1], acc[mb][1]);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     // lower half-wave: column 0's pixel, upper half-wave: column 1's; each lane ends up with the 8 channels of plane
     // 2 * block + psel of its pixel
