@@ -50,13 +50,7 @@ __device__ __forceinline__ c1_f32x4 c1_mfma(u32x4 a, u32x4 b, c1_f32x4 c) {
 #endif
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ u32x4 load16_buf(buf_rsrc_t r, uint32_t voff, uint32_t soff) {
-  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-}
-#else
-__device__ inline u32x4 load16_buf(buf_rsrc_t, uint32_t, uint32_t) { return u32x4{0u, 0u, 0u, 0u}; }
-#endif
+// load16_buf: conv_pipe_kernel.h
 
 // OCC = workgroups (4 waves each) per CU the register budget is cut for: more waves in flight for the long-K layers,
 // whose fragments are the bulk of the registers (KSTEPS * NG * 4 per lane)
