@@ -79,17 +79,21 @@ size_t pack_conv_weights_m32(const float* w, int cout, int cin, int ks, int mt, 
   return total * 2;
 }
 
-// producer/consumer kernel: weights stay resident (all chunks in LDS) when the layer has one Cout block and they fit
-static int m32p_wbufs(const PackedConv& pc, int plane_stride, int nr) {
-  const size_t lds_w = (size_t)pc.ksteps_full * 2 * pc.mt * 16;
+// producer/consumer kernel, K-chunks of `cp` planes (a launch-time choice: the packed image of a 2*cp-plane chunk is the
+// images of its two cp-plane chunks back to back, and K is accumulated in the same order whatever the chunking):
+// weights stay resident (all chunks in LDS) when the layer has one Cout block and they fit
+struct M32pChunking { int cp, nchunks, ksteps_full; };
+static M32pChunking m32p_chunking(const PackedConv& pc, int cp) { return {cp, (pc.cin / 8) / cp, (cp / 2) * pc.ks * pc.ks}; }
+static int m32p_wbufs(const PackedConv& pc, const M32pChunking& ck, int plane_stride, int nr) {
+  const size_t lds_w = (size_t)ck.ksteps_full * 2 * pc.mt * 16;
   const size_t lds_bias = (((size_t)pc.n_mblk * pc.mt * 4) + 511) & ~(size_t)511;
-  const size_t rest = lds_bias + 2 * (size_t)pc.cp * plane_stride + (size_t)(pc.mt / 8) * (4 * nr * 32) * 16;
-  return (pc.n_mblk == 1 && pc.nchunks > 2 && rest + pc.nchunks * lds_w <= 160 * 1024) ? pc.nchunks : 2;
+  const size_t rest = lds_bias + 2 * (size_t)ck.cp * plane_stride + (size_t)(pc.mt / 8) * (4 * nr * 32) * 16;
+  return (pc.n_mblk == 1 && ck.nchunks > 2 && rest + ck.nchunks * lds_w <= 160 * 1024) ? ck.nchunks : 2;
 }
-static size_t m32p_lds_bytes(const PackedConv& pc, int plane_stride, int nr) {
-  const size_t lds_w = (size_t)pc.ksteps_full * 2 * pc.mt * 16;
+static size_t m32p_lds_bytes(const PackedConv& pc, const M32pChunking& ck, int plane_stride, int nr) {
+  const size_t lds_w = (size_t)ck.ksteps_full * 2 * pc.mt * 16;
   const size_t lds_bias = (((size_t)pc.n_mblk * pc.mt * 4) + 511) & ~(size_t)511;
-  return lds_bias + m32p_wbufs(pc, plane_stride, nr) * lds_w + 2 * (size_t)pc.cp * plane_stride + (size_t)(pc.mt / 8) * (4 * nr * 32) * 16;
+  return lds_bias + m32p_wbufs(pc, ck, plane_stride, nr) * lds_w + 2 * (size_t)ck.cp * plane_stride + (size_t)(pc.mt / 8) * (4 * nr * 32) * 16;
 }
 
 static size_t m32_lds_bytes(const PackedConv& pc, int plane_stride) {
@@ -108,15 +112,16 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   // (one computes while the other is stalled in its memory instructions), then pixels per weight chunk
   double best = -1e30, best_p = 1e30;
   bool found = false, found_p = false;
-  int b_th = 0, b_tw = 0, b_nseg = 0, b_nr = 0, b_ps = 0, b_occ = 1;
-  int p_th = 0, p_tw = 0, p_nseg = 0, p_nr = 0, p_ps = 0;   // best producer/consumer candidate (cost model)
+  int b_th = 0, b_tw = 0, b_nseg = 0, b_nr = 0, b_ps = 0, b_occ = 1, b_cp = pc.cp;
+  long b_items = 0;
+  int p_th = 0, p_tw = 0, p_nseg = 0, p_nr = 0, p_ps = 0, p_cp = pc.cp;   // best producer/consumer candidate (cost model)
   const int cus = conv_device_cus();
   const int tw_cand[8] = {L.Wo, 64, 48, 32, 24, 16, 12, 8};
   // the search below depends on (layer, N, Ho, Wo) only: its result is remembered in the layer (a forward launches the
   // same shapes every time; small batches are launch-bound on the host)
   PackedConv::TileMemo& memo = pc.m32_memo;
   const bool memo_hit = memo.n == L.N && memo.ho == L.Ho && memo.wo == L.Wo && !dev_env("SCPOSE_M32_OCC") && !dev_env("SCPOSE_M32_NR");
-  if (memo_hit) { found = true; b_th = memo.th; b_tw = memo.tw; b_nseg = memo.nseg; b_nr = memo.nr; b_ps = memo.ps; b_occ = memo.occ; }
+  if (memo_hit) { found = true; b_th = memo.th; b_tw = memo.tw; b_nseg = memo.nseg; b_nr = memo.nr; b_ps = memo.ps; b_occ = memo.occ; b_cp = memo.cp; }
   for (const M32Variant& v : kVariants) {
     if (memo_hit) break;
     static const char* nr_env = dev_env("SCPOSE_M32_NR");   // development: restrict the search to one column count
@@ -135,51 +140,67 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
         for (int nseg = 1; nseg <= 8; ++nseg) {
           if (nseg * th * tw > cap || nseg * hh * hw > halo_cap) break;
           const int ps = (nseg * hh * hw * 16 + 255) & ~255;
-          if ((v.occ == 3 ? m32p_lds_bytes(pc, ps, nr) : m32_lds_bytes(pc, ps)) > lds_cap) break;
+          if (v.occ != 3 && m32_lds_bytes(pc, ps) > lds_cap) break;
           const int tx = (L.Wo + tw - 1) / tw, ty = (L.Ho + th - 1) / th;
           const double eff = (double)L.Ho * L.Wo / ((double)tx * ty / nseg * cap);
           // measured preference: producer/consumer for 96-row blocks, two workgroups per CU for 64-row blocks
           const double pref = v.occ == 3 ? (v.mr == 3 ? 1.5 : 1.1) : v.occ == 2 ? 1.25 : 1.0;
+          const long items = (((long)L.N * tx * ty + nseg - 1) / nseg) * pc.n_mblk;
           if (v.occ == 3) {
             // producer/consumer candidates are ranked by a cycle model fitted to the phase stamps:
-            // stage = max(consumer MFMAs, producer bytes at ~13 B/clk) + barrier; items are quantised per CU
-            const long items = (((long)L.N * tx * ty + nseg - 1) / nseg) * pc.n_mblk;
-            const double per_cu = (double)((items + cus - 1) / cus);
-            const double mfma = (double)v.mr * nr * (pc.cp / 2) * pc.ks * pc.ks * 32.0 * 1.35;
-            const bool res_w = m32p_wbufs(pc, ps, nr) > 2;
-            const double bytes = (res_w ? 0.0 : (double)pc.ksteps_full * 2 * pc.mt * 16) + (double)pc.cp * ps +
-                                 2.0 * pc.mt * (nseg * th * tw) * 2 / pc.nchunks;
-            const double stage = (mfma > bytes / 13.0 ? mfma : bytes / 13.0) + 700.0;
-            const double cost = per_cu * (pc.nchunks * stage + (double)v.mr * nr * 16 * 25.0);
-            if (cost < best_p) { found_p = true; best_p = cost; p_th = th; p_tw = tw; p_nseg = nseg; p_nr = nr; p_ps = ps; }
+            // stage = max(consumer MFMAs, producer bytes at ~13 B/clk) + barrier, but never shorter than the round trip of
+            // the stage's LDS-DMA (small tiles: the stage count, not the MFMAs, sets the time -> deeper K-chunks);
+            // items are quantised per CU
+            bool any = false;
+            for (int mul = 1; mul <= 4; mul *= 2) {
+              const int cp = pc.cp * mul;
+              if ((mul > 1 && pc.cp != 2) || (pc.cin / 8) % cp != 0) continue;
+              const M32pChunking ck = m32p_chunking(pc, cp);
+              if (ck.nchunks < 3 || m32p_lds_bytes(pc, ck, ps, nr) > lds_cap) continue;
+              any = true;
+              const double per_cu = (double)((items + cus - 1) / cus);
+              const double mfma = (double)v.mr * nr * (cp / 2) * pc.ks * pc.ks * 32.0 * 1.35;
+              const bool res_w = m32p_wbufs(pc, ck, ps, nr) > 2;
+              const double bytes = (res_w ? 0.0 : (double)ck.ksteps_full * 2 * pc.mt * 16) + (double)cp * ps +
+                                   2.0 * pc.mt * (nseg * th * tw) * 2 / ck.nchunks;
+              double stage = (mfma > bytes / 13.0 ? mfma : bytes / 13.0) + 700.0;
+              if (stage < 2600.0) stage = 2600.0;
+              const double cost = per_cu * (ck.nchunks * stage + (double)v.mr * nr * 16 * 25.0);
+              if (cost < best_p) { found_p = true; best_p = cost; p_th = th; p_tw = tw; p_nseg = nseg; p_nr = nr; p_ps = ps; p_cp = cp; }
+            }
+            if (!any) break;
             continue;
           }
           const double score = eff * pref / (1.0 + 2.0 / (wn * nr)) - 0.02 * (double)(hh * hw) / (th * tw);
-          if (score > best) { found = true; best = score; b_th = th; b_tw = tw; b_nseg = nseg; b_nr = nr; b_ps = ps; b_occ = v.occ; }
+          if (score > best) { found = true; best = score; b_th = th; b_tw = tw; b_nseg = nseg; b_nr = nr; b_ps = ps; b_occ = v.occ; b_items = items; }
         }
       }
     }
   }
-  // measured preference: producer/consumer for 96-row blocks and for stride 2, two workgroups per CU for 64-row blocks
-  if (!memo_hit && found_p && (!found || pc.mrep == 3 || pc.stride == 2 || pc.cout == 48)) {
-    found = true; b_th = p_th; b_tw = p_tw; b_nseg = p_nseg; b_nr = p_nr; b_ps = p_ps; b_occ = 3;
+  // measured preference: producer/consumer for 96-row blocks and for stride 2, two workgroups per CU for 64-row blocks --
+  // unless those would leave the chip under-filled (at most one round of items: small batches, deep branches), where the
+  // layer is a chain of DMA round trips and the small-tile producer/consumer candidates are 1.7-2x faster
+  // (W32 batch 64: 128->128 @16x16 30.8 -> 14.9 us, 256->256 @8x8 40.1 -> 23.0 us before deeper chunks)
+  if (!memo_hit && found_p && (!found || pc.mrep == 3 || pc.stride == 2 || pc.cout == 48 || b_items <= (long)cus * b_occ)) {
+    found = true; b_th = p_th; b_tw = p_tw; b_nseg = p_nseg; b_nr = p_nr; b_ps = p_ps; b_occ = 3; b_cp = p_cp;
   }
   SCP_REQUIRE(found, "conv m32: no tiling for %dx%d output", L.Ho, L.Wo);
-  memo.n = L.N; memo.ho = L.Ho; memo.wo = L.Wo; memo.th = b_th; memo.tw = b_tw; memo.nseg = b_nseg; memo.nr = b_nr; memo.ps = b_ps; memo.occ = b_occ;
+  memo.n = L.N; memo.ho = L.Ho; memo.wo = L.Wo; memo.th = b_th; memo.tw = b_tw; memo.nseg = b_nseg; memo.nr = b_nr; memo.ps = b_ps; memo.occ = b_occ; memo.cp = b_cp;
   L.th = b_th; L.tw = b_tw; L.nt = b_nseg;
   L.tiles_x = (L.Wo + L.tw - 1) / L.tw;
   L.tiles_y = (L.Ho + L.th - 1) / L.th;
   L.halo_h = (L.th - 1) * pc.stride + 1 + 2 * k2;
   L.halo_w = (L.tw - 1) * pc.stride + 1 + 2 * k2;
   L.plane_stride = b_ps;
-  L.cp = pc.cp; L.nchunks = pc.nchunks; L.ksteps_full = pc.ksteps_full; L.n_mblk = pc.n_mblk;
-  L.lds_w = pc.ksteps_full * 2 * pc.mt * 16;
-  L.lds_x = pc.cp * L.plane_stride;
+  const M32pChunking ck = b_occ == 3 ? m32p_chunking(pc, b_cp) : M32pChunking{pc.cp, pc.nchunks, pc.ksteps_full};
+  L.cp = ck.cp; L.nchunks = ck.nchunks; L.ksteps_full = ck.ksteps_full; L.n_mblk = pc.n_mblk;
+  L.lds_w = ck.ksteps_full * 2 * pc.mt * 16;
+  L.lds_x = ck.cp * L.plane_stride;
   L.lds_bias = ((pc.n_mblk * pc.mt * 4) + 511) & ~511;
-  L.nbuf_w = b_occ == 3 ? m32p_wbufs(pc, L.plane_stride, b_nr) : (pc.nchunks == 1 && pc.n_mblk == 1) ? 1 : 2;
+  L.nbuf_w = b_occ == 3 ? m32p_wbufs(pc, ck, L.plane_stride, b_nr) : (pc.nchunks == 1 && pc.n_mblk == 1) ? 1 : 2;
   L.nbuf_x = 2;
   L.groups = 1;
-  const size_t lds = b_occ == 3 ? m32p_lds_bytes(pc, L.plane_stride, b_nr) : m32_lds_bytes(pc, L.plane_stride);
+  const size_t lds = b_occ == 3 ? m32p_lds_bytes(pc, ck, L.plane_stride, b_nr) : m32_lds_bytes(pc, L.plane_stride);
   L.zero16 = conv_zero_page();
   SCP_REQUIRE(L.zero16, "conv: cannot allocate the zero page");
   L.tiles_total = L.N * L.tiles_x * L.tiles_y;
@@ -197,8 +218,8 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   L.dbg_buf = nullptr;
   if (L.dbg & 8) L.dbg_buf = conv_dbg_buffer(stream);
   if (L.dbg & 32)
-    fprintf(stderr, "m32 %d->%d %dx%d: mr=%d nr=%d occ=%d tile %dx%d nseg=%d halo %dx%d lds=%zu items=%d\n", pc.cin, pc.cout, L.Ho, L.Wo,
-            pc.mrep, b_nr, b_occ, L.th, L.tw, L.nt, L.halo_h, L.halo_w, lds, L.items_total);
+    fprintf(stderr, "m32 %d->%d %dx%d: mr=%d nr=%d occ=%d cp=%d tile %dx%d nseg=%d halo %dx%d lds=%zu items=%d\n", pc.cin, pc.cout, L.Ho, L.Wo,
+            pc.mrep, b_nr, b_occ, L.cp, L.th, L.tw, L.nt, L.halo_h, L.halo_w, lds, L.items_total);
   L.fd_npix = make_fastdiv(L.th * L.tw); L.fd_tw = make_fastdiv(L.tw);
   L.fd_hp = make_fastdiv(L.halo_h * L.halo_w); L.fd_halo_w = make_fastdiv(L.halo_w);
   L.fd_tiles_img = make_fastdiv(L.tiles_x * L.tiles_y); L.fd_tiles_x = make_fastdiv(L.tiles_x);
@@ -211,7 +232,7 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   if (b_occ == 3) {
     // L.groups doubles as "K-chunks of weights held in producer registers" for the producer/consumer kernel
     static const char* wr_env = dev_env("SCPOSE_M32_WREG");
-    L.groups = (pc.n_mblk == 1 && pc.nchunks == 6 && pc.stride == 1 && pc.mrep == 3 && b_nr == 3 && !(wr_env && atoi(wr_env) == 0)) ? 6 : 1;
+    L.groups = (pc.n_mblk == 1 && ck.nchunks == 6 && ck.cp == 2 && pc.stride == 1 && pc.mrep == 3 && b_nr == 3 && !(wr_env && atoi(wr_env) == 0)) ? 6 : 1;
     if (pc.dtype == SCPOSE_DT_BF16) return conv_m32p_dispatch_bf16(pc.stride, pc.mrep, b_nr, L, lds, stream);
     return conv_m32p_dispatch_f16(pc.stride, pc.mrep, b_nr, L, lds, stream);
   }
