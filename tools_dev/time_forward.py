@@ -23,7 +23,7 @@ print("stats", st, "workspace GB", eng.workspace_bytes(n, size, size) / 1e9)
 for _ in range(2):
     y = eng(x)
 torch.cuda.synchronize()
-iters = 5
+iters = int(os.environ.get("ITERS", "5"))
 t = time.time()
 for _ in range(iters):
     y = eng(x)
