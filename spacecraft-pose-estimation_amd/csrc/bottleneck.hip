@@ -7,18 +7,33 @@
 // for 1.0 ms at 5.0-5.4 TB/s (12 % of the forward for 4 % of its FLOPs).  Fused, HBM sees x once (plus the halo
 // overlap of neighbouring tiles, mostly served by L2) and y once.
 //
-// One 512-thread workgroup per CU, persistent over tiles of 8 x 8 output pixels.  LDS (156.6 KB):
-//   x tile   2 x [32 planes][10 x 10 halo pixels][16 B]   double-buffered, LDS-DMA: also the residual of phase C
-//   t1 tile  [8 planes][10 x 10][16 B]                    conv1 output on the halo (zero outside the image)
-//   t2 tile  [8 planes][8 x 8][16 B]                      conv2 output
-//   W1       [8 k-steps][4 blocks][4 k-groups][16 rows][16 B] = 32 KB (conv1's weights; conv2's and conv3's live in registers)
-// Per tile, three phases separated by workgroup barriers:
-//   A  conv1 on the 100 halo pixels (7 columns of 16): a wave owns 32 output channels and two columns;
-//      bias + ReLU + 16-bit rounding -> t1 (the value the unfused path stores)
-//   B  conv2 (3x3) on the 64 output pixels: a wave owns 32 output channels x one column (two tile rows), its
-//      2 x 18 weight fragments in 144 VGPRs; bias + ReLU + rounding -> t2
-//   C  conv3 on the 64 pixels: a wave owns 32 of the 256 output channels x all four columns; bias, lane exchange,
-//      + residual (centre of the x tile), ReLU, 16-byte stores.
+// One 512-thread workgroup per CU, persistent over tiles of 16 x 16 output pixels.  x is never staged in LDS: conv1 is
+// a 1x1 convolution, so a lane's B fragment is one 16-byte vector of the blocked layout and comes straight from global
+// memory into registers (buffer loads, out-of-image halo pixels read as zeros); the residual of phase C is re-read the
+// same way.  LDS (108.8 KB):
+//   t1 tile  [8 planes][18 x 18 halo pixels][16 B]        conv1 output on the halo (zero outside the image)
+//   t2 tile  [8 planes][16 x 16][16 B]                    conv2 output
+//   W1       [8 k-steps][4 blocks][4 k-groups][16 rows][16 B] = 32 KB (conv1's weights)
+// Per tile, three phases and two workgroup barriers:
+//   A  conv1 on the 324 halo pixels (21 columns of 16): wave w owns columns w, w + 8, w + 16 and all four 16-channel
+//      blocks (one x vector feeds four MFMAs; no x vector is loaded by two waves).  Its 8 x 3 x vectors were requested a
+//      whole tile ahead (96 registers per wave = 192 KB in flight per CU); bias + ReLU + 16-bit rounding -> t1
+//   B  conv2 (3x3) on the 256 output pixels: a wave owns 32 output channels x four tile rows; its 2 x 18 weight
+//      fragments (144 registers) are re-read from L2 per tile at the end of phase A -- resident they would leave no
+//      room for the x and residual vectors; bias + ReLU + rounding -> t2
+//   C  every residual vector of the tile is requested up front (64 registers), then conv3 runs on the 256 pixels (a wave
+//      owns 32 of the 256 output channels, two tile rows at a time): bias, lane exchange, + residual, ReLU, 16-byte
+//      stores; row pair k first requests the next tile's x vectors of k-step k.  A wave's vector-memory operations
+//      complete in order, so a load issued behind stores cannot be used before those stores are acknowledged: with the
+//      residual loads only one to three row pairs ahead of their stores, phase C took 12 us per tile.  (The x requests
+//      do sit behind earlier pairs' stores, but are not needed before the next tile's phase A.)
+// Measured at batch 256, 96 x 96 (MI355X): 0.78 ms per launch (three layers: 1.00 ms).  Ablations: without the residual
+// reads 0.71 ms, without the stores 0.61 ms, without both 0.52 ms.  The first version of this kernel (8 x 8 tiles, x tile
+// double-buffered in LDS by LDS-DMA, three barriers per 64 pixels, 56 % halo recompute in conv1) was bound by LDS reads
+// at 0.89 ms; a version of this one with 3 k-steps of look-ahead and duplicated x loads was latency-bound at 0.97 ms.
+// Register-allocation notes: anything defined on only one path of the tile loop (an `if (next tile exists)` around the
+// requests) is live around the whole loop and spilled 91 registers; the requests therefore always run, with out-of-range
+// offsets on the last tile.
 // Rounding points are exactly those of the unfused layers, so the oracle's storage model is unchanged.
 #include "common.h"
 #include "conv_device.h"
@@ -28,13 +43,13 @@ namespace scpose {
 
 namespace {
 
-constexpr int kT = 8;                          // output tile edge
-constexpr int kHW = kT + 2, kHPix = kHW * kHW; // 10 x 10 halo pixels
-constexpr int kXS = (kHPix | 1) * 16;          // bytes of one x / t1 plane (101 slots: odd pitch)
-constexpr int kT2S = (kT * kT | 1) * 16;       // bytes of one t2 plane (65 slots)
-constexpr int kXBuf = 32 * kXS;                // one x tile
+constexpr int kT = 16;                         // output tile edge
+constexpr int kHW = kT + 2, kHPix = kHW * kHW; // 18 x 18 halo pixels
+constexpr int kCols1 = (kHPix + 15) / 16;      // 21 MFMA columns of conv1
+constexpr int kXS = (kHPix | 1) * 16;          // bytes of one t1 plane (325 slots: odd pitch)
+constexpr int kT2S = (kT * kT | 1) * 16;       // bytes of one t2 plane (257 slots)
 constexpr int kW1Bytes = 8 * 4 * 4 * 16 * 16;  // 32 KB
-constexpr int kLds = 2 * kXBuf + 8 * kXS + 8 * kT2S + kW1Bytes + (64 + 64 + 256) * 4;
+constexpr int kLds = 8 * kXS + 8 * kT2S + kW1Bytes + (64 + 64 + 256) * 4;
 
 struct BneckLaunch {
   const void* in;
@@ -48,6 +63,7 @@ struct BneckLaunch {
   uint32_t bytes;   // size of in (= out)
   int32_t N, H, W;
   int32_t tiles_x, tiles_y, tiles_total, tiles_per_wg, grid;
+  unsigned long long* dbg_buf;   // development (SCPOSE_BNECK_DBG=1): cycles per phase and wave
 };
 
 inline int bneck_row_channel(int row) {
@@ -62,8 +78,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename DtOf<DT>::type T;
   typedef typename FragOf<T>::type frag_t;
-  char* xl0 = smem;
-  char* t1l = smem + 2 * kXBuf;
+  char* t1l = smem;
   char* t2l = t1l + 8 * kXS;
   char* w1l = t2l + 8 * kT2S;
 
@@ -76,23 +91,19 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
   // ---- weights ----
   for (int o = tid * 16; o < kW1Bytes; o += 512 * 16)
     *reinterpret_cast<u32x4*>(w1l + o) = *reinterpret_cast<const u32x4*>(static_cast<const char*>(p.w1) + o);
-  frag_t w2f[18][2], w3f[2][2];
-#pragma unroll
-  for (int s = 0; s < 18; ++s)
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-      w2f[s][mb] = *reinterpret_cast<const frag_t*>(static_cast<const char*>(p.w2) + ((((size_t)s * 4 + 2 * ch + mb) * 4 + q) * 16 + r) * 16);
+  frag_t w3f[2][2];
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
       w3f[s][mb] = *reinterpret_cast<const frag_t*>(static_cast<const char*>(p.w3) + ((((size_t)s * 16 + 2 * wave + mb) * 4 + q) * 16 + r) * 16);
-  // biases stay in LDS (behind W1) and are re-read per phase: 24 VGPRs fewer, which is what keeps conv2's weights in registers
+  // biases stay in LDS (behind W1) and are re-read per phase
   float* bl = reinterpret_cast<float*>(w1l + kW1Bytes);
   for (int e = tid; e < 64 + 64 + 256; e += 512) bl[e] = e < 64 ? p.b1[e] : e < 128 ? p.b2[e - 64] : p.b3[e - 128];
   // conv2 operand addressing: k-step s, k-group q -> (tap, plane) pair 4 s + q: tap = s >> 1 (compile time),
   // plane = q + 4 (s & 1): one per-lane offset (q * plane pitch), everything else an immediate
   const int qoff = q * kXS;
+  const uint32_t w2vo = (uint32_t)(((2 * ch) * 4 + q) * 16 + r) * 16u;   // this lane's slot in a conv2 weight fragment; + (s * 4 + mb) * 1024
 
   const int wg = xcd_remap(blockIdx.x, p.grid);
   const int t_begin = wg * p.tiles_per_wg;
@@ -103,106 +114,130 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
     const int ty = rem / p.tiles_x;
     oy0 = ty * kT; ox0 = (rem - ty * p.tiles_x) * kT;
   };
-  const buf_rsrc_t rs_in = make_buf(p.in, p.bytes), rs_out = make_buf(p.out, p.bytes);
-  // LDS-DMA of the x halo tile of tile t into buffer b: 2 pieces of 64 slots per plane, 64 pieces; wave w takes planes 4w .. 4w + 3
-  auto issue_x = [&](int t, int b) {
+  const buf_rsrc_t rs_in = make_buf(p.in, p.bytes), rs_out = make_buf(p.out, p.bytes), rs_w2 = make_buf(p.w2, 18u * 4 * 4 * 16 * 16);
+  const uint32_t kstep_bytes = (uint32_t)(4 * HW) * 16u;     // four planes = one k-step of conv1
+
+  // conv1 columns of this wave: wave + 8 i, i = 0..2 (21 columns: the third exists for waves 0-4 only).
+  // vo[i] = byte offset of (image, plane q, halo pixel of this lane) in x, BUF_OOB outside the image / the halo
+  const bool has_col2 = wave + 16 < kCols1;
+  uint32_t vo[3];
+  auto locate = [&](int t) {
     int img, oy0, ox0;
     decode(t, img, oy0, ox0);
-    char* xl = xl0 + b * kXBuf;
 #pragma unroll
-    for (int piece = 0; piece < 2; ++piece) {
-      const int slot = piece * 64 + lane;
+    for (int i = 0; i < 3; ++i) {
+      const int slot = (wave + 8 * i) * 16 + r;
       const int my = slot / kHW, mx = slot - my * kHW;
-      const int iy = oy0 - 1 + my, ix = ox0 - 1 + mx;
-      const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      const uint32_t voff = ok ? (uint32_t)(img * 32 * HW + iy * p.W + ix) * 16u : BUF_OOB;   // padding: read as zeros
-      if (slot < kHPix) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int pl = 4 * wave + k;
-          dma16_buf(rs_in, voff, (uint32_t)(pl * HW) * 16u, xl + pl * kXS + piece * 1024);
-        }
-      }
+      const int gy = oy0 - 1 + my, gx = ox0 - 1 + mx;
+      const bool ok = slot < kHPix && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      vo[i] = ok ? (uint32_t)((img * 32 + q) * HW + gy * p.W + gx) * 16u : BUF_OOB;
     }
   };
+  // x vectors of conv1: all 8 k-steps of the wave's three columns (96 registers, 192 KB in flight per CU), requested
+  // one tile ahead -- at the start of the previous tile's phase C, BEFORE that phase's stores: a wave's vector-memory
+  // operations complete in order, so a load issued behind stores is not usable until those stores are acknowledged
+  // (measured: with loads and stores interleaved per row pair, phase C took 12 us per tile)
+  u32x4 xr[8][3];
+  auto request = [&](auto sc) {
+    constexpr int S = decltype(sc)::value;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      xr[S][i] = load16_buf(rs_in, vo[i], (uint32_t)S * kstep_bytes);   // a column that does not exist reads zeros (BUF_OOB)
+  };
+  auto request_head = [&]() {
+    request(std::integral_constant<int, 0>{}); request(std::integral_constant<int, 1>{});
+    request(std::integral_constant<int, 2>{}); request(std::integral_constant<int, 3>{});
+    request(std::integral_constant<int, 4>{}); request(std::integral_constant<int, 5>{});
+    request(std::integral_constant<int, 6>{}); request(std::integral_constant<int, 7>{});
+  };
 
-  if (t_begin < t_end) issue_x(t_begin, 0);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  if (t_begin < t_end) {
+    locate(t_begin);
+    request_head();
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                            // W1 and the biases are in LDS
 
-  int buf = 0;
-  for (int t = t_begin; t < t_end; ++t, buf ^= 1) {
+  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
+  auto now = [&]() -> unsigned long long { return p.dbg_buf ? __builtin_amdgcn_s_memtime() : 0ull; };
+  for (int t = t_begin; t < t_end; ++t) {
     int img, oy0, ox0;
     decode(t, img, oy0, ox0);
-    if (t + 1 < t_end) issue_x(t + 1, buf ^ 1);            // streams in under this tile's three phases
-    const char* xl = xl0 + buf * kXBuf;
+    const unsigned long long ts0 = now();
 
-    // ---- A: conv1 (1x1, 256 -> 64) on the halo pixels -> t1 ----
+    // ---- A: conv1 (1x1, 256 -> 64) on the halo pixels -> t1: all four 16-channel blocks of the wave's columns ----
+    frag_t w2f[18][2];                                     // conv2's weights of this wave: re-read per tile (below)
     {
-      f32x4 acc[2][2];                                     // accumulators start at the bias of their rows
+      f32x4 acc[4][3];
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        const float4 bs = *reinterpret_cast<const float4*>(bl + (2 * ch + mb) * 16 + q * 4);
-        acc[mb][0] = f32x4{bs.x, bs.y, bs.z, bs.w}; acc[mb][1] = acc[mb][0];
+      for (int mb = 0; mb < 4; ++mb) {                     // accumulators start at the bias of their rows
+        const float4 bs = *reinterpret_cast<const float4*>(bl + mb * 16 + q * 4);
+        acc[mb][0] = f32x4{bs.x, bs.y, bs.z, bs.w}; acc[mb][1] = acc[mb][0]; acc[mb][2] = acc[mb][0];
       }
-      int pidx[2];
-      bool live[2];
+      auto load_a = [&](int s, frag_t* a) {
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int col = wq + 4 * c;                        // columns wq and wq + 4 (7 columns: column 7 does not exist)
-        pidx[c] = col * 16 + r;
-        live[c] = pidx[c] < kHPix;
-        if (!live[c]) pidx[c] = kHPix - 1;
-      }
-      // fragments one k-step ahead of the MFMAs that use them (the compiler waits for an LDS read at its first use)
-      auto load_a = [&](int s, frag_t* a, frag_t* b) {
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) a[mb] = *reinterpret_cast<const frag_t*>(w1l + ((((s * 4 + 2 * ch + mb) * 4 + q) * 16 + r) * 16));
-#pragma unroll
-        for (int c = 0; c < 2; ++c) b[c] = *reinterpret_cast<const frag_t*>(xl + (4 * s + q) * kXS + pidx[c] * 16);
+        for (int mb = 0; mb < 4; ++mb) a[mb] = *reinterpret_cast<const frag_t*>(w1l + ((((s * 4 + mb) * 4 + q) * 16 + r) * 16));
       };
-      frag_t fa[2][2], fb[2][2];
-      load_a(0, fa[0], fb[0]);
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        if (s + 1 < 8) load_a(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+      frag_t fa[2][4];
+      load_a(0, fa[0]);
+      auto step = [&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+        if constexpr (S + 1 < 8) load_a(S + 1, fa[(S + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-          for (int c = 0; c < 2; ++c) acc[mb][c] = mfma16<T>(fa[s & 1][mb], fb[s & 1][c], acc[mb][c]);
+        for (int mb = 0; mb < 4; ++mb) {
+          acc[mb][0] = mfma16<T>(fa[S & 1][mb], __builtin_bit_cast(frag_t, xr[S][0]), acc[mb][0]);
+          acc[mb][1] = mfma16<T>(fa[S & 1][mb], __builtin_bit_cast(frag_t, xr[S][1]), acc[mb][1]);
+          if (has_col2) acc[mb][2] = mfma16<T>(fa[S & 1][mb], __builtin_bit_cast(frag_t, xr[S][2]), acc[mb][2]);
+        }
         __builtin_amdgcn_sched_barrier(0);
-      }
+      };
+      step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+      step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+      // t1 <- ReLU(acc), zero outside the image
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int my = pidx[c] / kHW, mx = pidx[c] - my * kHW;
-        const int gy = oy0 - 1 + my, gx = ox0 - 1 + mx;
-        const bool inimg = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      for (int i = 0; i < 3; ++i) {
+        const int slot = (wave + 8 * i) * 16 + r;
+        const bool inimg = vo[i] != BUF_OOB;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+        for (int mb = 0; mb < 4; ++mb) {
           uint2 o;
-          o.x = relu2_16(pack2<T>(acc[mb][c][0], acc[mb][c][1]), 0u);
-          o.y = relu2_16(pack2<T>(acc[mb][c][2], acc[mb][c][3]), 0u);
+          o.x = relu2_16(pack2<T>(acc[mb][i][0], acc[mb][i][1]), 0u);
+          o.y = relu2_16(pack2<T>(acc[mb][i][2], acc[mb][i][3]), 0u);
           if (!inimg) o = make_uint2(0u, 0u);              // conv2's zero padding, not a conv1 output
-          if (live[c]) *reinterpret_cast<uint2*>(t1l + (2 * (2 * ch + mb) + psel) * kXS + pidx[c] * 16 + 8 * (q >> 1)) = o;
+          if (slot < kHPix) *reinterpret_cast<uint2*>(t1l + (2 * mb + psel) * kXS + slot * 16 + 8 * (q >> 1)) = o;
         }
       }
+      // conv2's 36 weight fragments of this wave (36 KB per wave and tile, L2 hits): resident they would take 144 of the
+      // 256 registers, which is what conv1's x vectors and conv3's residual vectors need to keep enough bytes in flight.
+      // Buffer loads on purpose: through a laundered generic pointer hipcc emitted flat_load, and the results were
+      // sporadically wrong (non-deterministic at the 1e-1 level; found by the determinism check of tools_dev/dump_tap.py).
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s2 = 0; s2 < 18; ++s2)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+          w2f[s2][mb] = __builtin_bit_cast(frag_t, load16_buf(rs_w2, w2vo, (uint32_t)((s2 * 4 + mb) * 1024)));
+      __builtin_amdgcn_sched_barrier(0);
     }
+    const unsigned long long ts1 = now();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                          // t1 complete
+    __builtin_amdgcn_s_barrier();                          // t1 complete (and every wave is done with t2 of the previous tile)
+    const unsigned long long ts2 = now();
 
-    // ---- B: conv2 (3x3, 64 -> 64) on the 64 output pixels -> t2 ----
-    {
+    // ---- B: conv2 (3x3, 64 -> 64) on the 256 output pixels -> t2: tile rows wq, wq + 4, wq + 8, wq + 12 ----
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
       f32x4 acc[2];
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
         const float4 bs = *reinterpret_cast<const float4*>(bl + 64 + (2 * ch + mb) * 16 + q * 4);
         acc[mb] = f32x4{bs.x, bs.y, bs.z, bs.w};
       }
-      const int pix = wq * 16 + r;                         // output pixel of this lane: rows 2 wq, 2 wq + 1
-      const int py = pix >> 3, px = pix & 7;
-      const char* bcol = t1l + (py * kHW + px) * 16;
-      const char* bq0 = bcol + qoff;
+      const int py = wq + 4 * c, px = r;                   // output pixel of this lane
+      const int pix = py * kT + px;
+      const char* bq0 = t1l + (py * kHW + px) * 16 + qoff;
       auto k2imm = [](int s) { const int tap = s >> 1, ky = tap / 3, kx = tap - 3 * ky; return 4 * (s & 1) * kXS + (ky * kHW + kx) * 16; };
       frag_t bq[3];                                       // fragments two k-steps ahead
       bq[0] = *reinterpret_cast<const frag_t*>(bq0 + k2imm(0));
@@ -223,68 +258,90 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
         *reinterpret_cast<uint2*>(t2l + (2 * (2 * ch + mb) + psel) * kT2S + pix * 16 + 8 * (q >> 1)) = o;
       }
     }
+    const unsigned long long ts3 = now();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                          // t2 complete
+    __builtin_amdgcn_s_barrier();                          // t2 complete (and every wave is done with t1)
+    const unsigned long long ts4 = now();
 
     // ---- C: conv3 (1x1, 64 -> 256) + residual -> y ----
-    // column pairs (0,1), (2,3), one after the other (keeps the live accumulators at 2 x 2): after the lane exchange the
-    // lower half-wave owns the pixel of the even column, the upper half-wave that of the odd one, each lane the 8 channels
+    // row pairs (0,1), (2,3), ... one after the other (keeps the live accumulators at 2 x 2): after the lane exchange the
+    // lower half-wave owns the pixel of the even row, the upper half-wave that of the odd one, each lane the 8 channels
     // of plane 2 * block + psel
+    {
+      const uint32_t pl_bytes = (uint32_t)HW * 16u;
+      auto out_off = [&](int cp) -> uint32_t {
+        const int oy = oy0 + 2 * cp + half, ox = ox0 + r;
+        return (oy < p.H && ox < p.W) ? (uint32_t)((img * 32 + psel) * HW + oy * p.W + ox) * 16u : BUF_OOB;
+      };
+      // every residual vector of the tile (64 registers) before the first store
+      u32x4 rv[8][2];
 #pragma unroll
-    for (int cp = 0; cp < 2; ++cp) {
-      f32x4 acc[2][2];
+      for (int cp = 0; cp < 8; ++cp) {
+        const uint32_t o = out_off(cp);
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        const float4 bs = *reinterpret_cast<const float4*>(bl + 128 + (2 * wave + mb) * 16 + q * 4);
-        acc[mb][0] = f32x4{bs.x, bs.y, bs.z, bs.w}; acc[mb][1] = acc[mb][0];
+        for (int mb = 0; mb < 2; ++mb) rv[cp][mb] = load16_buf(rs_in, o, (uint32_t)(2 * (2 * wave + mb)) * pl_bytes);
       }
-      frag_t bc[2][2];
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) bc[s][c] = *reinterpret_cast<const frag_t*>(t2l + (4 * s + q) * kT2S + ((2 * cp + c) * 16 + r) * 16);
-      const int pix = (2 * cp + half) * 16 + r, py = pix >> 3, px = pix & 7;
-      u32x4 rv[2];                                         // residual: centre of the x tile
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) rv[mb] = *reinterpret_cast<const u32x4*>(xl + (2 * (2 * wave + mb) + psel) * kXS + ((py + 1) * kHW + px + 1) * 16);
       __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < t_end) locate(t + 1);
+      else vo[0] = vo[1] = vo[2] = BUF_OOB;                // last tile: the requests still run (they read nothing), so that the
+                                                           // ring is redefined on every path and is not live across phase B
+      auto pair = [&](auto cpc) {
+        constexpr int cp = decltype(cpc)::value;
+        request(cpc);                                      // next tile's x vectors of k-step cp: in front of this pair's stores
+        f32x4 acc[2][2];
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-          for (int c = 0; c < 2; ++c) acc[mb][c] = mfma16<T>(w3f[s][mb], bc[s][c], acc[mb][c]);
-      const int oy = oy0 + py, ox = ox0 + px;
-      const bool store_ok = oy < p.H && ox < p.W;
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        const f32x4 a0 = acc[mb][0], a1 = acc[mb][1];
-        uint32_t a[4], b[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) { a[jj] = __float_as_uint(a0[jj]); b[jj] = __float_as_uint(a1[jj]); }
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const auto sw = __builtin_amdgcn_permlane32_swap(a[jj], b[jj], false, false);
-          a[jj] = sw[0]; b[jj] = sw[1];
+        for (int mb = 0; mb < 2; ++mb) {
+          const float4 bs = *reinterpret_cast<const float4*>(bl + 128 + (2 * wave + mb) * 16 + q * 4);
+          acc[mb][0] = f32x4{bs.x, bs.y, bs.z, bs.w}; acc[mb][1] = acc[mb][0];
         }
-        const int plane = 2 * (2 * wave + mb) + psel;
-        float v[8];
+        frag_t bc[2][2];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) { v[jj] = __uint_as_float(a[jj]); v[4 + jj] = __uint_as_float(b[jj]); }
-        v[0] += from_bits<T>(rv[mb][0] & 0xffff); v[1] += from_bits<T>(rv[mb][0] >> 16);
-        v[2] += from_bits<T>(rv[mb][1] & 0xffff); v[3] += from_bits<T>(rv[mb][1] >> 16);
-        v[4] += from_bits<T>(rv[mb][2] & 0xffff); v[5] += from_bits<T>(rv[mb][2] >> 16);
-        v[6] += from_bits<T>(rv[mb][3] & 0xffff); v[7] += from_bits<T>(rv[mb][3] >> 16);
-        u32x4 ov;
-        ov[0] = relu2_16(pack2<T>(v[0], v[1]), 0u); ov[1] = relu2_16(pack2<T>(v[2], v[3]), 0u);
-        ov[2] = relu2_16(pack2<T>(v[4], v[5]), 0u); ov[3] = relu2_16(pack2<T>(v[6], v[7]), 0u);
-        const uint32_t voff = store_ok ? (uint32_t)((img * 32 + plane) * HW + oy * p.W + ox) * 16u : BUF_OOB;
-        store16_buf(rs_out, voff, 0u, ov);
-      }
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) bc[s][c] = *reinterpret_cast<const frag_t*>(t2l + (4 * s + q) * kT2S + ((2 * cp + c) * 16 + r) * 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[mb][c] = mfma16<T>(w3f[s][mb], bc[s][c], acc[mb][c]);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          const f32x4 a0 = acc[mb][0], a1 = acc[mb][1];
+          uint32_t a[4], b[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) { a[jj] = __float_as_uint(a0[jj]); b[jj] = __float_as_uint(a1[jj]); }
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(a[jj], b[jj], false, false);
+            a[jj] = sw[0]; b[jj] = sw[1];
+          }
+          const u32x4 rr = rv[cp][mb];
+          float v[8];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) { v[jj] = __uint_as_float(a[jj]); v[4 + jj] = __uint_as_float(b[jj]); }
+          v[0] += from_bits<T>(rr[0] & 0xffff); v[1] += from_bits<T>(rr[0] >> 16);
+          v[2] += from_bits<T>(rr[1] & 0xffff); v[3] += from_bits<T>(rr[1] >> 16);
+          v[4] += from_bits<T>(rr[2] & 0xffff); v[5] += from_bits<T>(rr[2] >> 16);
+          v[6] += from_bits<T>(rr[3] & 0xffff); v[7] += from_bits<T>(rr[3] >> 16);
+          u32x4 ov;
+          ov[0] = relu2_16(pack2<T>(v[0], v[1]), 0u); ov[1] = relu2_16(pack2<T>(v[2], v[3]), 0u);
+          ov[2] = relu2_16(pack2<T>(v[4], v[5]), 0u); ov[3] = relu2_16(pack2<T>(v[6], v[7]), 0u);
+          store16_buf(rs_out, out_off(cp), (uint32_t)(2 * (2 * wave + mb)) * pl_bytes, ov);
+        }
+      };
+      pair(std::integral_constant<int, 0>{}); pair(std::integral_constant<int, 1>{}); pair(std::integral_constant<int, 2>{});
+      pair(std::integral_constant<int, 3>{}); pair(std::integral_constant<int, 4>{}); pair(std::integral_constant<int, 5>{});
+      pair(std::integral_constant<int, 6>{}); pair(std::integral_constant<int, 7>{});
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // next x tile landed (this wave's planes); residual reads done
-    __builtin_amdgcn_s_barrier();                                   // x buffer, t1 and t2 are free again
+    if (p.dbg_buf) {   // [A][barrier][B][barrier][C]
+      const unsigned long long ts5 = now();
+      tph[0] += ts1 - ts0; tph[1] += ts2 - ts1; tph[2] += ts3 - ts2; tph[3] += ts4 - ts3; tph[4] += ts5 - ts4;
+    }
   }
+  if (p.dbg_buf && lane == 0)
+    for (int k = 0; k < 6; ++k) p.dbg_buf[((size_t)blockIdx.x * 8 + wave) * 6 + k] = tph[k];
 }
 
 // ---- host ----
@@ -351,6 +408,7 @@ int32_t bottleneck_launch(const void* in, const void* w1, const void* w2, const 
     if (grid > L.tiles_total) grid = L.tiles_total;
     L.tiles_per_wg = (L.tiles_total + grid - 1) / grid;
     L.grid = (L.tiles_total + L.tiles_per_wg - 1) / L.tiles_per_wg;
+    { static const char* e = dev_env("SCPOSE_BNECK_DBG"); L.dbg_buf = (e && atoi(e)) ? conv_dbg_buffer(stream) : nullptr; if (L.dbg_buf) conv_dbg_set_grid(L.grid); }
     if (dtype == SCPOSE_DT_BF16) {
       { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(bottleneck_kernel<0>), kLds, &big_b); if (rc != SCPOSE_OK) return rc; }
       hipLaunchKernelGGL(bottleneck_kernel<0>, dim3(L.grid), dim3(512), kLds, stream, L);

@@ -120,7 +120,7 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   // the search below depends on (layer, N, Ho, Wo) only: its result is remembered in the layer (a forward launches the
   // same shapes every time; small batches are launch-bound on the host)
   PackedConv::TileMemo& memo = pc.m32_memo;
-  const bool memo_hit = memo.n == L.N && memo.ho == L.Ho && memo.wo == L.Wo && !dev_env("SCPOSE_M32_OCC") && !dev_env("SCPOSE_M32_NR");
+  const bool memo_hit = memo.n == L.N && memo.ho == L.Ho && memo.wo == L.Wo && !dev_env("SCPOSE_M32_OCC") && !dev_env("SCPOSE_M32_NR") && !dev_env("SCPOSE_M32_CPMUL");
   if (memo_hit) { found = true; b_th = memo.th; b_tw = memo.tw; b_nseg = memo.nseg; b_nr = memo.nr; b_ps = memo.ps; b_occ = memo.occ; b_cp = memo.cp; }
   for (const M32Variant& v : kVariants) {
     if (memo_hit) break;
@@ -152,7 +152,9 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
             // the stage's LDS-DMA (small tiles: the stage count, not the MFMAs, sets the time -> deeper K-chunks);
             // items are quantised per CU
             bool any = false;
-            for (int mul = 1; mul <= 4; mul *= 2) {
+            static const char* mul_env = dev_env("SCPOSE_M32_CPMUL");   // development: cap the K-chunk depth multiplier
+            const int mul_max = mul_env ? atoi(mul_env) : 4;
+            for (int mul = 1; mul <= mul_max; mul *= 2) {
               const int cp = pc.cp * mul;
               if ((mul > 1 && pc.cp != 2) || (pc.cin / 8) % cp != 0) continue;
               const M32pChunking ck = m32p_chunking(pc, cp);

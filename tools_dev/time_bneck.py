@@ -1,0 +1,22 @@
+"""layer1 only (stem + first Bottleneck + the three fused ones); SCPOSE_BNECK_DBG=1 prints the last Bottleneck's cycles per phase.
+   python tools_dev/time_bneck.py [w48|w32] [N]"""
+import _dev  # noqa: F401
+import sys, os, time, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, scpose
+from importlib import import_module
+ops = import_module("spacecraft-pose-estimation_amd.ops")
+from oracle import hrnet_ref as R
+which = sys.argv[1] if len(sys.argv) > 1 else "w48"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+size = 384 if which == "w48" else 256
+cfg = R.w48_cfg() if which == "w48" else R.w32_cfg()
+eng = ops.HrnetEngine(cfg, R.make_state_dict(cfg, seed=0), dtype="bf16")
+x = torch.randint(0, 256, (n, size, size, 3), dtype=torch.uint8, device="cuda")
+for tap in ("stem2", "layer1"):
+    for _ in range(2): eng.forward_tap(x, tap)
+    torch.cuda.synchronize(); t = time.time()
+    for _ in range(5): eng.forward_tap(x, tap)
+    torch.cuda.synchronize(); print("%s: %.3f ms" % (tap, (time.time() - t) / 5 * 1e3))
+if os.environ.get("SCPOSE_BNECK_DBG"):
+    ctypes.CDLL(ops.nat.LIB_PATH).scpose_dbg_dump()
