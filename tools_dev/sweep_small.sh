@@ -1,10 +1,10 @@
 #!/bin/bash
-# Small-batch tile sweep of the 32x32x16 kernels (W32 branch shapes): tools_dev/sweep_small.sh [N]
 N=${1:-64}
 cd $GRAFT_REPO_ROOT
-for shape in "64 64 3 1 32" "128 128 3 1 16" "256 256 3 1 8"; do
-  echo "== $shape N=$N default"; SCPOSE_DEV=1 SCPOSE_DBG=32 python3 tools_dev/time_conv.py $shape $N 2>&1 | tail -2
-  for occ in 1 2 3; do for nr in 1 2 3 4; do
-    echo "-- occ=$occ nr=$nr"; SCPOSE_DEV=1 SCPOSE_DBG=32 SCPOSE_M32_OCC=$occ SCPOSE_M32_NR=$nr python3 tools_dev/time_conv.py $shape $N 2>&1 | tail -2
-  done; done
+for shape in "128 128 3 1 16" "256 256 3 1 8" "128 128 3 1 24" "256 256 3 1 12" "192 192 3 1 24" "384 384 3 1 12" "96 96 3 1 48"; do
+  SCPOSE_DEV=1 SCPOSE_DBG=32 python3 tools_dev/time_conv.py $shape $N 2>&1 | tail -2
 done
+python3 tools_dev/time_graph.py w32 64
+python3 tools_dev/time_graph.py w32 1
+python3 tools_dev/time_graph.py w48 64 384
+python3 -m pytest tests/test_gpu_conv.py tests/test_gpu_hrnet.py -m gpu -x -q 2>&1 | tail -3
