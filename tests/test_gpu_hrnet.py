@@ -334,3 +334,34 @@ def test_fused_stem_matches_oracle(gpu_ops, h, w, n, dt):
     print("stem %dx%d %s: max %.2f ulps, %.5f of the elements off by > 0.5 ulp" % (h, w, dt, u.max().item(), (u > 0.5).float().mean().item()))
     assert u.max().item() <= 2.5 and (u > 0.5).float().mean().item() <= 2e-3
     eng.close()
+
+
+@pytest.mark.parametrize("h,w,n,dt", [(64, 64, 3, "bf16"), (96, 160, 2, "bf16"), (160, 224, 2, "f16"), (384, 384, 2, "bf16"), (32, 32, 1, "f16")])
+def test_fused_bottleneck_matches_oracle(gpu_ops, h, w, n, dt):
+    """csrc/bottleneck.hip (layer1's three identity-residual Bottlenecks, pose_hrnet.py:78-98, one launch each) through the
+    "layer1" tap: element-wise against the oracle's storage model, with ragged 16 x 16 tiles (H/4, W/4 not multiples of 16),
+    several tiles per workgroup (384 x 384: 36 tiles per frame), both operand types -- and bit-identical run to run.
+    The run-to-run check is what caught a `flat_load` miscompile in this kernel that stayed inside the tolerance at
+    small sizes."""
+    cfg = R.w32_cfg()
+    sd = R.make_state_dict(cfg, seed=23)
+    g = torch.Generator().manual_seed(h * 13 + w)
+    u8 = torch.randint(0, 256, (n, h, w, 3), generator=g, dtype=torch.uint8)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    x = (u8.permute(0, 3, 1, 2).float() / 255.0 - mean) / std
+    taps = {}
+    with torch.no_grad():
+        R.forward(sd, cfg, x, emulate=dt, taps=taps)
+    ref = taps["layer1"]
+    eng = gpu_ops.HrnetEngine(cfg, sd, dtype=dt)
+    runs = [eng.forward_tap(u8.cuda(), "layer1").cpu() for _ in range(3)]
+    assert runs[0].shape == ref.shape == (n, 256, h // 4, w // 4)
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), "layer1 differs from run to run"
+    _, max_ulps, mean_ulps, _ = [b for b in TAP_BOUNDS if b[0] == "layer1"][0]
+    eps = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+    ulp = eps * torch.maximum(ref.abs(), torch.full_like(ref, float(ref.abs().mean())))
+    u = (runs[0] - ref).abs() / ulp
+    print("layer1 %dx%d %s: worst %.1f ulps, mean %.3f ulps" % (h, w, dt, u.max().item(), u.mean().item()))
+    assert u.max().item() <= max_ulps and u.mean().item() <= mean_ulps
+    eng.close()
