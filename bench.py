@@ -29,6 +29,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                 once), the bound is chosen from flops / those bytes against the ridge, and `frac` is
                 against that bound's peak.  `traffic` (PMC bytes per launch) is reported only when
                 profiles/roofline_traffic.json was measured on the same kernel sources (src_sha).
+                MFMA-bound classes also carry `frac_of_sustained`: against the 1 930 TFLOP/s a register-operand
+                MFMA stream sustains on random data at the board's power limit (profiles/round2_mfma_ceiling.txt).
   cpu_baseline  the CPU oracle (oracle/, a port of the reference path) timed on this host's
                 cores on a bounded sample of the same workload.
 """
@@ -48,6 +50,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16/f16 MFMA
+MFMA_SUSTAINED_TFLOPS = 1930.0   # measured: 32x32x16 bf16, operands in registers, random data, all CUs (profiles/round2_mfma_ceiling.txt)
 BATCH_PER_GPU = 256
 IMAGE = 384
 JOINTS = 11
@@ -268,7 +271,9 @@ def main():
             kind, a, cin, cout = key
             name = {0: "stem_conv1_kernel (3->64 3x3 s2, f32 VALU)", 2: "fuse_sum_kernel (%d terms, C=%d)" % (a, cin),
                     3: "conv_block_kernel: fused BasicBlock 2 x (3x3 s1 %d->%d), input read once + output written once" % (cin, cout),
-                    4: "head_gather_kernel (k%d s%d, C=%d)" % (a // 10, a % 10, cin)}.get(
+                    4: "head_gather_kernel (k%d s%d, C=%d)" % (a // 10, a % 10, cin),
+                    5: "stem_fused_kernel: conv1 + conv2 of the stem (3->64->64, both 3x3 s2), image read once + output written once",
+                    6: "bottleneck_kernel: fused Bottleneck 1x1 %d->64, 3x3 64->64, 1x1 64->%d + residual, input read once + output written once" % (cin, cout)}.get(
                 kind, "conv %dx%d s%d %d->%d (MFMA implicit-GEMM)" % (a // 10, a // 10, a % 10, cin, cout))
             ai = flops / byts if byts else float("inf")
             sec = ms / 1e3
@@ -276,6 +281,10 @@ def main():
                 r = {"bound": "hbm", "achieved": round(byts / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
             else:
                 r = {"bound": "mfma", "achieved": round(flops / sec / 1e12, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+                # what a register-operand MFMA stream sustains on random bf16 data at the board's power limit
+                # (tools_dev/micro/mfma_bench.hip, profiles/round2_mfma_ceiling.txt); `frac` stays against the nominal peak
+                r["peak_sustained_measured"] = MFMA_SUSTAINED_TFLOPS
+                r["frac_of_sustained"] = round(r["achieved"] / MFMA_SUSTAINED_TFLOPS, 4)
             r["frac"] = round(r["achieved"] / r["peak"], 4)
             # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes; summary committed under
             # profiles/): only reported when it was measured on exactly these kernel sources, batch, dtype and image
@@ -295,9 +304,9 @@ def main():
         roof["profiled_steps"] = prof_steps
         roof["src_sha"] = sha
         # the next kernel classes by share of the forward, each against its own roofline (same definitions);
-        # class = kind:10*ksize+stride|nterms:Cin:Cout (kind 0 stem, 1 conv, 2 fuse sum, 3 fused BasicBlock, 4 head gather)
+        # class = kind:10*ksize+stride|nterms:Cin:Cout (kind 0 stem, 1 conv, 2 fuse sum, 3 fused BasicBlock, 4 head gather, 5 fused stem, 6 fused Bottleneck)
         roof["next_classes"] = [{k: v for k, v in describe(k2, *v2).items()
-                                 if k in ("class", "share_of_forward", "avg_launch_us", "bound", "achieved", "unit", "frac", "traffic")}
+                                 if k in ("class", "share_of_forward", "avg_launch_us", "bound", "achieved", "unit", "frac", "frac_of_sustained", "traffic")}
                                 for k2, v2 in ranked[1:6]]
         fwd_ms = sum(v[0] for v in prof_ms.values()) / max(prof_steps, 1)
         cpu = None
