@@ -98,6 +98,7 @@ struct ConvLaunch {
                                   // addressing).  conv_pipe: out_bytes = size of in2 (K-concatenated second input).
   unsigned long long* dbg_buf;  // development: per-workgroup phase cycle sums (dbg & 8), else null
   int32_t dbg;           // development ablation bits (0 in production): 1 skip MFMA loop, 2 skip epilogue, 4 skip input DMA
+  int32_t cu_share;      // host only: CUs to size the layer for (0 = the whole chip)
 };
 
 // Per-layer choice of kernel variant + tiling.
@@ -125,8 +126,8 @@ struct PackedConv {
   size_t w1_bytes = 0;
   int cout_pad1 = 0;
   // tiling chosen by conv_launch_m32 for the last (N, Ho, Wo) seen (the search is a function of those and the layer only)
-  struct TileMemo { int n = -1, ho = 0, wo = 0, th = 0, tw = 0, nseg = 0, nr = 0, ps = 0, occ = 0, cp = 0; };
-  mutable TileMemo m32_memo;
+  struct TileMemo { int n = -1, ho = 0, wo = 0, th = 0, tw = 0, nseg = 0, nr = 0, ps = 0, occ = 0, cp = 0, cus = 0; };
+  mutable TileMemo m32_memo[2];   // [0] whole chip, [1] a share of it (concurrent lanes)
   // register-weight stride-2 kernel (conv_s2r.hip): weights [k-step][cout block][k-group][row][8], bias in MFMA row order
   void* d_ws2 = nullptr;
   float* d_bs2 = nullptr;
@@ -152,9 +153,11 @@ size_t pack_conv_weights(const float* w, int cout, int cin, int ks, int mt, int 
 int32_t conv_upload(const float* w, const float* bias, int cout, int cin, int ks, int stride,
                     int dtype, PackedConv* pc);
 void conv_free(PackedConv* pc);
+// cu_share > 0: the caller runs other layers beside this one (concurrent lanes of the captured forward); a small 3x3 layer
+// then sizes its grid and tiles for that many CUs instead of the whole chip (same results: tiling never changes a pixel's sum)
 int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, const void* res,
                     int relu, int out_nchw_f32, void* out, hipStream_t stream,
-                    const void* in2 = nullptr, int split_planes = 0);
+                    const void* in2 = nullptr, int split_planes = 0, int cu_share = 0);
 size_t conv_lds_bytes(const PackedConv& pc, int nrep, int th, int tw);
 int plane_stride_for(int stride, int halo_h, int halo_w);
 // software-pipelined persistent kernel (conv_pipe_kernel.h); nt = pixel tiles per work item

@@ -239,7 +239,7 @@ size_t conv_lds_bytes(const PackedConv& pc, int nrep, int th, int tw) {
 }
 
 int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, const void* res,
-                    int relu, int out_nchw_f32, void* out, hipStream_t stream, const void* in2, int split_planes) {
+                    int relu, int out_nchw_f32, void* out, hipStream_t stream, const void* in2, int split_planes, int cu_share) {
   SCP_REQUIRE(!in2 || (pc.variant == 0 && pc.ks == 1 && split_planes > 0 && split_planes % pc.cp == 0 && split_planes < pc.cin / 8),
               "conv: a second input tensor needs a 1x1 layer whose K-chunks do not straddle the split (split=%d planes, cp=%d)", split_planes, pc.cp);
   SCP_REQUIRE(N > 0 && H > 0 && W > 0, "conv: bad shape N=%d H=%d W=%d", N, H, W);
@@ -251,6 +251,7 @@ int32_t conv_launch(const PackedConv& pc, const void* in, int N, int H, int W, c
   L.Wo = (W - 1) / pc.stride + 1;
   L.cin_planes = pc.cin / 8;
   L.cout = pc.cout;
+  L.cu_share = cu_share;
   if (pc.d_ws2 && !res && !in2 && !out_nchw_f32 && (size_t)N * L.cin_planes * H * W * 16 < 0xfffffff0ull &&
       (size_t)N * (pc.cout / 8) * L.Ho * L.Wo * 16 < 0xfffffff0ull)
     return conv_s2r_launch(pc, in, N, H, W, relu, out, stream);

@@ -115,12 +115,17 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   int b_th = 0, b_tw = 0, b_nseg = 0, b_nr = 0, b_ps = 0, b_occ = 1, b_cp = pc.cp;
   long b_items = 0;
   int p_th = 0, p_tw = 0, p_nseg = 0, p_nr = 0, p_ps = 0, p_cp = pc.cp;   // best producer/consumer candidate (cost model)
-  const int cus = conv_device_cus();
+  static const char* cus_env = dev_env("SCPOSE_M32_CUS");   // development: size small layers for a share of the chip (concurrent lanes)
+  const int cus_all = conv_device_cus();
+  // a share of the chip only for layers that cannot fill it anyway (<= 64 k output pixels: chains of DMA round trips, whose
+  // duration hardly depends on the CU count -- W32 256x256 batch 64 captured forward 3.39 -> 3.07 ms with half the chip each)
+  const int share = cus_env && atoi(cus_env) > 0 ? atoi(cus_env) : L.cu_share;
+  const int cus = (share > 0 && share < cus_all && (long)L.N * L.Ho * L.Wo <= 65536) ? share : cus_all;
   const int tw_cand[8] = {L.Wo, 64, 48, 32, 24, 16, 12, 8};
   // the search below depends on (layer, N, Ho, Wo) only: its result is remembered in the layer (a forward launches the
   // same shapes every time; small batches are launch-bound on the host)
-  PackedConv::TileMemo& memo = pc.m32_memo;
-  const bool memo_hit = memo.n == L.N && memo.ho == L.Ho && memo.wo == L.Wo && !dev_env("SCPOSE_M32_OCC") && !dev_env("SCPOSE_M32_NR") && !dev_env("SCPOSE_M32_CPMUL");
+  PackedConv::TileMemo& memo = pc.m32_memo[cus != cus_all];
+  const bool memo_hit = memo.n == L.N && memo.ho == L.Ho && memo.wo == L.Wo && memo.cus == cus && !dev_env("SCPOSE_M32_OCC") && !dev_env("SCPOSE_M32_NR") && !dev_env("SCPOSE_M32_CPMUL") && !dev_env("SCPOSE_M32_CUS");
   if (memo_hit) { found = true; b_th = memo.th; b_tw = memo.tw; b_nseg = memo.nseg; b_nr = memo.nr; b_ps = memo.ps; b_occ = memo.occ; b_cp = memo.cp; }
   for (const M32Variant& v : kVariants) {
     if (memo_hit) break;
@@ -187,7 +192,7 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
     found = true; b_th = p_th; b_tw = p_tw; b_nseg = p_nseg; b_nr = p_nr; b_ps = p_ps; b_occ = 3; b_cp = p_cp;
   }
   SCP_REQUIRE(found, "conv m32: no tiling for %dx%d output", L.Ho, L.Wo);
-  memo.n = L.N; memo.ho = L.Ho; memo.wo = L.Wo; memo.th = b_th; memo.tw = b_tw; memo.nseg = b_nseg; memo.nr = b_nr; memo.ps = b_ps; memo.occ = b_occ; memo.cp = b_cp;
+  memo.n = L.N; memo.ho = L.Ho; memo.wo = L.Wo; memo.th = b_th; memo.tw = b_tw; memo.nseg = b_nseg; memo.nr = b_nr; memo.ps = b_ps; memo.occ = b_occ; memo.cp = b_cp; memo.cus = cus;
   L.th = b_th; L.tw = b_tw; L.nt = b_nseg;
   L.tiles_x = (L.Wo + L.tw - 1) / L.tw;
   L.tiles_y = (L.Ho + L.th - 1) / L.th;
@@ -226,7 +231,7 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   L.fd_hp = make_fastdiv(L.halo_h * L.halo_w); L.fd_halo_w = make_fastdiv(L.halo_w);
   L.fd_tiles_img = make_fastdiv(L.tiles_x * L.tiles_y); L.fd_tiles_x = make_fastdiv(L.tiles_x);
   L.fd_nmblk = make_fastdiv(pc.n_mblk);
-  int grid = conv_device_cus() * (b_occ == 2 ? 2 : 1);
+  int grid = cus * (b_occ == 2 ? 2 : 1);
   if (grid > L.items_total) grid = L.items_total;
   L.items_per_wg = (L.items_total + grid - 1) / grid;
   L.grid = (L.items_total + L.items_per_wg - 1) / L.items_per_wg;

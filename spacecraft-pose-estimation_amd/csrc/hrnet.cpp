@@ -616,7 +616,7 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
       void* out = op.out == -2 ? static_cast<void*>(heatmaps) : ptr(op.out);
       rc = conv_launch(net->convs[op.conv], ptr(op.in), n, h >> ti.ds, w >> ti.ds, ptr(op.res),
                        op.relu, op.out_f32, out, st, op.in2 > 0 ? ptr(op.in2 - 1) : nullptr,
-                       op.in2 > 0 ? net->tensors[op.in].C / 8 : 0);
+                       op.in2 > 0 ? net->tensors[op.in].C / 8 : 0, open_lanes ? conv_device_cus() / 2 : 0);
     } else if (op.kind == OP_HEAD) {
       const TensorDesc& ti = net->tensors[op.in];
       float* out = op.out == -2 ? heatmaps : static_cast<float*>(ptr(op.out));
