@@ -80,7 +80,7 @@ def parse():
                     help="BASELINE configs[4] side line: HRNet-W32 256x256, f16 MFMA kernels, mixed RGB + event-frame batch")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: un-profiled steps replay the forward from a hipGraph with concurrent branches (scpose_hrnet_graph_*); "
-                         "0: eager launches; default: 1 for batches <= 64 (launch-bound; -33 %% at W32 batch 64), 0 above "
+                         "0: eager launches; default: 1 for batches <= 128 (W32 batch 64: -24 %%, W48 batch 128: -2 %%), 0 above "
                          "(at batch 256 every kernel fills the chip and concurrent lanes only contend: measured +0.4 ms)")
     ap.add_argument("--chained", action="store_true",
                     help="feed the PnP stage with the decoded (random-weight) keypoints instead of synthetic ones")
@@ -166,7 +166,7 @@ def main():
     eng = ops.HrnetEngine(cfg, sd, dtype=args.dtype, device=dev)
     B = args.batch
     if args.graph < 0:
-        args.graph = 1 if B <= 64 else 0
+        args.graph = 1 if B <= 128 else 0
     hh = image // 4
 
     # ---- synthetic inputs, resident in HBM before the timed region (shard = rank's slice) ----
