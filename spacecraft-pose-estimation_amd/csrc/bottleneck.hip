@@ -1,6 +1,7 @@
 // Fused Bottleneck of layer1:  y = ReLU( bn3(conv3( ReLU(bn2(conv2( ReLU(bn1(conv1(x))) ))) )) + x ),
 // conv1 1x1 256 -> 64, conv2 3x3 64 -> 64, conv3 1x1 64 -> 256, all on v_mfma_f32_16x16x32_{bf16,f16}
-// (landmark_regression/lib/models/pose_hrnet.py:60-98, the three identity-residual blocks of layer1, :374-391).
+// (landmark_regression/lib/models/pose_hrnet.py:60-98, the blocks of layer1, :374-391; the first one, whose residual is
+// projected by `downsample`, runs as the PROJ instantiation -- see the kernel template).
 //
 // Why: run as three layers a Bottleneck moves 4.8 GB at batch 256 / 96x96 -- the 256-channel tensor is read by conv1,
 // read again as the residual and written by conv3, and two 64-channel tensors are written and re-read in between --
@@ -50,17 +51,21 @@ constexpr int kXS = (kHPix | 1) * 16;          // bytes of one t1 plane (325 slo
 constexpr int kT2S = (kT * kT | 1) * 16;       // bytes of one t2 plane (257 slots)
 constexpr int kW1Bytes = 8 * 4 * 4 * 16 * 16;  // 32 KB
 constexpr int kLds = 8 * kXS + 8 * kT2S + kW1Bytes + (64 + 64 + 256) * 4;
+// first Bottleneck (PROJ): x has 64 channels, W1 is 8 KB, and the tile's 256 centre pixels of x (8 planes) are kept in LDS,
+// double-buffered, as the operand of the projection half of conv3
+constexpr int kW1BytesProj = 2 * 4 * 4 * 16 * 16;
+constexpr int kLdsProj = 8 * kXS + 8 * kT2S + 2 * 8 * kT2S + kW1BytesProj + (64 + 64 + 256) * 4;
 
 struct BneckLaunch {
   const void* in;
-  const void* w1;   // [8][4][4][16][8]
+  const void* w1;   // [Cin / 32][4][4][16][8]
   const void* w2;   // [18][4][4][16][8]   (tap, plane) pairs t = 4 s + q: tap = t >> 3, plane = t & 7
-  const void* w3;   // [2][16][4][16][8]
+  const void* w3;   // [2 or 4][16][4][16][8]   (4: [W3 | Wds] of the first Bottleneck)
   const float* b1;  // MFMA row order
   const float* b2;
   const float* b3;
   void* out;
-  uint32_t bytes;   // size of in (= out)
+  uint32_t in_bytes, out_bytes;
   int32_t N, H, W;
   int32_t tiles_x, tiles_y, tiles_total, tiles_per_wg, grid;
   unsigned long long* dbg_buf;   // development (SCPOSE_BNECK_DBG=1): cycles per phase and wave
@@ -73,14 +78,22 @@ inline int bneck_row_channel(int row) {
 
 }  // namespace
 
-template <int DT>
+// PROJ = false: identity residual, Cin = 256 (layer1 blocks 1-3).  PROJ = true: the first Bottleneck (pose_hrnet.py:378-384,
+// :78-98 with `downsample`): Cin = 64, and conv3 runs over the concatenated operand [t2 ; x] with weights [W3 | Wds] and bias
+// b3 + bds -- the 1x1 projection of the residual is two more k-steps of conv3 and is summed in the fp32 accumulators.
+template <int DT, bool PROJ>
 __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p) {
+  constexpr int CINP = PROJ ? 8 : 32;          // input planes
+  constexpr int KA = CINP / 4;                 // conv1 k-steps
+  constexpr int KC = PROJ ? 4 : 2;             // conv3 k-steps
+  constexpr int W1B = PROJ ? kW1BytesProj : kW1Bytes;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename DtOf<DT>::type T;
   typedef typename FragOf<T>::type frag_t;
   char* t1l = smem;
   char* t2l = t1l + 8 * kXS;
-  char* w1l = t2l + 8 * kT2S;
+  char* xcl = t2l + 8 * kT2S;                  // PROJ: 2 x [8 planes][256 centre pixels] of x
+  char* w1l = xcl + (PROJ ? 2 * 8 * kT2S : 0);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, r = lane & 15, half = lane >> 5, psel = q & 1;
@@ -89,16 +102,16 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
   const int tiles_per_img = p.tiles_x * p.tiles_y;
 
   // ---- weights ----
-  for (int o = tid * 16; o < kW1Bytes; o += 512 * 16)
+  for (int o = tid * 16; o < W1B; o += 512 * 16)
     *reinterpret_cast<u32x4*>(w1l + o) = *reinterpret_cast<const u32x4*>(static_cast<const char*>(p.w1) + o);
-  frag_t w3f[2][2];
+  frag_t w3f[KC][2];
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+  for (int s = 0; s < KC; ++s)
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
       w3f[s][mb] = *reinterpret_cast<const frag_t*>(static_cast<const char*>(p.w3) + ((((size_t)s * 16 + 2 * wave + mb) * 4 + q) * 16 + r) * 16);
   // biases stay in LDS (behind W1) and are re-read per phase
-  float* bl = reinterpret_cast<float*>(w1l + kW1Bytes);
+  float* bl = reinterpret_cast<float*>(w1l + W1B);
   for (int e = tid; e < 64 + 64 + 256; e += 512) bl[e] = e < 64 ? p.b1[e] : e < 128 ? p.b2[e - 64] : p.b3[e - 128];
   // conv2 operand addressing: k-step s, k-group q -> (tap, plane) pair 4 s + q: tap = s >> 1 (compile time),
   // plane = q + 4 (s & 1): one per-lane offset (q * plane pitch), everything else an immediate
@@ -114,13 +127,14 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
     const int ty = rem / p.tiles_x;
     oy0 = ty * kT; ox0 = (rem - ty * p.tiles_x) * kT;
   };
-  const buf_rsrc_t rs_in = make_buf(p.in, p.bytes), rs_out = make_buf(p.out, p.bytes), rs_w2 = make_buf(p.w2, 18u * 4 * 4 * 16 * 16);
+  const buf_rsrc_t rs_in = make_buf(p.in, p.in_bytes), rs_out = make_buf(p.out, p.out_bytes), rs_w2 = make_buf(p.w2, 18u * 4 * 4 * 16 * 16);
   const uint32_t kstep_bytes = (uint32_t)(4 * HW) * 16u;     // four planes = one k-step of conv1
 
   // conv1 columns of this wave: wave + 8 i, i = 0..2 (21 columns: the third exists for waves 0-4 only).
   // vo[i] = byte offset of (image, plane q, halo pixel of this lane) in x, BUF_OOB outside the image / the halo
   const bool has_col2 = wave + 16 < kCols1;
   uint32_t vo[3];
+  int cx[3] = {-1, -1, -1};   // PROJ: byte offset of this lane's pixel in a centre plane, -1 for halo pixels
   auto locate = [&](int t) {
     int img, oy0, ox0;
     decode(t, img, oy0, ox0);
@@ -130,19 +144,21 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
       const int my = slot / kHW, mx = slot - my * kHW;
       const int gy = oy0 - 1 + my, gx = ox0 - 1 + mx;
       const bool ok = slot < kHPix && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-      vo[i] = ok ? (uint32_t)((img * 32 + q) * HW + gy * p.W + gx) * 16u : BUF_OOB;
+      vo[i] = ok ? (uint32_t)((img * CINP + q) * HW + gy * p.W + gx) * 16u : BUF_OOB;
+      if constexpr (PROJ) cx[i] = (slot < kHPix && my >= 1 && my <= kT && mx >= 1 && mx <= kT) ? ((my - 1) * kT + mx - 1) * 16 : -1;
     }
   };
   // x vectors of conv1: all 8 k-steps of the wave's three columns (96 registers, 192 KB in flight per CU), requested
   // one tile ahead -- at the start of the previous tile's phase C, BEFORE that phase's stores: a wave's vector-memory
   // operations complete in order, so a load issued behind stores is not usable until those stores are acknowledged
   // (measured: with loads and stores interleaved per row pair, phase C took 12 us per tile)
-  u32x4 xr[8][3];
+  u32x4 xr[KA][3];
   auto request = [&](auto sc) {
     constexpr int S = decltype(sc)::value;
+    if constexpr (S < KA)
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-      xr[S][i] = load16_buf(rs_in, vo[i], (uint32_t)S * kstep_bytes);   // a column that does not exist reads zeros (BUF_OOB)
+      for (int i = 0; i < 3; ++i)
+        xr[S][i] = load16_buf(rs_in, vo[i], (uint32_t)S * kstep_bytes);   // a column that does not exist reads zeros (BUF_OOB)
   };
   auto request_head = [&]() {
     request(std::integral_constant<int, 0>{}); request(std::integral_constant<int, 1>{});
@@ -160,7 +176,8 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
 
   unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
   auto now = [&]() -> unsigned long long { return p.dbg_buf ? __builtin_amdgcn_s_memtime() : 0ull; };
-  for (int t = t_begin; t < t_end; ++t) {
+  int xbuf = 0;
+  for (int t = t_begin; t < t_end; ++t, xbuf ^= 1) {
     int img, oy0, ox0;
     decode(t, img, oy0, ox0);
     const unsigned long long ts0 = now();
@@ -182,7 +199,12 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
       load_a(0, fa[0]);
       auto step = [&](auto sc) {
         constexpr int S = decltype(sc)::value;
-        if constexpr (S + 1 < 8) load_a(S + 1, fa[(S + 1) & 1]);
+        if constexpr (S + 1 < KA) load_a(S + 1, fa[(S + 1) & 1]);
+        if constexpr (PROJ) {   // the centre pixels' x vectors are the projection operand of conv3: into this tile's LDS copy
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            if (cx[i] >= 0) *reinterpret_cast<u32x4*>(xcl + (xbuf * 8 + 4 * S + q) * kT2S + cx[i]) = xr[S][i];
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
@@ -192,9 +214,11 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
         }
         __builtin_amdgcn_sched_barrier(0);
       };
-      step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
-      step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
-      step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+      step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+      if constexpr (KA > 2) {
+        step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{});
+        step(std::integral_constant<int, 5>{}); step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+      }
       // t1 <- ReLU(acc), zero outside the image
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
@@ -274,16 +298,18 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
         return (oy < p.H && ox < p.W) ? (uint32_t)((img * 32 + psel) * HW + oy * p.W + ox) * 16u : BUF_OOB;
       };
       // every residual vector of the tile (64 registers) before the first store
-      u32x4 rv[8][2];
+      u32x4 rv[PROJ ? 1 : 8][2];
+      if constexpr (!PROJ) {
 #pragma unroll
-      for (int cp = 0; cp < 8; ++cp) {
-        const uint32_t o = out_off(cp);
+        for (int cp = 0; cp < 8; ++cp) {
+          const uint32_t o = out_off(cp);
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) rv[cp][mb] = load16_buf(rs_in, o, (uint32_t)(2 * (2 * wave + mb)) * pl_bytes);
+          for (int mb = 0; mb < 2; ++mb) rv[cp][mb] = load16_buf(rs_in, o, (uint32_t)(2 * (2 * wave + mb)) * pl_bytes);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (t + 1 < t_end) locate(t + 1);
-      else vo[0] = vo[1] = vo[2] = BUF_OOB;                // last tile: the requests still run (they read nothing), so that the
+      else { vo[0] = vo[1] = vo[2] = BUF_OOB; cx[0] = cx[1] = cx[2] = -1; }   // last tile: the requests still run (they read nothing), so that the
                                                            // ring is redefined on every path and is not live across phase B
       auto pair = [&](auto cpc) {
         constexpr int cp = decltype(cpc)::value;
@@ -294,14 +320,15 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
           const float4 bs = *reinterpret_cast<const float4*>(bl + 128 + (2 * wave + mb) * 16 + q * 4);
           acc[mb][0] = f32x4{bs.x, bs.y, bs.z, bs.w}; acc[mb][1] = acc[mb][0];
         }
-        frag_t bc[2][2];
+        frag_t bc[KC][2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < KC; ++s)
 #pragma unroll
-          for (int c = 0; c < 2; ++c) bc[s][c] = *reinterpret_cast<const frag_t*>(t2l + (4 * s + q) * kT2S + ((2 * cp + c) * 16 + r) * 16);
+          for (int c = 0; c < 2; ++c)   // k-steps 0, 1: t2; PROJ k-steps 2, 3: the tile's copy of x
+            bc[s][c] = *reinterpret_cast<const frag_t*>((s < 2 ? t2l + (4 * s + q) * kT2S : xcl + (xbuf * 8 + 4 * (s - 2) + q) * kT2S) + ((2 * cp + c) * 16 + r) * 16);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < KC; ++s)
 #pragma unroll
           for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -317,14 +344,16 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
             const auto sw = __builtin_amdgcn_permlane32_swap(a[jj], b[jj], false, false);
             a[jj] = sw[0]; b[jj] = sw[1];
           }
-          const u32x4 rr = rv[cp][mb];
           float v[8];
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) { v[jj] = __uint_as_float(a[jj]); v[4 + jj] = __uint_as_float(b[jj]); }
+          if constexpr (!PROJ) {
+          const u32x4 rr = rv[cp][mb];
           v[0] += from_bits<T>(rr[0] & 0xffff); v[1] += from_bits<T>(rr[0] >> 16);
           v[2] += from_bits<T>(rr[1] & 0xffff); v[3] += from_bits<T>(rr[1] >> 16);
           v[4] += from_bits<T>(rr[2] & 0xffff); v[5] += from_bits<T>(rr[2] >> 16);
           v[6] += from_bits<T>(rr[3] & 0xffff); v[7] += from_bits<T>(rr[3] >> 16);
+          }
           u32x4 ov;
           ov[0] = relu2_16(pack2<T>(v[0], v[1]), 0u); ov[1] = relu2_16(pack2<T>(v[2], v[3]), 0u);
           ov[2] = relu2_16(pack2<T>(v[4], v[5]), 0u); ov[3] = relu2_16(pack2<T>(v[6], v[7]), 0u);
@@ -345,22 +374,26 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
 }
 
 // ---- host ----
-bool bottleneck_fusable(int cin, int cmid, int cout) { return cin == 256 && cmid == 64 && cout == 256; }
+bool bottleneck_fusable(int cin, int cmid, int cout) { return (cin == 256 || cin == 64) && cmid == 64 && cout == 256; }
 
-// w1: [64][256] (1x1), w2: [64][64][3][3], w3: [256][64] (1x1), BN-folded f32 OIHW.
-void bottleneck_pack(const float* w1, const float* w2, const float* w3, const float* b1, const float* b2, const float* b3, int dtype,
+// w1: [64][cin] (1x1), w2: [64][64][3][3], w3: [256][64] (1x1), BN-folded f32 OIHW.  cin = 256: identity residual (wds, bds
+// null).  cin = 64: the first Bottleneck -- wds [256][64] / bds are its `downsample` 1x1 conv + BN, appended to conv3 as
+// k-steps 2 and 3 (input planes 8..15 of the concatenated operand [t2 ; x]) with the biases summed.
+void bottleneck_pack(const float* w1, const float* w2, const float* w3, const float* wds, const float* b1, const float* b2, const float* b3,
+                     const float* bds, int cin, int dtype,
                      std::vector<uint16_t>* pw1, std::vector<uint16_t>* pw2, std::vector<uint16_t>* pw3, std::vector<float>* pb) {
-  pw1->assign((size_t)8 * 4 * 4 * 16 * 8, 0);
+  const int ka = cin / 32, kc = wds ? 4 : 2;
+  pw1->assign((size_t)ka * 4 * 4 * 16 * 8, 0);
   pw2->assign((size_t)18 * 4 * 4 * 16 * 8, 0);
-  pw3->assign((size_t)2 * 16 * 4 * 16 * 8, 0);
+  pw3->assign((size_t)kc * 16 * 4 * 16 * 8, 0);
   pb->assign(64 + 64 + 256, 0.f);
-  for (int s = 0; s < 8; ++s)
+  for (int s = 0; s < ka; ++s)
     for (int m = 0; m < 4; ++m)
       for (int q = 0; q < 4; ++q)
         for (int r = 0; r < 16; ++r) {
           const int co = 16 * m + bneck_row_channel(r), plane = 4 * s + q;
           uint16_t* d = pw1->data() + ((((size_t)s * 4 + m) * 4 + q) * 16 + r) * 8;
-          for (int j = 0; j < 8; ++j) d[j] = host_f32_to_16(w1[(size_t)co * 256 + plane * 8 + j], dtype);
+          for (int j = 0; j < 8; ++j) d[j] = host_f32_to_16(w1[(size_t)co * cin + plane * 8 + j], dtype);
         }
   for (int s = 0; s < 18; ++s)
     for (int m = 0; m < 4; ++m)
@@ -371,36 +404,53 @@ void bottleneck_pack(const float* w1, const float* w2, const float* w3, const fl
           uint16_t* d = pw2->data() + ((((size_t)s * 4 + m) * 4 + q) * 16 + r) * 8;
           for (int j = 0; j < 8; ++j) d[j] = host_f32_to_16(w2[((size_t)(co * 64 + plane * 8 + j) * 3 + ky) * 3 + kx], dtype);
         }
-  for (int s = 0; s < 2; ++s)
+  for (int s = 0; s < kc; ++s)
     for (int m = 0; m < 16; ++m)
       for (int q = 0; q < 4; ++q)
         for (int r = 0; r < 16; ++r) {
           const int co = 16 * m + bneck_row_channel(r), plane = 4 * s + q;
           uint16_t* d = pw3->data() + ((((size_t)s * 16 + m) * 4 + q) * 16 + r) * 8;
-          for (int j = 0; j < 8; ++j) d[j] = host_f32_to_16(w3[(size_t)co * 64 + plane * 8 + j], dtype);
+          const float* src = plane < 8 ? w3 + (size_t)co * 64 + plane * 8 : wds + (size_t)co * 64 + (plane - 8) * 8;
+          for (int j = 0; j < 8; ++j) d[j] = host_f32_to_16(src[j], dtype);
         }
   for (int pos = 0; pos < 64; ++pos) {
     const int co = (pos & ~15) + bneck_row_channel(pos & 15);
     (*pb)[pos] = b1[co]; (*pb)[64 + pos] = b2[co];
   }
-  for (int pos = 0; pos < 256; ++pos) (*pb)[128 + pos] = b3[(pos & ~15) + bneck_row_channel(pos & 15)];
+  for (int pos = 0; pos < 256; ++pos) {
+    const int co = (pos & ~15) + bneck_row_channel(pos & 15);
+    (*pb)[128 + pos] = b3[co] + (bds ? bds[co] : 0.f);
+  }
 }
 
+template <int DT, bool PROJ>
+static int32_t bneck_launch_one(const BneckLaunch& L, hipStream_t stream) {
+  auto kern = bottleneck_kernel<DT, PROJ>;
+  constexpr int lds = PROJ ? kLdsProj : kLds;
+  static LdsOptIn big;   // per device (common.h)
+  { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(kern), lds, &big); if (rc != SCPOSE_OK) return rc; }
+  hipLaunchKernelGGL(kern, dim3(L.grid), dim3(512), lds, stream, L);
+  SCP_CHECK_HIP(hipGetLastError());
+  return SCPOSE_OK;
+}
+
+// cin = 256: identity residual; cin = 64: first Bottleneck (projection folded into conv3, see bottleneck_pack)
 int32_t bottleneck_launch(const void* in, const void* w1, const void* w2, const void* w3, const float* bias, int N, int H, int W,
-                          int dtype, void* out, hipStream_t stream) {
+                          int cin, int dtype, void* out, hipStream_t stream) {
   // the kernel addresses its tensors through 32-bit buffer descriptors: batches whose 256-channel tensor reaches 4 GiB
   // (~900 frames at 96 x 96) run as several launches over frame ranges
-  const size_t per_frame = (size_t)32 * H * W * 16;
-  SCP_REQUIRE(per_frame < 0xfffffff0ull, "bottleneck: one %dx%d frame does not fit a 32-bit buffer descriptor", H, W);
-  const int max_n = (int)(0xfffffff0ull / per_frame);
-  static LdsOptIn big_b, big_f;
+  const bool proj = cin == 64;
+  SCP_REQUIRE(cin == 64 || cin == 256, "bottleneck: Cin = %d (64 or 256)", cin);
+  const size_t in_frame = (size_t)(cin / 8) * H * W * 16, out_frame = (size_t)32 * H * W * 16;
+  SCP_REQUIRE(out_frame < 0xfffffff0ull, "bottleneck: one %dx%d frame does not fit a 32-bit buffer descriptor", H, W);
+  const int max_n = (int)(0xfffffff0ull / out_frame);
   for (int n0 = 0; n0 < N; n0 += max_n) {
     const int n = N - n0 < max_n ? N - n0 : max_n;
     BneckLaunch L{};
-    L.in = static_cast<const char*>(in) + (size_t)n0 * per_frame;
-    L.out = static_cast<char*>(out) + (size_t)n0 * per_frame;
+    L.in = static_cast<const char*>(in) + (size_t)n0 * in_frame;
+    L.out = static_cast<char*>(out) + (size_t)n0 * out_frame;
     L.w1 = w1; L.w2 = w2; L.w3 = w3; L.b1 = bias; L.b2 = bias + 64; L.b3 = bias + 128;
-    L.bytes = (uint32_t)((size_t)n * per_frame);
+    L.in_bytes = (uint32_t)((size_t)n * in_frame); L.out_bytes = (uint32_t)((size_t)n * out_frame);
     L.N = n; L.H = H; L.W = W;
     L.tiles_x = (W + kT - 1) / kT; L.tiles_y = (H + kT - 1) / kT;
     L.tiles_total = n * L.tiles_x * L.tiles_y;
@@ -409,14 +459,10 @@ int32_t bottleneck_launch(const void* in, const void* w1, const void* w2, const 
     L.tiles_per_wg = (L.tiles_total + grid - 1) / grid;
     L.grid = (L.tiles_total + L.tiles_per_wg - 1) / L.tiles_per_wg;
     { static const char* e = dev_env("SCPOSE_BNECK_DBG"); L.dbg_buf = (e && atoi(e)) ? conv_dbg_buffer(stream) : nullptr; if (L.dbg_buf) conv_dbg_set_grid(L.grid); }
-    if (dtype == SCPOSE_DT_BF16) {
-      { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(bottleneck_kernel<0>), kLds, &big_b); if (rc != SCPOSE_OK) return rc; }
-      hipLaunchKernelGGL(bottleneck_kernel<0>, dim3(L.grid), dim3(512), kLds, stream, L);
-    } else {
-      { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(bottleneck_kernel<1>), kLds, &big_f); if (rc != SCPOSE_OK) return rc; }
-      hipLaunchKernelGGL(bottleneck_kernel<1>, dim3(L.grid), dim3(512), kLds, stream, L);
-    }
-    SCP_CHECK_HIP(hipGetLastError());
+    int32_t rc;
+    if (dtype == SCPOSE_DT_BF16) rc = proj ? bneck_launch_one<0, true>(L, stream) : bneck_launch_one<0, false>(L, stream);
+    else rc = proj ? bneck_launch_one<1, true>(L, stream) : bneck_launch_one<1, false>(L, stream);
+    if (rc != SCPOSE_OK) return rc;
   }
   return SCPOSE_OK;
 }

@@ -188,12 +188,14 @@ void stem_fused_pack(const float* w1, const float* b1, const float* w2, const fl
 int32_t stem_fused_launch(const void* in, int in_fmt, const void* w1, const void* w2, const float* b1, const float* b2,
                           const float* mean_std, int N, int H, int W, int dtype, void* out, hipStream_t stream);
 
-// fused layer1 Bottleneck (bottleneck.hip): conv1 1x1 256->64, conv2 3x3 64->64, conv3 1x1 64->256 + residual in one launch
+// fused layer1 Bottleneck (bottleneck.hip): conv1 1x1 Cin->64, conv2 3x3 64->64, conv3 1x1 64->256 + residual in one launch;
+// Cin = 256: identity residual; Cin = 64: the first Bottleneck, its `downsample` projection (wds, bds) folded into conv3
 bool bottleneck_fusable(int cin, int cmid, int cout);
-void bottleneck_pack(const float* w1, const float* w2, const float* w3, const float* b1, const float* b2, const float* b3, int dtype,
+void bottleneck_pack(const float* w1, const float* w2, const float* w3, const float* wds, const float* b1, const float* b2, const float* b3,
+                     const float* bds, int cin, int dtype,
                      std::vector<uint16_t>* pw1, std::vector<uint16_t>* pw2, std::vector<uint16_t>* pw3, std::vector<float>* pb);
 int32_t bottleneck_launch(const void* in, const void* w1, const void* w2, const void* w3, const float* bias, int N, int H, int W,
-                          int dtype, void* out, hipStream_t stream);
+                          int cin, int dtype, void* out, hipStream_t stream);
 
 // ---- elementwise ---------------------------------------------------------------------------
 int32_t fuse_sum_launch(const void* const* terms, const int32_t* shifts, int nterms, int N, int C,

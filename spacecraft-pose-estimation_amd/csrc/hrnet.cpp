@@ -113,7 +113,7 @@ struct scpose_hrnet {
   void* d_stemf_w2 = nullptr;
   float* d_stemf_b1 = nullptr;
   float* d_stemf_b2 = nullptr;
-  struct Bneck { void* w1 = nullptr; void* w2 = nullptr; void* w3 = nullptr; float* bias = nullptr; };   // fused Bottlenecks (bottleneck.hip)
+  struct Bneck { void* w1 = nullptr; void* w2 = nullptr; void* w3 = nullptr; float* bias = nullptr; int cin = 256; };   // fused Bottlenecks (bottleneck.hip)
   std::vector<Bneck> bnecks;
   float* d_head_bias = nullptr; // [4][16] folded biases of the hrnet_cms heads
   int head_k = 0, head_s = 1;   // transposed-conv kernel / stride of the heads (heat-map = S * branch-0 size)
@@ -198,16 +198,22 @@ struct Builder {
     push(op);
     return op.out;
   }
-  // Bottleneck with identity residual (layer1 blocks 1-3, pose_hrnet.py:78-98): one fused launch (bottleneck.hip)
+  // Bottleneck (layer1, pose_hrnet.py:78-98): one fused launch (bottleneck.hip).  Blocks 1-3 have an identity residual;
+  // block 0 (64 input channels) projects its residual with `downsample` (1x1 conv + BN, :378-384), which rides in conv3.
   int bottleneck(int x, const std::string& p) {
     if (status != SCPOSE_OK) return -1;
-    std::vector<float> w1, b1, w2, b2, w3, b3;
-    if (!fold(*W, p + ".conv1", p + ".bn1", 64, 256, 1, false, &w1, &b1) || !fold(*W, p + ".conv2", p + ".bn2", 64, 64, 3, false, &w2, &b2) ||
-        !fold(*W, p + ".conv3", p + ".bn3", 256, 64, 1, false, &w3, &b3)) { status = SCPOSE_E_MISSING; return -1; }
+    const int cin = net->tensors[x].C;
+    const bool proj = cin == 64;
+    std::vector<float> w1, b1, w2, b2, w3, b3, wd, bd;
+    if (!fold(*W, p + ".conv1", p + ".bn1", 64, cin, 1, false, &w1, &b1) || !fold(*W, p + ".conv2", p + ".bn2", 64, 64, 3, false, &w2, &b2) ||
+        !fold(*W, p + ".conv3", p + ".bn3", 256, 64, 1, false, &w3, &b3) ||
+        (proj && !fold(*W, p + ".downsample.0", p + ".downsample.1", 256, 64, 1, false, &wd, &bd))) { status = SCPOSE_E_MISSING; return -1; }
     std::vector<uint16_t> pw1, pw2, pw3;
     std::vector<float> pb;
-    bottleneck_pack(w1.data(), w2.data(), w3.data(), b1.data(), b2.data(), b3.data(), net->desc.dtype, &pw1, &pw2, &pw3, &pb);
+    bottleneck_pack(w1.data(), w2.data(), w3.data(), proj ? wd.data() : nullptr, b1.data(), b2.data(), b3.data(), proj ? bd.data() : nullptr,
+                    cin, net->desc.dtype, &pw1, &pw2, &pw3, &pb);
     scpose_hrnet::Bneck bn;
+    bn.cin = cin;
     auto up = [&](void** d, const void* h, size_t bytes) {
       if (hipMalloc(d, bytes) != hipSuccess || hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) != hipSuccess) status = SCPOSE_E_HIP;
     };
@@ -359,7 +365,9 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
     static const char* cat_env = dev_env("SCPOSE_CAT_DOWNSAMPLE");
     const bool cat = b == 0 && !(cat_env && atoi(cat_env) == 0);
     static const char* bn_env = dev_env("SCPOSE_BNECK_FUSED");
-    if (b > 0 && net->tensors[x].C == 256 && !(bn_env && atoi(bn_env) == 0)) {   // identity-residual Bottleneck: one launch
+    static const char* bn0_env = dev_env("SCPOSE_BNECK0_FUSED");
+    if (((b > 0 && net->tensors[x].C == 256) || (b == 0 && net->tensors[x].C == 64 && cat && !(bn0_env && atoi(bn0_env) == 0))) &&
+        !(bn_env && atoi(bn_env) == 0)) {   // one launch per Bottleneck
       x = B.bottleneck(x, p);
       continue;
     }
@@ -626,7 +634,7 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
     } else if (op.kind == OP_BNECK) {
       const TensorDesc& ti = net->tensors[op.in];
       const scpose_hrnet::Bneck& bn = net->bnecks[op.conv];
-      rc = bottleneck_launch(ptr(op.in), bn.w1, bn.w2, bn.w3, bn.bias, n, h >> ti.ds, w >> ti.ds, net->desc.dtype, ptr(op.out), st);
+      rc = bottleneck_launch(ptr(op.in), bn.w1, bn.w2, bn.w3, bn.bias, n, h >> ti.ds, w >> ti.ds, bn.cin, net->desc.dtype, ptr(op.out), st);
     } else if (op.kind == OP_BLOCK) {
       const TensorDesc& ti = net->tensors[op.in];
       rc = block_launch(net->convs[op.conv], net->convs[op.conv2], ptr(op.in), n, h >> ti.ds, w >> ti.ds, ptr(op.out), st);
@@ -688,9 +696,10 @@ static void op_work(const scpose_hrnet* net, const Op& op, int h, int w, double*
     // conv2 in + out, conv3 in + residual + out)
     const TensorDesc& ti = net->tensors[op.in];
     const double px = (double)(h >> ti.ds) * (w >> ti.ds);
-    *f = 2.0 * px * (256.0 * 64 + 64.0 * 64 * 9 + 64.0 * 256);
-    *by = px * 2 * (unfused ? (256 + 64) + (64 + 64) + (64 + 256 + 256) : 256 + 256);
-    sig[1] = 131; sig[2] = 256; sig[3] = 256;
+    const double cin = ti.C;   // 256: identity residual; 64: first Bottleneck, conv3 over [t2 ; x] (the projection of the residual)
+    *f = 2.0 * px * (cin * 64 + 64.0 * 64 * 9 + 64.0 * 256 + (cin == 64 ? 64.0 * 256 : 0.0));
+    *by = px * 2 * (unfused ? (cin + 64) + (64 + 64) + (64 + cin + 256) : cin + 256);
+    sig[1] = 131; sig[2] = (int)cin; sig[3] = 256;
   } else if (op.kind == OP_HEAD) {
     const TensorDesc& ti = net->tensors[op.in];
     const double hi = h >> ti.ds, wi = w >> ti.ds, S = net->head_s, J = net->desc.num_joints;
