@@ -97,7 +97,7 @@ def cpu_baseline(cfg, sd, image, nframes, kp_sample):
     g = torch.Generator().manual_seed(123)
     mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
-    bs = 8
+    bs = 16   # the reference's TEST.BATCH_SIZE_PER_GPU (landmark_regression/experiments/events/events-config.yaml)
     t_net = t_dec = t_pnp = 0.0
     done = 0
     P.lib()
