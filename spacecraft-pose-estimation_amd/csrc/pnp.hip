@@ -28,6 +28,11 @@
 namespace scpose {
 
 static constexpr int kMaxJ = 64;
+// Lanes that own a 12x12 work matrix in LDS (144 doubles each): the hypotheses of a RANSAC batch plus the speculative
+// final fits.  32 instead of 64 halves the workgroup's LDS to 37 KB, so four one-wave workgroups share a CU instead of two
+// and a batch of frames takes half as many CUs away from the convolution kernels of the next forward (bench.py runs the
+// PnP stage beside it); the ordered replay below is independent of the batch width, so the results do not change.
+static constexpr int kPW = 32;
 
 struct PnpArgs {
   const float* kp;          // N x J x 3
@@ -174,7 +179,7 @@ __device__ void svd_solve(const double* A, const double* b, double* x) {
 
 // 12x12 one-sided Jacobi on the lane's LDS matrix; only U^T (rows) and the ordering are needed
 // (the V accumulation of JacobiSVDImpl_ does not influence U or W).
-#define UT(r, c) ut[((r) * 12 + (c)) * 64]
+#define UT(r, c) ut[((r) * 12 + (c)) * kPW]
 __device__ void jacobi12(double* ut /* = base + lane */) {
   const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
   double W[12];
@@ -656,8 +661,8 @@ __device__ int ransac_update_num_iters(double p, double ep, int model_points, in
 
 __global__ __launch_bounds__(64) void pnp_kernel(const PnpArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* s_ut = smem;                       // 144 x 64
-  double* s_obj = s_ut + 144 * 64;           // kMaxJ x 3
+  double* s_ut = smem;                       // 144 x kPW
+  double* s_obj = s_ut + 144 * kPW;          // kMaxJ x 3
   double* s_u32 = s_obj + kMaxJ * 3;         // kMaxJ x 2  (undistorted, float32-rounded, * f + c)
   double* s_u64 = s_u32 + kMaxJ * 2;         // kMaxJ x 2
   double* s_img = s_u64 + kMaxJ * 2;         // kMaxJ x 2  raw float32 image points
@@ -698,7 +703,7 @@ __global__ __launch_bounds__(64) void pnp_kernel(const PnpArgs a) {
   int status;
   EpnpCtx e;
   e.obj = s_obj; e.uc = cam.cx; e.vc = cam.cy; e.fu = cam.fx; e.fv = cam.fy;
-  double* ut = s_ut + lane;
+  double* ut = s_ut + (lane & (kPW - 1));    // wave-uniform solves: lanes l and l + kPW write the same values to the same slots
   const int model_points = 5;
 
   if (n < 4) {
@@ -725,14 +730,14 @@ __global__ __launch_bounds__(64) void pnp_kernel(const PnpArgs a) {
     // The hypothesis stream is unchanged: batches only group consecutive iterations, and the ordered scan below
     // replays the sequential accept / RANSACUpdateNumIters rule whatever the group sizes are.
     const unsigned long long full_mask = (n >= 64) ? ~0ULL : ((1ULL << n) - 1ULL);
-    const int nspec = n <= 31 ? n + 1 : 1;
-    const int sidx = 63 - lane;                                   // 0: full set, i: full set without point i - 1
-    const bool spec_lane = sidx < nspec;
+    const int nspec = n + 1 <= kPW / 2 ? n + 1 : 1;
+    const int sidx = (kPW - 1) - lane;                            // 0: full set, i: full set without point i - 1
+    const bool spec_lane = sidx >= 0 && sidx < nspec;
     const unsigned long long spec_mask = full_mask & ~(sidx > 0 && spec_lane ? 1ULL << (sidx - 1) : 0ULL);
     double spec_r[3] = {0, 0, 0}, spec_t[3] = {0, 0, 0};
     for (int iter0 = 0; iter0 < niters;) {
       const bool first = iter0 == 0;
-      const int nb = min(first ? 64 - nspec : 64, niters - iter0);
+      const int nb = min(first ? kPW - nspec : kPW, niters - iter0);
       unsigned my_packed = 0;
       for (int k = 0; k < nb; k++) {   // getSubset: duplicate-free draws, one shared RNG stream
         unsigned packed = 0;
@@ -826,7 +831,7 @@ int32_t pnp_launch(const float* kp_xyc, const double* landmarks, const double* K
   PnpArgs a{kp_xyc, landmarks, K, dist, rot, tvec, rvec, status, N, J, conf_thr0, thr_decay, min_pts, thr_iters,
             max_iters, reproj_err, confidence, 0};
   { static const char* e = dev_env("SCPOSE_PNP_SPEC"); a.dbg_no_spec = (e && atoi(e) == 0) ? 1 : 0; }
-  const size_t lds = (size_t)(144 * 64 + kMaxJ * 9) * sizeof(double);
+  const size_t lds = (size_t)(144 * kPW + kMaxJ * 9) * sizeof(double);
   static LdsOptIn big_lds;   // per device (common.h)
   { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(pnp_kernel), (int)lds, &big_lds); if (rc != SCPOSE_OK) return rc; }
   hipLaunchKernelGGL(pnp_kernel, dim3(N), dim3(64), lds, stream, a);
