@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SCPOSE_ABI_VERSION 3
+#define SCPOSE_ABI_VERSION 4
 
 enum {
   SCPOSE_OK = 0,
@@ -66,6 +66,9 @@ enum {
 
 int32_t scpose_abi_version(void);
 const char* scpose_last_error(void);
+/* 0 for the shipped library (libscpose_hip.so: no instrumentation or ablation path compiled into any kernel), 1 for the
+ * development build of the same sources (libscpose_hip_dev.so, -DSCPOSE_DEV_BUILD), which tools_dev/ loads with SCPOSE_DEV=1. */
+int32_t scpose_is_dev_build(void);
 
 /* ------------------------------------------------------------------------------------------
  * HRNet.  Replaces models.pose_hrnet.get_pose_net(cfg, is_train=False) + load_state_dict +
@@ -150,8 +153,9 @@ int32_t scpose_hrnet_forward_tap(scpose_hrnet_t h, const void* in, int32_t in_fm
 
 /* Measurement hooks (bench.py): the same forward with a HIP event recorded on `stream` before
  * every launch and after the last one, then per-launch milliseconds, algorithmic FLOPs and
- * bytes per frame and a kernel signature {kind(0 stem,1 conv,2 fuse), 10*ksize+stride | nterms,
- * Cin, Cout}.  profile_read blocks on the last event.  Call with ms == NULL to get *count. */
+ * bytes per frame and a kernel signature {kind, 10*ksize+stride | nterms, Cin, Cout} with kind
+ * 0 stem conv1 alone (two-layer stem), 1 convolution, 2 fuse sum, 3 fused BasicBlock, 4 head gather
+ * (hrnet_cms), 5 fused stem (conv1 + conv2), 6 fused Bottleneck.  profile_read blocks on the last event.  Call with ms == NULL to get *count. */
 int32_t scpose_hrnet_forward_profiled(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n,
                                       int32_t height, int32_t width, float* heatmaps,
                                       void* workspace, size_t workspace_bytes, void* stream);

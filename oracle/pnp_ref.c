@@ -48,6 +48,45 @@ static int rng_uniform(cvrng* r, int a, int b) { return a == b ? a : (int)(rng_n
 /* At: n rows of length m (the COLUMNS of the m x n matrix A, m >= n); on return rows of At
  * are the left singular vectors u_i (length m), W the singular values (descending), Vt rows the
  * right singular vectors.  Mirrors lapack.cpp JacobiSVDImpl_ (eps = 10*DBL_EPSILON). */
+/* hypot / log / integer pow as fixed sequences of IEEE-754 operations (this file is compiled with -ffp-contract=off;
+ * + - * / sqrt are correctly rounded everywhere), instead of libm's: OpenCV calls hypot (lapack.cpp JacobiSVDImpl_),
+ * log and pow (ptsetreg.cpp RANSACUpdateNumIters), whose last bits differ between C libraries.  The HIP kernel runs the
+ * same sequences (csrc/pnp.hip), so the two agree bit for bit through the Jacobi sweeps; the difference to libm's values
+ * is <= 2 ulp and only matters where the problem is ill-conditioned in the first place. */
+static double det_hypot(double a, double b) {
+  double hi, lo, r;
+  a = fabs(a); b = fabs(b);
+  hi = a > b ? a : b; lo = a > b ? b : a;
+  if (hi == 0.) return 0.;
+  r = lo / hi;
+  return hi * sqrt(1. + r * r);
+}
+static double det_log(double x) {
+  unsigned long long u;
+  int e;
+  double m, f, sq, z, pz;
+  memcpy(&u, &x, 8);
+  e = (int)((u >> 52) & 0x7ff);
+  if (e == 0) { x *= 18014398509481984.; memcpy(&u, &x, 8); e = (int)((u >> 52) & 0x7ff) - 54; }
+  e -= 1023;
+  u = (u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+  memcpy(&m, &u, 8);
+  if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+  f = m - 1.; sq = f / (2. + f); z = sq * sq;
+  pz = 1. / 27.;
+  pz = pz * z + 1. / 25.; pz = pz * z + 1. / 23.; pz = pz * z + 1. / 21.; pz = pz * z + 1. / 19.;
+  pz = pz * z + 1. / 17.; pz = pz * z + 1. / 15.; pz = pz * z + 1. / 13.; pz = pz * z + 1. / 11.;
+  pz = pz * z + 1. / 9.; pz = pz * z + 1. / 7.; pz = pz * z + 1. / 5.; pz = pz * z + 1. / 3.;
+  pz = pz * z + 1.;
+  return (double)e * 0.6931471805599453 + 2. * sq * pz;
+}
+static double det_powi(double x, int n) {
+  double r = 1.;
+  int i;
+  for (i = 0; i < n; i++) r = r * x;
+  return r;
+}
+
 static void jacobi_svd(double* At, double* W, double* Vt, int m, int n) {
   const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
   int i, j, k, iter, max_iter = m > 30 ? m : 30;
@@ -68,7 +107,7 @@ static void jacobi_svd(double* At, double* W, double* Vt, int m, int n) {
         if (fabs(p) <= eps * sqrt(a * b)) continue;
         p *= 2;
         {
-          double beta = a - b, gamma = hypot(p, beta);
+          double beta = a - b, gamma = det_hypot(p, beta);
           if (beta < 0) {
             double delta = (gamma - beta) * 0.5;
             s = sqrt(delta / gamma);
@@ -628,10 +667,10 @@ static int ransac_update_num_iters(double p, double ep, int model_points, int ma
   p = p > 0. ? p : 0.; p = p < 1. ? p : 1.;
   ep = ep > 0. ? ep : 0.; ep = ep < 1. ? ep : 1.;
   num = (1. - p) > DBL_MIN ? (1. - p) : DBL_MIN;
-  denom = 1. - pow(1. - ep, model_points);
+  denom = 1. - det_powi(1. - ep, model_points);
   if (denom < DBL_MIN) return 0;
-  num = log(num);
-  denom = log(denom);
+  num = det_log(num);
+  denom = det_log(denom);
   return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)lrint(num / denom);
 }
 

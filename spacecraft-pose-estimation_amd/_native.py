@@ -10,12 +10,18 @@ from ctypes import (POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_si
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libscpose_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-if os.environ.get("SCPOSE_DEV") == "1" and os.environ.get("SCPOSE_LIB"):
-    LIB_PATH = os.path.abspath(os.environ["SCPOSE_LIB"])   # development A/B runs of two builds on one box (tools_dev/README.md)
+DEV_LIB_PATH = os.path.join(_HERE, "libscpose_hip_dev.so")   # same sources, -DSCPOSE_DEV_BUILD (csrc/Makefile: make dev)
+if os.environ.get("SCPOSE_DEV") == "1":
+    # developer scripts only (tools_dev/README.md): an explicit build for A/B runs, else the development build -- the
+    # only one whose kernels contain the phase stamps and ablation switches -- when it has been built
+    if os.environ.get("SCPOSE_LIB"):
+        LIB_PATH = os.path.abspath(os.environ["SCPOSE_LIB"])
+    elif os.path.exists(DEV_LIB_PATH):
+        LIB_PATH = DEV_LIB_PATH
 
 DT_BF16, DT_F16 = 0, 1
 IN_F32_NCHW, IN_U8_NHWC = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class HrnetDesc(ctypes.Structure):
@@ -38,6 +44,7 @@ class HrnetDesc(ctypes.Structure):
 SYMBOLS = {
     "scpose_abi_version": (c_int32, []),
     "scpose_last_error": (c_char_p, []),
+    "scpose_is_dev_build": (c_int32, []),
     "scpose_hrnet_create": (c_int32, [POINTER(HrnetDesc), POINTER(c_char_p), POINTER(c_void_p),
                                       POINTER(c_int64), c_int32, c_int32, POINTER(c_void_p)]),
     "scpose_hrnet_destroy": (c_int32, [c_void_p]),

@@ -8,6 +8,7 @@ using namespace scpose;
 struct scpose_conv { PackedConv pc; };
 
 extern "C" int32_t scpose_abi_version(void) { return SCPOSE_ABI_VERSION; }
+extern "C" int32_t scpose_is_dev_build(void) { return scpose::kDevBuild ? 1 : 0; }
 extern "C" const char* scpose_last_error(void) { return last_error(); }
 
 extern "C" int32_t scpose_decode(const float* heatmaps, int32_t n, int32_t j, int32_t h, int32_t w,

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
   __builtin_amdgcn_s_barrier();                            // W1 and the biases are in LDS
 
   unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
-  auto now = [&]() -> unsigned long long { return p.dbg_buf ? __builtin_amdgcn_s_memtime() : 0ull; };
+  auto now = [&]() -> unsigned long long { return SCP_DBG_BUF(p) ? __builtin_amdgcn_s_memtime() : 0ull; };
   int xbuf = 0;
   for (int t = t_begin; t < t_end; ++t, xbuf ^= 1) {
     int img, oy0, ox0;
@@ -364,13 +364,13 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
       pair(std::integral_constant<int, 3>{}); pair(std::integral_constant<int, 4>{}); pair(std::integral_constant<int, 5>{});
       pair(std::integral_constant<int, 6>{}); pair(std::integral_constant<int, 7>{});
     }
-    if (p.dbg_buf) {   // [A][barrier][B][barrier][C]
+    if (SCP_DBG_BUF(p)) {   // [A][barrier][B][barrier][C]
       const unsigned long long ts5 = now();
       tph[0] += ts1 - ts0; tph[1] += ts2 - ts1; tph[2] += ts3 - ts2; tph[3] += ts4 - ts3; tph[4] += ts5 - ts4;
     }
   }
-  if (p.dbg_buf && lane == 0)
-    for (int k = 0; k < 6; ++k) p.dbg_buf[((size_t)blockIdx.x * 8 + wave) * 6 + k] = tph[k];
+  if (SCP_DBG_BUF(p) && lane == 0)
+    for (int k = 0; k < 6; ++k) SCP_DBG_BUF(p)[((size_t)blockIdx.x * 8 + wave) * 6 + k] = tph[k];
 }
 
 // ---- host ----
@@ -458,7 +458,7 @@ int32_t bottleneck_launch(const void* in, const void* w1, const void* w2, const 
     if (grid > L.tiles_total) grid = L.tiles_total;
     L.tiles_per_wg = (L.tiles_total + grid - 1) / grid;
     L.grid = (L.tiles_total + L.tiles_per_wg - 1) / L.tiles_per_wg;
-    { static const char* e = dev_env("SCPOSE_BNECK_DBG"); L.dbg_buf = (e && atoi(e)) ? conv_dbg_buffer(stream) : nullptr; if (L.dbg_buf) conv_dbg_set_grid(L.grid); }
+    { static const char* e = dev_env("SCPOSE_BNECK_DBG"); L.dbg_buf = (kDevBuild && e && atoi(e)) ? conv_dbg_buffer(stream) : nullptr; if (L.dbg_buf) conv_dbg_set_grid(L.grid); }
     int32_t rc;
     if (dtype == SCPOSE_DT_BF16) rc = proj ? bneck_launch_one<0, true>(L, stream) : bneck_launch_one<0, false>(L, stream);
     else rc = proj ? bneck_launch_one<1, true>(L, stream) : bneck_launch_one<1, false>(L, stream);

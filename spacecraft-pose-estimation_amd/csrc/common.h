@@ -34,6 +34,22 @@ const char* last_error();
     }                                     \
   } while (0)
 
+// Development instrumentation and ablation switches (phase stamps, "skip the MFMA loop" and the like) exist only in
+// the DEVELOPMENT build of the library (make dev -> libscpose_hip_dev.so, -DSCPOSE_DEV_BUILD, loaded by tools_dev/ through
+// SCPOSE_DEV=1).  In the shipped libscpose_hip.so these fold to constants at compile time: its kernels contain no
+// switchable wrong-results path and never read the dbg fields of their launch descriptors.
+#ifdef SCPOSE_DEV_BUILD
+#define SCP_DBG(p, bits) ((p).dbg & (bits))
+#define SCP_DBG_BUF(p) ((p).dbg_buf)
+#define SCP_DEV_ONLY(x) (x)
+constexpr bool kDevBuild = true;
+#else
+#define SCP_DBG(p, bits) (0)
+#define SCP_DBG_BUF(p) (static_cast<unsigned long long*>(nullptr))
+#define SCP_DEV_ONLY(x) (0)
+constexpr bool kDevBuild = false;
+#endif
+
 // Kernels that use more than 64 KB of dynamic LDS must be opted in with hipFuncSetAttribute, which applies to the
 // device that is current at the call.  One memo per kernel instantiation, indexed by device: the attribute is set the
 // first time that instantiation is launched on each device (idempotent per-device memoisation like conv_zero_page();
@@ -96,8 +112,9 @@ struct ConvLaunch {
   uint32_t in_bytes, out_bytes;   // sizes of the input / output (= residual) tensors when both are < 4 GiB
                                   // (buffer-addressed global traffic, conv_pipe_kernel.h: dma16_buf), else 0 (64-bit
                                   // addressing).  conv_pipe: out_bytes = size of in2 (K-concatenated second input).
-  unsigned long long* dbg_buf;  // development: per-workgroup phase cycle sums (dbg & 8), else null
-  int32_t dbg;           // development ablation bits (0 in production): 1 skip MFMA loop, 2 skip epilogue, 4 skip input DMA
+  unsigned long long* dbg_buf;  // development build only (SCP_DBG_BUF): per-workgroup phase cycle sums (dbg & 8), else null
+  int32_t dbg;           // development build only (SCP_DBG): ablation bits 1 skip MFMA loop, 2 skip epilogue, 4 skip input DMA;
+                         // the shipped library's kernels never read either field
   int32_t cu_share;      // host only: CUs to size the layer for (0 = the whole chip)
 };
 

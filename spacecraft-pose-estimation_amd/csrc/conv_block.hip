@@ -39,7 +39,7 @@ int32_t block_launch(const PackedConv& c1, const PackedConv& c2, const void* in,
   if (grid > L.tiles_total) grid = L.tiles_total;
   L.tiles_per_wg = (L.tiles_total + grid - 1) / grid;
   L.grid = (L.tiles_total + L.tiles_per_wg - 1) / L.tiles_per_wg;
-  { static const char* e = dev_env("SCPOSE_DBG"); const int dbg = e ? atoi(e) : 0;
+  { static const char* e = dev_env("SCPOSE_DBG"); const int dbg = (kDevBuild && e) ? atoi(e) : 0;
     L.dbg_buf = (dbg & 8) ? conv_dbg_buffer(stream) : nullptr;
     if (dbg & 8) conv_dbg_set_grid(L.grid); }
   const int mrep = c1.cin / 16;

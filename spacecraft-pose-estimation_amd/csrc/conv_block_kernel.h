@@ -230,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
   }
 
   unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
-  auto now = [&]() -> unsigned long long { return p.dbg_buf ? __builtin_amdgcn_s_memtime() : 0ull; };
+  auto now = [&]() -> unsigned long long { return SCP_DBG_BUF(p) ? __builtin_amdgcn_s_memtime() : 0ull; };
   for (int t = t_begin; t < t_end; ++t) {
     const unsigned long long t0 = now();
     int img, oy0, ox0;
@@ -316,14 +316,14 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
     // conv2 epilogue of waves 4-7 into the next tile (a stagger between the two waves of a SIMD) measured no gain either.)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                   // ... and the intermediate tile is free again
-    if (p.dbg_buf) {   // [conv1 loop][conv1 epilogue][barrier][DMA issue][conv2 loop][conv2 epilogue + end wait/barrier]
+    if (SCP_DBG_BUF(p)) {   // [conv1 loop][conv1 epilogue][barrier][DMA issue][conv2 loop][conv2 epilogue + end wait/barrier]
       const unsigned long long t7 = now();
       tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; tph[3] += t4 - t3; tph[4] += t5 - t4; tph[5] += t7 - t5;
       (void)t6;
     }
   }
-  if (p.dbg_buf && lane == 0)
-    for (int k = 0; k < 6; ++k) p.dbg_buf[((size_t)blockIdx.x * 8 + wave) * 6 + k] = tph[k];
+  if (SCP_DBG_BUF(p) && lane == 0)
+    for (int k = 0; k < 6; ++k) SCP_DBG_BUF(p)[((size_t)blockIdx.x * 8 + wave) * 6 + k] = tph[k];
 }
 
 template <int DT, int MREP>

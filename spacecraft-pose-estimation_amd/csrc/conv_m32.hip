@@ -215,6 +215,7 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
     L.total_blocks = (b_occ == 3 && v > 0 && v <= pc.nchunks - 2) ? v : 0; }
   L.items_total = ((L.tiles_total + L.nt - 1) / L.nt) * pc.n_mblk;
   { static const char* e = dev_env("SCPOSE_DBG"); L.dbg = e ? atoi(e) : 0; }
+  if (!kDevBuild) L.dbg &= 32;   // shipped library: only the host-side "print the tile choice" bit means anything (common.h: SCP_DBG)
   {   // producer/consumer kernel: buffer-addressed global traffic when both tensors fit a 32-bit descriptor
     static const char* e = dev_env("SCPOSE_M32_BUF");
     const size_t ib = (size_t)L.N * L.cin_planes * L.H * L.W * 16, ob = (size_t)L.N * ((pc.cout + 7) / 8) * L.Ho * L.Wo * 16;

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, OCC) void conv_m32_kernel(const ConvLaunch p) 
       const bool ok = img >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       // buffer addressing (p.in_bytes != 0): the slot holds a 32-bit offset, BUF_OOB for padding pixels
       if (p.in_bytes) xoff[i] = ok ? (size_t)((uint32_t)(img * p.cin_planes * HW + iy * p.W + ix) * 16u) : (size_t)BUF_OOB;
-      else xoff[i] = ok ? ((size_t)((p.dbg & 64) ? 0 : img) * p.cin_planes * HW + (size_t)(iy * p.W + ix)) * 16 : ~(size_t)0;
+      else xoff[i] = ok ? ((size_t)(SCP_DBG(p, 64) ? 0 : img) * p.cin_planes * HW + (size_t)(iy * p.W + ix)) * 16 : ~(size_t)0;
     }
   };
   const buf_rsrc_t rs_in = make_buf(p.in, p.in_bytes);
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, OCC) void conv_m32_kernel(const ConvLaunch p) 
   // spread the weight-chunk reads of lock-stepped CUs over L2, measured no faster and made a frame's result depend
   // on which workgroup computed it, i.e. on its position in the batch.)
   auto issue_x = [&](int cl, int xb) {
-    if (p.dbg & 4) return;
+    if SCP_DBG(p, 4) return;
     const int c = cl;
     const int planes = c == p.nchunks - 1 ? planes_last : p.cp;
     const char* inb = static_cast<const char*>(p.in) + (size_t)c * p.cp * HW * 16;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, OCC) void conv_m32_kernel(const ConvLaunch p) 
 
   int xb = 0;
   unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
-  auto now = [&]() -> unsigned long long { return (p.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull; };
+  auto now = [&]() -> unsigned long long { return SCP_DBG(p, 8) ? __builtin_amdgcn_s_memtime() : 0ull; };
   for (int it = it_begin; it < it_end; ++it) {
     const int mb = it - fdiv(it, p.fd_nmblk) * p.n_mblk;
     const int plane0 = (mb * MT + wm * (MR * 32)) >> 3;   // first output plane of this wave's rows
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256, OCC) void conv_m32_kernel(const ConvLaunch p) 
           pixel_of(n, ps, py, px);
           decode_tile(it, ps, img, oy0, ox0);
           const int oy = oy0 + py, ox = ox0 + px;
-          const bool ok = img >= 0 && oy < p.Ho && ox < p.Wo && !(p.dbg & 2);
+          const bool ok = img >= 0 && oy < p.Ho && ox < p.Wo && !SCP_DBG(p, 2);
           pbase[n] = ok ? ((size_t)img * cout_planes * HoWo + (size_t)oy * p.Wo + ox) * 16 : ~(size_t)0;
         }
         if constexpr (OCC == 1)
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, OCC) void conv_m32_kernel(const ConvLaunch p) 
       const unsigned long long t1 = now();
       {  // (3) MFMA loop: plane pairs x KK taps, taps unrolled so that every LDS offset is an immediate
         const int planes = last ? planes_last : p.cp;
-        const int npp = (p.dbg & 1) ? 0 : planes >> 1;
+        const int npp = SCP_DBG(p, 1) ? 0 : planes >> 1;
         const uint32_t xl = (uint32_t)(size_t)(xl0 + xb * p.lds_x) + half * p.plane_stride;
         uint32_t wa = (uint32_t)(size_t)(wl0 + (w_resident ? 0 : (wc & 1)) * p.lds_w) + (half * MT + wm * (MR * 32) + r) * 16;
         const int hw16 = p.halo_w * 16;
@@ -469,9 +469,9 @@ __global__ __launch_bounds__(256, OCC) void conv_m32_kernel(const ConvLaunch p) 
                 *reinterpret_cast<u32x4*>(static_cast<char*>(p.out) + pbase[n] + (size_t)pl * HoWo * 16) = slot[m][n][g];
             }
       }
-      if (p.dbg & 8) {
+      if SCP_DBG(p, 8) {
         const unsigned long long t6 = now();
-        if (p.dbg & 256) {   // finer split of the front of the stage: [zero+residual][locate][X issue][W issue][MFMA][rest]
+        if SCP_DBG(p, 256) {   // finer split of the front of the stage: [zero+residual][locate][X issue][W issue][MFMA][rest]
           tph[0] += ta - t0; tph[1] += tb - ta; tph[2] += tc - tb; tph[3] += t1 - tc; tph[4] += t2 - t1; tph[5] += t6 - t2;
         } else {
           tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; tph[3] += t4 - t3; tph[4] += t5 - t4; tph[5] += t6 - t5;
@@ -480,8 +480,8 @@ __global__ __launch_bounds__(256, OCC) void conv_m32_kernel(const ConvLaunch p) 
       xb ^= 1;
     }
   }
-  if ((p.dbg & 8) && p.dbg_buf && lane == 0)
-    for (int k = 0; k < 6; ++k) p.dbg_buf[((size_t)blockIdx.x * 8 + wave) * 6 + k] = tph[k];
+  if (SCP_DBG(p, 8) && SCP_DBG_BUF(p) && lane == 0)
+    for (int k = 0; k < 6; ++k) SCP_DBG_BUF(p)[((size_t)blockIdx.x * 8 + wave) * 6 + k] = tph[k];
 }
 
 // ---- launch dispatch (instantiated per dtype in conv_m32_bf16.hip / conv_m32_f16.hip) ----

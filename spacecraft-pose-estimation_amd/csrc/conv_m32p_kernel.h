@@ -248,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
           }
     };
 
-    if (!(p.dbg & 128)) __builtin_amdgcn_s_setprio(3);   // memory instructions ahead of the consumers' MFMA stream
+    if (!SCP_DBG(p, 128)) __builtin_amdgcn_s_setprio(3);   // memory instructions ahead of the consumers' MFMA stream
     size_t qb_cur[NQ], qb_prev[NQ];
 #pragma unroll
     for (int k = 0; k < NQ; ++k) qb_cur[k] = qb_prev[k] = buf ? (size_t)BUF_OOB : ~(size_t)0;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
 
     const int n_ld = p.nchunks - 1 - n_st;   // stages that load residual rows
     unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
-    auto now = [&]() -> unsigned long long { return (p.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull; };
+    auto now = [&]() -> unsigned long long { return SCP_DBG(p, 8) ? __builtin_amdgcn_s_memtime() : 0ull; };
     for (int it = it_begin; it < it_end; ++it) {
       locate_out(it, qb_cur);
       for (int c = 0; c < p.nchunks; ++c, ++wc) {
@@ -280,15 +280,15 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
         // Issue order = expected latency, longest first: the retire-buffer traffic and the halos come from
         // HBM, the weights from L2; everything is waited for once, at the end of the stage.
         if (c < n_st) {
-          if (it > it_begin && !(p.dbg & 2)) store_results(it - 1, qb_prev, ROPL * c / n_st, ROPL * (c + 1) / n_st);
-        } else if (!last && p.res && !(p.dbg & 2)) {
+          if (it > it_begin && !SCP_DBG(p, 2)) store_results(it - 1, qb_prev, ROPL * c / n_st, ROPL * (c + 1) / n_st);
+        } else if (!last && p.res && !SCP_DBG(p, 2)) {
           load_residual(it, qb_cur, ROPL * (c - n_st) / n_ld, ROPL * (c - n_st + 1) / n_ld);
         }
         const unsigned long long t1 = now();
         unsigned long long t2 = t1;
         if (nit < it_end) {   // DMA for the next stage
           if (nc == 0) locate_halo(nit);
-          if (!(p.dbg & 4)) issue_x(nc, xb ^ 1);
+          if (!SCP_DBG(p, 4)) issue_x(nc, xb ^ 1);
           t2 = now();
           if (!w_resident) issue_w(nit, nc, (wc + 1) & 1);
         }
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const unsigned long long t4 = now();
         __builtin_amdgcn_s_barrier();
-        if (p.dbg & 8) {   // producers: [retire-buffer traffic][locate + X issue][W issue][wait][barrier]
+        if SCP_DBG(p, 8) {   // producers: [retire-buffer traffic][locate + X issue][W issue][wait][barrier]
           const unsigned long long t5 = now();
           tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; tph[3] += t4 - t3; tph[4] += t5 - t4;
         }
@@ -305,9 +305,9 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
 #pragma unroll
       for (int k = 0; k < NQ; ++k) qb_prev[k] = qb_cur[k];
     }
-    if (it_begin < it_end && !(p.dbg & 2)) store_results(it_end - 1, qb_prev, 0, ROPL);   // drain the last tile
-    if ((p.dbg & 8) && p.dbg_buf && lane == 0)
-      for (int k = 0; k < 6; ++k) p.dbg_buf[((size_t)blockIdx.x * 8 + wave_all) * 6 + k] = tph[k];
+    if (it_begin < it_end && !SCP_DBG(p, 2)) store_results(it_end - 1, qb_prev, 0, ROPL);   // drain the last tile
+    if (SCP_DBG(p, 8) && SCP_DBG_BUF(p) && lane == 0)
+      for (int k = 0; k < 6; ++k) SCP_DBG_BUF(p)[((size_t)blockIdx.x * 8 + wave_all) * 6 + k] = tph[k];
   } else {
     // =====================================================================================
     // consumers: LDS reads, MFMAs, epilogue into the retire buffer
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
     __syncthreads();   // matches the producers' prologue barrier
 
     unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
-    auto now = [&]() -> unsigned long long { return (p.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull; };
+    auto now = [&]() -> unsigned long long { return SCP_DBG(p, 8) ? __builtin_amdgcn_s_memtime() : 0ull; };
     for (int it = it_begin; it < it_end; ++it) {
       const int mb = it - fdiv(it, p.fd_nmblk) * p.n_mblk;
       for (int c = 0; c < p.nchunks; ++c, ++wc) {
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
           }
         }
         {  // MFMA loop: plane pairs x KK taps, taps unrolled so that every LDS offset is an immediate
-          const int npp = (p.dbg & 1) ? 0 : ((p.dbg & 256) ? 2 : 1) * (p.cp >> 1);   // dbg 256: every stage's MFMA loop twice (timing experiment, wrong results)
+          const int npp = SCP_DBG(p, 1) ? 0 : (SCP_DBG(p, 256) ? 2 : 1) * (p.cp >> 1);   // dbg 256: every stage's MFMA loop twice (timing experiment, wrong results)
           const uint32_t xl = (uint32_t)(size_t)(xl0 + xb * p.lds_x) + half * p.plane_stride;
           const int cidx = c;
           uint32_t wa = (uint32_t)(size_t)(wl0 + (w_resident ? cidx : (wc & 1)) * p.lds_w) + (half * MT + r) * 16;
@@ -480,15 +480,15 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned long long t2 = now();
         __builtin_amdgcn_s_barrier();
-        if (p.dbg & 8) {   // consumers: [zero + MFMA loop][epilogue][barrier]
+        if SCP_DBG(p, 8) {   // consumers: [zero + MFMA loop][epilogue][barrier]
           const unsigned long long t3 = now();
           tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2;
         }
         xb ^= 1;
       }
     }
-    if ((p.dbg & 8) && p.dbg_buf && lane == 0)
-      for (int k = 0; k < 6; ++k) p.dbg_buf[((size_t)blockIdx.x * 8 + wave_all) * 6 + k] = tph[k];
+    if (SCP_DBG(p, 8) && SCP_DBG_BUF(p) && lane == 0)
+      for (int k = 0; k < 6; ++k) SCP_DBG_BUF(p)[((size_t)blockIdx.x * 8 + wave_all) * 6 + k] = tph[k];
   }
 }
 

@@ -77,7 +77,7 @@ int32_t conv_launch_pipe(const PackedConv& pc, ConvLaunch& L, int nrep, int nt, 
   L.fd_nmblk = make_fastdiv(pc.n_mblk);
   L.nt = nt;
   L.items_total = ((L.tiles_total + nt * groups - 1) / (nt * groups)) * pc.n_mblk;
-  { static const char* e = dev_env("SCPOSE_DBG"); L.dbg = e ? atoi(e) : 0; }
+  { static const char* e = dev_env("SCPOSE_DBG"); L.dbg = (kDevBuild && e) ? atoi(e) : 0; }
   L.dbg_buf = nullptr;
   if (L.dbg & 8) L.dbg_buf = conv_dbg_buffer(stream);
   const int cus = conv_device_cus();

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
   auto issue_x = [&](int it, int j, int c, int xb) {       // input planes of chunk c for tile j of item it
     int img, oy0, ox0;
     decode_tile(it, j, img, oy0, ox0);
-    if (img < 0 || (p.dbg & 4)) return;
+    if (img < 0 || SCP_DBG(p, 4)) return;
     const int planes = c == p.nchunks - 1 ? planes_last : p.cp;
     const int iy0 = oy0 * STRIDE - (KS / 2), ix0 = ox0 * STRIDE - (KS / 2);
     // K-concatenated 1x1 layers read the chunks past split_planes from a second tensor (its own plane count)
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
   int xb = 0;                 // X buffer of the stage being computed
   // development instrumentation (dbg & 8): cycles spent per phase, summed over the launch
   unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
-  auto now = [&]() -> unsigned long long { return (p.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull; };
+  auto now = [&]() -> unsigned long long { return SCP_DBG(p, 8) ? __builtin_amdgcn_s_memtime() : 0ull; };
   for (int it = it_begin; it < it_end; ++it) {
     const int mb = item_mb(it);
     for (int c = 0; c < p.nchunks; ++c, ++wc) {
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
 #pragma unroll
             for (int np = 0; np < NPAIR; ++np) {
               const int oy = oy0 + epy[np], ox = ox0 + epx[np];
-              const bool ok = img >= 0 && epy[np] >= 0 && oy < p.Ho && ox < p.Wo && co_plane < p.cout && !(p.dbg & 2);
+              const bool ok = img >= 0 && epy[np] >= 0 && oy < p.Ho && ox < p.Wo && co_plane < p.cout && !SCP_DBG(p, 2);
               ooff[m][np] = ok ? (uint32_t)((((size_t)(co_plane >> 3)) * HoWo + (size_t)oy * p.Wo + ox) * 16) : 0xffffffffu;
               slot[m][np] = u32x4{0u, 0u, 0u, 0u};
             }
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
         if (img >= 0) {  // (3) MFMA loop over the chunk's k-steps: fragments one step ahead, k-offsets two
           const int planes = last ? planes_last : p.cp;
           const int npt = (planes >> 1) * KK;
-          const int ksteps = (p.dbg & 1) ? 0 : (npt + 1) >> 1;
+          const int ksteps = SCP_DBG(p, 1) ? 0 : (npt + 1) >> 1;
           const int klast = ksteps - 1;
           const char* xl = xl0 + (grp * 2 + xb) * p.lds_x;
           const char* wq = wl0 + (w_resident ? 0 : (wc & 1)) * p.lds_w + (q * MT + r) * 16;
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
               for (int np = 0; np < NPAIR; ++np)
                 if (ooff[m][np] != 0xffffffffu)
                   *reinterpret_cast<u32x4*>(static_cast<char*>(p.out) + img_off + ooff[m][np]) = slot[m][np];
-          } else if (!(p.dbg & 2)) {   // final layer: few channels, float32 NCHW, 4-byte stores
+          } else if (!SCP_DBG(p, 2)) {   // final layer: few channels, float32 NCHW, 4-byte stores
 #pragma unroll
             for (int m = 0; m < MREP; ++m) {
               const int co = mb * MT + m * 16 + psel * 8 + half * 4;
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
             }
           }
         }
-        if (p.dbg & 8) {
+        if SCP_DBG(p, 8) {
           const unsigned long long t6 = now();
           tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; tph[3] += t4 - t3; tph[4] += t5 - t4; tph[5] += t6 - t5;
         }
@@ -522,8 +522,8 @@ __global__ __launch_bounds__(256 * G, (G == 2) ? 2 : OCC) void conv_pipe_kernel(
       if constexpr (NT > 2) stage(std::integral_constant<int, 2>{});
     }
   }
-  if ((p.dbg & 8) && p.dbg_buf && lane == 0)
-    for (int k = 0; k < 6; ++k) p.dbg_buf[((size_t)blockIdx.x * 8 + wave_all) * 6 + k] = tph[k];
+  if (SCP_DBG(p, 8) && SCP_DBG_BUF(p) && lane == 0)
+    for (int k = 0; k < 6; ++k) SCP_DBG_BUF(p)[((size_t)blockIdx.x * 8 + wave_all) * 6 + k] = tph[k];
 }
 
 // ---- launch dispatch (instantiated per dtype in conv_pipe_bf16.hip / conv_pipe_f16.hip) ----

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvLaunch p) {
     }
     int img, oy0, ox0;
     decode_tile(it, img, oy0, ox0);
-    if (img < 0 || (p.dbg & 4)) return cnt;
+    if (img < 0 || SCP_DBG(p, 4)) return cnt;
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
     const char* inb = static_cast<const char*>(p.in) + ((size_t)img * p.cin_planes + (size_t)c * p.cp) * HW * 16;
     char* xl = xl0 + (grp * 2 + (s & 1)) * p.lds_x;
@@ -179,13 +179,13 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvLaunch p) {
   auto slot_off = [&](int m, int np, int mb, int img, int oy0, int ox0) -> uint32_t {
     const int co_plane = mb * MT + m * 16 + psel * 8;
     const int oy = oy0 + epy[np], ox = ox0 + epx[np];
-    const bool ok = img >= 0 && epy[np] >= 0 && oy < p.Ho && ox < p.Wo && co_plane < p.cout && !(p.dbg & 2);
+    const bool ok = img >= 0 && epy[np] >= 0 && oy < p.Ho && ox < p.Wo && co_plane < p.cout && !SCP_DBG(p, 2);
     return ok ? (uint32_t)((((size_t)(co_plane >> 3)) * HoWo + (size_t)oy * p.Wo + ox) * 16) : 0xffffffffu;
   };
 
   // development instrumentation (dbg & 8)
   unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
-  auto now = [&]() -> unsigned long long { return (p.dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull; };
+  auto now = [&]() -> unsigned long long { return SCP_DBG(p, 8) ? __builtin_amdgcn_s_memtime() : 0ull; };
 
   // phase 0: stages 0 and 1 (each group its tile chunks and weight halves)
   issue_stage(0);
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvLaunch p) {
       if (img >= 0) {
         const int planes = last ? planes_last : p.cp;
         const int npt = (planes >> 1) * KK;
-        const int ksteps = (p.dbg & 1) ? 0 : (npt + 1) >> 1;
+        const int ksteps = SCP_DBG(p, 1) ? 0 : (npt + 1) >> 1;
         const char* xl = xl0 + (grp * 2 + (s & 1)) * p.lds_x;
         const char* wq = wl0 + (s % 3) * p.lds_w + (q * MT + r) * 16;
         const int* kt = koff + (last ? 64 : 0) + q;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvLaunch p) {
       // the DMA and stores this group issued one phase ago have had this whole phase to complete
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned long long t3 = now();
-      if (p.dbg & 8) { tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; }
+      if SCP_DBG(p, 8) { tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; }
     } else if (u >= 1 && (u & 1)) {
       // ------- issue the DMA of stage s+2; while it queues, retire stage s's tile if s was its last chunk -------
       const int s = (u - 1) >> 1;
@@ -316,15 +316,15 @@ __global__ __launch_bounds__(512, 2) void conv_stag_kernel(const ConvLaunch p) {
           }
         }
       }
-      if (p.dbg & 8) { tph[5] += now() - t0; }
+      if SCP_DBG(p, 8) { tph[5] += now() - t0; }
     }
     const unsigned long long tb = now();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (p.dbg & 8) tph[4] += now() - tb;
+    if SCP_DBG(p, 8) tph[4] += now() - tb;
   }
-  if ((p.dbg & 8) && p.dbg_buf && lane == 0)
-    for (int k = 0; k < 6; ++k) p.dbg_buf[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 6 + k] = tph[k];
+  if (SCP_DBG(p, 8) && SCP_DBG_BUF(p) && lane == 0)
+    for (int k = 0; k < 6; ++k) SCP_DBG_BUF(p)[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 6 + k] = tph[k];
 }
 
 template <int DT, int MREP, int NREP>

@@ -672,7 +672,7 @@ static void op_work(const scpose_hrnet* net, const Op& op, int h, int w, double*
     // + the H/2 x W/2 tensor written once and read once)
     *f = 2.0 * 27 * 64 * (h / 2) * (w / 2) + 2.0 * 64 * 64 * 9 * (h / 4) * (w / 4);
     *by = (double)64 * (h / 4) * (w / 4) * 2 + 3.0 * h * w + (unfused ? 2.0 * 64 * (h / 2) * (w / 2) * 2 : 0.0);
-    sig[0] = OP_STEM; sig[1] = 32; sig[2] = 3; sig[3] = 64;
+    sig[1] = 32; sig[2] = 3; sig[3] = 64;   // sig[0] stays OP_STEM2 (5): the fused stem is its own kernel class
   } else if (op.kind == OP_CONV) {
     const PackedConv& pc = net->convs[op.conv];
     const TensorDesc& ti = net->tensors[op.in];
@@ -888,10 +888,14 @@ extern "C" int32_t scpose_hrnet_graph_create(scpose_hrnet_t h, const void* in, i
     for (auto& e : g->lanes.fork) GC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : g->lanes.join) GC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
-  // one eager forward on this device first: per-device kernel attributes, zero page and tile tables exist before capture
-  int32_t rc = hrnet_forward(h, in, in_fmt, n, height, width, heatmaps, workspace, workspace_bytes, g->cap, false, -1, 1, nullptr);
+  // One eager forward on this device first, through the SAME path the capture takes (same lanes, hence the same cu_share,
+  // tilings and kernel instantiations per layer): per-device kernel attributes (hipFuncSetAttribute), the zero page and the
+  // tile memos all exist before hipStreamBeginCapture, so the capture records nothing but launches (scpose.h contract).
+  int32_t rc = hrnet_forward(h, in, in_fmt, n, height, width, heatmaps, workspace, workspace_bytes, g->cap, false, -1, 1,
+                             concurrent ? &g->lanes : nullptr);
   if (rc != SCPOSE_OK) return fail(rc);
-  GC(hipStreamSynchronize(g->cap));
+  GC(hipStreamSynchronize(g->cap));   // the lanes were joined to g->cap at their epoch boundaries
+  if (concurrent) for (auto& st : g->lanes.side) GC(hipStreamSynchronize(st));
   GC(hipStreamBeginCapture(g->cap, hipStreamCaptureModeThreadLocal));
   rc = hrnet_forward(h, in, in_fmt, n, height, width, heatmaps, workspace, workspace_bytes, g->cap, false, -1, 1,
                      concurrent ? &g->lanes : nullptr);

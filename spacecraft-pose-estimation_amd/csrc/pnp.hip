@@ -29,7 +29,7 @@ namespace scpose {
 
 static constexpr int kMaxJ = 64;
 // Lanes that own a 12x12 work matrix in LDS (144 doubles each): the hypotheses of a RANSAC batch plus the speculative
-// final fits.  32 instead of 64 halves the workgroup's LDS to 37 KB, so four one-wave workgroups share a CU instead of two
+// final fits.  32 instead of 64 halves the workgroup's LDS to 36 KB + 72 B per landmark, so four one-wave workgroups share a CU instead of two
 // and a batch of frames takes half as many CUs away from the convolution kernels of the next forward (bench.py runs the
 // PnP stage beside it); the ordered replay below is independent of the batch width, so the results do not change.
 static constexpr int kPW = 32;
@@ -62,6 +62,40 @@ struct CvRng {
   __device__ int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
 };
 
+// ---- libm-free elementary functions -----------------------------------------------------------
+// hypot / log / integer pow as fixed sequences of IEEE-754 operations (+ - * / sqrt are correctly rounded on the device
+// and on the host, and contraction is off), so that the C oracle, which runs the same sequences (oracle/pnp_ref.c), gets
+// the same bits.  The device's and glibc's own hypot / log / pow differ in their last bits, and a 1-ulp difference in a
+// Jacobi rotation is amplified without bound when three of the four smallest eigenvalues of M^T M nearly coincide
+// (five nearly coplanar points: 2.6e-4 rad between the two implementations in round 2).
+__device__ __forceinline__ double det_hypot(double a, double b) {
+  a = fabs(a); b = fabs(b);
+  const double hi = a > b ? a : b, lo = a > b ? b : a;
+  if (hi == 0.) return 0.;
+  const double r = lo / hi;
+  return hi * sqrt(1. + r * r);
+}
+__device__ double det_log(double x) {   // x > 0 and finite; ~1e-16 relative
+  unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  int e = (int)((u >> 52) & 0x7ff);
+  if (e == 0) { x *= 18014398509481984.; u = __builtin_bit_cast(unsigned long long, x); e = (int)((u >> 52) & 0x7ff) - 54; }   // subnormal: * 2^54
+  e -= 1023;
+  double m = __builtin_bit_cast(double, (u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);   // [1, 2)
+  if (m > 1.4142135623730951) { m *= 0.5; e += 1; }                                               // [sqrt(1/2), sqrt(2)]
+  const double f = m - 1., sq = f / (2. + f), z = sq * sq;
+  double pz = 1. / 27.;                                                                            // atanh series, 14 terms
+  pz = pz * z + 1. / 25.; pz = pz * z + 1. / 23.; pz = pz * z + 1. / 21.; pz = pz * z + 1. / 19.;
+  pz = pz * z + 1. / 17.; pz = pz * z + 1. / 15.; pz = pz * z + 1. / 13.; pz = pz * z + 1. / 11.;
+  pz = pz * z + 1. / 9.; pz = pz * z + 1. / 7.; pz = pz * z + 1. / 5.; pz = pz * z + 1. / 3.;
+  pz = pz * z + 1.;
+  return (double)e * 0.6931471805599453 + 2. * sq * pz;
+}
+__device__ __forceinline__ double det_powi(double x, int n) {   // n >= 0, left-to-right products
+  double r = 1.;
+  for (int i = 0; i < n; i++) r = r * x;
+  return r;
+}
+
 // ---- one-sided Jacobi SVD on small private matrices (JacobiSVDImpl_<double>) -----------------
 // At: N rows of length M (columns of the M x N input).  Out: rows of At = left singular
 // vectors, W descending, Vt rows = right singular vectors.
@@ -85,7 +119,7 @@ __device__ void jacobi_small(double* At, double* W, double* Vt) {
         for (int k = 0; k < M; k++) p += Ai[k] * Aj[k];
         if (fabs(p) <= eps * sqrt(a * b)) continue;
         p *= 2;
-        const double beta = a - b, gamma = hypot(p, beta);
+        const double beta = a - b, gamma = det_hypot(p, beta);
         if (beta < 0) {
           const double delta = (gamma - beta) * 0.5;
           s = sqrt(delta / gamma);
@@ -200,7 +234,7 @@ __device__ void jacobi12(double* ut /* = base + lane */) {
         for (int k = 0; k < 12; k++) p += ai[k] * aj[k];
         if (fabs(p) <= eps * sqrt(a * b)) continue;
         p *= 2;
-        const double beta = a - b, gamma = hypot(p, beta);
+        const double beta = a - b, gamma = det_hypot(p, beta);
         if (beta < 0) {
           const double delta = (gamma - beta) * 0.5;
           s = sqrt(delta / gamma);
@@ -652,24 +686,24 @@ __device__ int ransac_update_num_iters(double p, double ep, int model_points, in
   p = p > 0. ? p : 0.; p = p < 1. ? p : 1.;
   ep = ep > 0. ? ep : 0.; ep = ep < 1. ? ep : 1.;
   double num = (1. - p) > DBL_MIN ? (1. - p) : DBL_MIN;
-  double denom = 1. - pow(1. - ep, (double)model_points);
+  double denom = 1. - det_powi(1. - ep, model_points);
   if (denom < DBL_MIN) return 0;
-  num = log(num);
-  denom = log(denom);
+  num = det_log(num);
+  denom = det_log(denom);
   return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
 }
 
 __global__ __launch_bounds__(64) void pnp_kernel(const PnpArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* s_ut = smem;                       // 144 x kPW
-  double* s_obj = s_ut + 144 * kPW;          // kMaxJ x 3
-  double* s_u32 = s_obj + kMaxJ * 3;         // kMaxJ x 2  (undistorted, float32-rounded, * f + c)
-  double* s_u64 = s_u32 + kMaxJ * 2;         // kMaxJ x 2
-  double* s_img = s_u64 + kMaxJ * 2;         // kMaxJ x 2  raw float32 image points
+  const int J = a.J;                         // the per-point arrays are sized by the launch's J (pnp_launch), not by kMaxJ
+  double* s_obj = s_ut + 144 * kPW;          // J x 3
+  double* s_u32 = s_obj + J * 3;             // J x 2  (undistorted, float32-rounded, * f + c)
+  double* s_u64 = s_u32 + J * 2;             // J x 2
+  double* s_img = s_u64 + J * 2;             // J x 2  raw float32 image points
 
   const int lane = threadIdx.x;
   const int frame = blockIdx.x;
-  const int J = a.J;
   Cam cam;
   cam.fx = a.K[0]; cam.fy = a.K[4]; cam.cx = a.K[2]; cam.cy = a.K[5];
   for (int i = 0; i < 5; i++) cam.k[i] = a.dist ? a.dist[i] : 0.0;
@@ -796,7 +830,7 @@ __global__ __launch_bounds__(64) void pnp_kernel(const PnpArgs a) {
       status = -2;
     } else {
       const unsigned long long hit = __ballot(spec_lane && spec_mask == best_mask);
-      if (hit != 0ULL && !(a.dbg_no_spec)) {   // the final fit has already been computed by a speculative lane
+      if (hit != 0ULL && !SCP_DEV_ONLY(a.dbg_no_spec)) {   // the final fit has already been computed by a speculative lane
         const int src = __builtin_ctzll(hit);
         for (int k = 0; k < 3; k++) { rvec[k] = __shfl(spec_r[k], src, 64); tvec[k] = __shfl(spec_t[k], src, 64); }
         status = (int)__popcll(best_mask);
@@ -830,10 +864,12 @@ int32_t pnp_launch(const float* kp_xyc, const double* landmarks, const double* K
   if (N == 0) return SCPOSE_OK;
   PnpArgs a{kp_xyc, landmarks, K, dist, rot, tvec, rvec, status, N, J, conf_thr0, thr_decay, min_pts, thr_iters,
             max_iters, reproj_err, confidence, 0};
-  { static const char* e = dev_env("SCPOSE_PNP_SPEC"); a.dbg_no_spec = (e && atoi(e) == 0) ? 1 : 0; }
-  const size_t lds = (size_t)(144 * kPW + kMaxJ * 9) * sizeof(double);
-  static LdsOptIn big_lds;   // per device (common.h)
-  { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(pnp_kernel), (int)lds, &big_lds); if (rc != SCPOSE_OK) return rc; }
+  { static const char* e = dev_env("SCPOSE_PNP_SPEC"); a.dbg_no_spec = (kDevBuild && e && atoi(e) == 0) ? 1 : 0; }
+  // 36 864 B of work matrices + 72 B per landmark: 37 656 B at J = 11, so FOUR one-wave workgroups fit the 160 KB of a CU
+  // (J <= 56; with the arrays sized for kMaxJ = 64 it was 41 472 B and only three fitted)
+  const size_t lds = (size_t)(144 * kPW + J * 9) * sizeof(double);
+  static LdsOptIn big_lds;   // per device (common.h); opted in once for the largest J
+  { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(pnp_kernel), (int)((144 * kPW + kMaxJ * 9) * sizeof(double)), &big_lds); if (rc != SCPOSE_OK) return rc; }
   hipLaunchKernelGGL(pnp_kernel, dim3(N), dim3(64), lds, stream, a);
   SCP_CHECK_HIP(hipGetLastError());
   return SCPOSE_OK;

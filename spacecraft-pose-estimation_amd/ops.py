@@ -407,6 +407,13 @@ class HrnetEngine:
     __call__ = forward
 
     def close(self):
+        # captured graphs bake in this engine's packed-weight pointers: destroy them first, so that no graph can replay
+        # kernels that read freed weights (their replay() raises afterwards)
+        for ref in list(getattr(self, "_graphs", ())):
+            g = ref()
+            if g is not None:
+                g.close()
+        self._graphs = []
         if getattr(self, "_h", None):
             nat.lib().scpose_hrnet_destroy(self._h)
             self._h = None
@@ -428,7 +435,8 @@ class HrnetGraph:
         nat.check(nat.lib().scpose_hrnet_graph_workspace_bytes(engine._h, n, h, w, ctypes.byref(b)), "hrnet_graph_workspace_bytes")
         self.engine, self.x, self.out = engine, x, out
         self._ws = torch.empty(b.value, dtype=torch.uint8, device=x.device)       # owned by the graph: addresses are baked in
-        torch.cuda.current_stream().synchronize()                                  # x must be valid: create runs one eager forward
+        torch.cuda.synchronize(x.device)     # create runs one eager forward on an internal stream: every pending write to x / out,
+                                             # on any stream of x's device (not only the current one), must have landed
         g = c_void_p()
         with torch.cuda.device(x.device):
             nat.check(nat.lib().scpose_hrnet_graph_create(engine._h, _ptr(x), fmt, n, h, w, _ptr(out), _ptr(self._ws), self._ws.numel(),
@@ -437,9 +445,15 @@ class HrnetGraph:
         k = c_int32()
         nat.check(nat.lib().scpose_hrnet_graph_nodes(self._g, ctypes.byref(k)), "hrnet_graph_nodes")
         self.nodes = k.value
+        import weakref
+        if not hasattr(engine, "_graphs"):
+            engine._graphs = []
+        engine._graphs.append(weakref.ref(self))     # HrnetEngine.close() destroys its live graphs before its weights
 
     def replay(self):
         """Enqueue the captured forward on the current stream; returns the (bound) heat-map buffer."""
+        if not getattr(self, "_g", None):
+            raise RuntimeError("HrnetGraph.replay(): the graph (or its engine) has been closed")
         nat.check(nat.lib().scpose_hrnet_graph_launch(self._g, _stream()), "hrnet_graph_launch")
         return self.out
 

@@ -29,8 +29,40 @@ def init(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend, rank=rank, world_size=ws)
+        dist.init_process_group(backend, init_method=init_method(), rank=rank, world_size=ws)
     return dist
+
+
+def init_method():
+    """Rendezvous of this job: the file store spawn_local_ranks() prepared (no TCP port to race for), else the
+    MASTER_ADDR / MASTER_PORT environment torch.distributed.run sets."""
+    f = os.environ.get("SCPOSE_RDZV_FILE")
+    return "file://" + f if f else "env://"
+
+
+def visible_gpu_count():
+    """Number of GPUs this process would see, WITHOUT touching HIP: KFD topology nodes with SIMDs
+    (/sys/class/kfd/kfd/topology/nodes/*/properties), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES.  None when the topology is not readable (the ranks then fail loudly themselves).
+    A parent that is about to start one child per GPU must not initialise the runtime (torch.cuda.device_count() can go
+    through hipGetDeviceCount on ROCm)."""
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    for path in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(path) if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
 
 
 def shard_range(n, rank, world_size):
@@ -58,6 +90,8 @@ def gather_rows(local, n_total, dist=None):
 
 
 def free_port():
+    """A port that was free a moment ago.  Only a default for MASTER_PORT: the ranks spawn_local_ranks() starts
+    rendezvous through a file store (SCPOSE_RDZV_FILE), so nothing binds this port between the check and its use."""
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -74,9 +108,12 @@ def spawn_local_ranks(argv, nprocs, env=None, timeout=None):
     process that initialised HIP), so `bench.py --gpus N` and `tools/test.py` can launch themselves without torchrun
     (replaces the in-process torch.nn.DataParallel of landmark_regression/tools/test.py:98)."""
     import subprocess
+    import tempfile
     import time
     base = dict(os.environ if env is None else env)
-    base.update(WORLD_SIZE=str(nprocs), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    rdzv_dir = tempfile.mkdtemp(prefix="scpose_rdzv_")
+    base.update(WORLD_SIZE=str(nprocs), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+                SCPOSE_RDZV_FILE=os.path.join(rdzv_dir, "store"))   # parallel.init_method(): file store, no port race
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
     procs = []
     for r in range(nprocs):
@@ -107,4 +144,6 @@ def spawn_local_ranks(argv, nprocs, env=None, timeout=None):
             if p.poll() is None:
                 p.kill()
             p.wait()
+        import shutil
+        shutil.rmtree(rdzv_dir, ignore_errors=True)
     return worst

@@ -200,7 +200,9 @@ def test_conv_is_equivariant_under_frame_permutation(gpu_ops, case):
 
 def test_development_switches_need_scpose_dev(gpu_ops):
     """A stray SCPOSE_* variable must not steer a production process: the ablation switch SCPOSE_DBG=1 (skip the MFMA
-    loops) is ignored unless SCPOSE_DEV=1 is set too, and then the library says so on stderr."""
+    loops) is ignored unless SCPOSE_DEV=1 is set too, and then the library says so on stderr.  The ablation paths exist
+    only in the development build (libscpose_hip_dev.so, -DSCPOSE_DEV_BUILD): the shipped library ignores SCPOSE_DBG even
+    with SCPOSE_DEV=1, because its kernels do not contain them."""
     import os
     import subprocess
     import sys
@@ -223,8 +225,14 @@ def test_development_switches_need_scpose_dev(gpu_ops):
 
     rel, err = run({"SCPOSE_DBG": "1"})
     assert rel < 1e-2 and "SCPOSE_DEV" not in err
-    rel, err = run({"SCPOSE_DBG": "1", "SCPOSE_DEV": "1"})
-    assert rel > 0.5 and "SCPOSE_DEV=1" in err
+    from importlib import import_module
+    nat = import_module("spacecraft-pose-estimation_amd._native")
+    assert nat.lib().scpose_is_dev_build() == 0          # this test process runs the shipped library
+    rel, err = run({"SCPOSE_DBG": "1", "SCPOSE_DEV": "1", "SCPOSE_LIB": os.path.join(os.path.dirname(nat.DEV_LIB_PATH), nat.LIB_NAME)})
+    assert rel < 1e-2 and "SCPOSE_DEV=1" in err          # shipped library: no ablation path to switch on
+    if os.path.exists(nat.DEV_LIB_PATH):
+        rel, err = run({"SCPOSE_DBG": "1", "SCPOSE_DEV": "1"})   # development build, picked up through SCPOSE_DEV=1
+        assert rel > 0.5 and "SCPOSE_DEV=1" in err
 
 
 def test_conv_64bit_addressing_path(gpu_ops):

@@ -34,6 +34,21 @@ def test_decode_random_maps(gpu_ops, shape, pp):
     assert np.abs(got[:, :, :2] - ref[:, :, :2]).max() <= 2e-4
 
 
+def test_decode_matches_reference_golden_directly(gpu_ops):
+    """The HIP kernel against tests/golden/decode_reference_outputs.npz itself -- the outputs of the reference's
+    lib/core/inference.py (get_max_preds :18-46, get_final_preds :49-79) on the fixture's heat-maps, produced by
+    tests/golden/make_golden.py -- with no oracle in between."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "decode_reference_outputs.npz"))
+    hm, c, s = g["heatmaps"], g["center"], g["scale"]
+    coords, mv = gpu_ops.max_preds(torch.from_numpy(hm).cuda())
+    assert np.array_equal(coords.cpu().numpy(), g["max_coords"]) and np.array_equal(mv.cpu().numpy(), g["max_vals"])
+    for pp in (True, False):
+        got = _run(gpu_ops, hm, c, s, pp)
+        assert np.array_equal(got[:, :, 2:3], g["maxvals_pp%d" % pp])                    # maxval: exact
+        assert np.abs(got[:, :, :2] - g["preds_pp%d" % pp]).max() <= 2e-4             # float32 image px (values up to ~2000)
+
+
 def test_decode_gaussian_targets_and_max_preds(gpu_ops):
     rng = np.random.default_rng(11)
     hm, cx, cy = D.gaussian_heatmaps(6, 11, 96, 96, rng, sigma=2.0)

@@ -105,6 +105,65 @@ def test_margin_gated_keypoint_parity(pk, model, size, n):
     eng.close()
 
 
+def test_every_keypoint_agrees_or_is_explained_w48_384(pk):
+    """Complete (not margin-gated) keypoint parity at the headline geometry (BASELINE configs[2]: W48, 384x384), 64 frames:
+    EVERY joint is either within 0.5 px of the oracle keypoint (north_star) or its disagreement is explained by the 16-bit
+    noise of the heat-map -- the oracle map's value at the GPU's argmax lies within 2*dev of the oracle maximum (a near-tie
+    the noise may flip, lib/core/inference.py:30-40), or the argmax agrees and the quarter-pixel sign test that differs
+    (:62-69) has |difference| <= 2*dev in the oracle.  dev is the measured max |HIP - oracle| of that map, and is itself
+    bounded against the map's dynamic range (measured: median 2.5 %, max 4.1 % on these nearly flat random-init maps; bound 6 %),
+    so that 'explained' cannot be satisfied by an inaccurate heat-map.  Measured split: 515 of 704 within 0.5 px, 181 near-tie
+    argmax, 8 quarter-pixel signs, 0 unexplained.
+    No joint may be neither; the split is printed."""
+    n, size = 64, 384
+    cfg = R.w48_cfg(11, size)
+    sd = R.make_state_dict(cfg, seed=21)
+    x = torch.randn(n, 3, size, size, generator=torch.Generator().manual_seed(23))
+    eng = pk.ops.HrnetEngine(cfg, sd)
+    hm_gpu = eng(x.cuda())
+    with torch.no_grad():
+        hm_ref = torch.cat([R.forward(sd, cfg, x[i:i + 16]) for i in range(0, n, 16)], 0)
+    c = torch.full((n, 2), 700.0); s = torch.full((n, 2), 1.3)
+    kp_gpu = pk.ops.decode(hm_gpu, c.cuda(), s.cuda(), True).cpu().numpy()
+    kp_ref = D.decode_xyc(True, hm_ref.numpy(), c.numpy(), s.numpy())
+    hg, hr = hm_gpu.cpu().numpy(), hm_ref.numpy()
+    H, W = hr.shape[2:]
+    dev = np.abs(hg - hr).reshape(n, 11, -1).max(2)
+    span = hr.reshape(n, 11, -1).max(2) - hr.reshape(n, 11, -1).min(2)
+    err = np.linalg.norm(kp_gpu[:, :, :2] - kp_ref[:, :, :2], axis=2)
+    agree = near_tie = sign_flip = 0
+    bad = []
+    for i in range(n):
+        for j in range(11):
+            if err[i, j] <= 0.5:
+                agree += 1
+                continue
+            gy, gx = np.unravel_index(hg[i, j].argmax(), (H, W))
+            ry, rx = np.unravel_index(hr[i, j].argmax(), (H, W))
+            if (gy, gx) != (ry, rx):
+                if hr[i, j, gy, gx] >= hr[i, j, ry, rx] - 2 * dev[i, j]:
+                    near_tie += 1
+                else:
+                    bad.append((i, j, "argmax", float(err[i, j])))
+                continue
+            ok = 1 < rx < W - 1 and 1 < ry < H - 1          # same argmax: only a quarter-pixel sign can differ
+            if ok:
+                dx = hr[i, j, ry, rx + 1] - hr[i, j, ry, rx - 1]; dy = hr[i, j, ry + 1, rx] - hr[i, j, ry - 1, rx]
+                gdx = hg[i, j, ry, rx + 1] - hg[i, j, ry, rx - 1]; gdy = hg[i, j, ry + 1, rx] - hg[i, j, ry - 1, rx]
+                ok = all(np.sign(a) == np.sign(b) or abs(a) <= 2 * dev[i, j] for a, b in ((dx, gdx), (dy, gdy)))
+            if ok:
+                sign_flip += 1
+            else:
+                bad.append((i, j, "quarter-pixel", float(err[i, j])))
+    rel = dev / span
+    print("W48 384x384, %d joints: %d within 0.5 px, %d near-tie argmax, %d quarter-pixel sign within noise, %d unexplained; "
+          "dev / dynamic range of the map: median %.4f max %.4f" % (n * 11, agree, near_tie, sign_flip, len(bad), np.median(rel), rel.max()))
+    assert not bad, bad[:8]
+    assert agree + near_tie + sign_flip == n * 11
+    assert rel.max() <= 0.06, "heat-map noise is not small against the map's dynamic range: %.4f" % rel.max()
+    eng.close()
+
+
 def _scene(tmp_path, n=6, j=11, size=(160, 120)):
     from PIL import Image
     rng = np.random.default_rng(3)

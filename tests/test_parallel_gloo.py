@@ -35,7 +35,7 @@ def _free_port():
 
 def test_two_rank_gather_preserves_frame_order():
     ctx = mp.get_context("spawn")
-    for n_total in (7, 256):            # ragged and even shards
+    for n_total in (7, 256, 2048):      # ragged and even shards; 2048 = BASELINE configs[3]: (2048, 13) f64 poses + (2048, 11, 3) f32 keypoints
         q = ctx.Queue()
         port = _free_port()
         procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]

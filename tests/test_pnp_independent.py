@@ -99,19 +99,21 @@ def test_hip_degenerate_cases_equal_the_oracle(gpu_ops):
     rot, tv, st = rot.cpu().numpy(), tv.cpu().numpy(), st.cpu().numpy()
     assert np.array_equal(st, ref["status"]) and (tv[:, 2] > 0).all()
     # Five nearly coplanar points are an ill-conditioned EPnP (three of the four smallest eigenvalues of M^T M nearly
-    # coincide), so last-bit differences between device and host libm are amplified: measured 2.6e-4 rad on 1 of 64
-    # frames, <= 4e-7 rad on the others.  The north-star 1e-4 bar is asserted on the well-conditioned sets
-    # (test_gpu_pnp.py); here the bound is 1e-3 rad worst case and 1e-6 rad for the median frame.
+    # coincide): any last-bit difference in a Jacobi rotation is amplified (round 2: 2.6e-4 rad on 1 of 64 frames, from
+    # hypot() of the device's vs glibc's libm).  Both implementations now run the same IEEE operation sequences for hypot /
+    # log / pow (det_hypot, det_log, det_powi), so the north-star bar holds on every frame of this set as well.
     ang = P.rot_angle(rot, ref["R"])
     terr = np.linalg.norm(tv - ref["t"], axis=1) / np.linalg.norm(ref["t"], axis=1)
-    assert ang.max() <= 1e-3 and np.median(ang) <= 1e-6, "near-coplanar: max %.3g median %.3g rad" % (ang.max(), np.median(ang))
-    assert terr.max() <= 1e-3 and np.median(terr) <= 1e-6
+    print("near-coplanar: rotation max %.3g median %.3g rad, translation max %.3g median %.3g" % (ang.max(), np.median(ang), terr.max(), np.median(terr)))
+    assert ang.max() <= 1e-4, "near-coplanar: max %.3g median %.3g rad" % (ang.max(), np.median(ang))
+    assert terr.max() <= 1e-4
     X = P.LANDMARKS.copy(); X[:, 2] = 0.0
     kpp, Rp, tp = P.synth_keypoints(64, rng, 0.5, 0.0, landmarks=X)
     refp = P.solve_batch(kpp, landmarks=X)
     rot, tv, st = gpu_ops.pnp_epnp_ransac(dev(kpp), dev(X), dev(P.CAMERA_K), dev(P.CAMERA_DIST))
     rot, st = rot.cpu().numpy(), st.cpu().numpy()
     agree = np.mean(st == refp["status"])
-    assert agree >= 0.9, "planar target: HIP and oracle statuses agree on %.0f %% of the frames" % (100 * agree)
+    print("planar target: statuses agree on %.1f %% of the frames" % (100 * agree))
+    assert agree == 1.0, "planar target: HIP and oracle statuses agree on %.0f %% of the frames" % (100 * agree)
     ok = st > 0
     assert np.abs(np.einsum("nij,nkj->nik", rot[ok], rot[ok]) - np.eye(3)).max() < 1e-9
