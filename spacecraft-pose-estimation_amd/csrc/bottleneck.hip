@@ -50,11 +50,11 @@ constexpr int kCols1 = (kHPix + 15) / 16;      // 21 MFMA columns of conv1
 constexpr int kXS = (kHPix | 1) * 16;          // bytes of one t1 plane (325 slots: odd pitch)
 constexpr int kT2S = (kT * kT | 1) * 16;       // bytes of one t2 plane (257 slots)
 constexpr int kW1Bytes = 8 * 4 * 4 * 16 * 16;  // 32 KB
-constexpr int kLds = 8 * kXS + 8 * kT2S + kW1Bytes + (64 + 64 + 256) * 4;
+constexpr int kLds = 8 * kXS + 8 * kT2S + kW1Bytes + (64 + 64 + 256) * 4 + 16;   // + the tile queue words
 // first Bottleneck (PROJ): x has 64 channels, W1 is 8 KB, and the tile's 256 centre pixels of x (8 planes) are kept in LDS,
 // double-buffered, as the operand of the projection half of conv3
 constexpr int kW1BytesProj = 2 * 4 * 4 * 16 * 16;
-constexpr int kLdsProj = 8 * kXS + 8 * kT2S + 2 * 8 * kT2S + kW1BytesProj + (64 + 64 + 256) * 4;
+constexpr int kLdsProj = 8 * kXS + 8 * kT2S + 2 * 8 * kT2S + kW1BytesProj + (64 + 64 + 256) * 4 + 16;
 
 struct BneckLaunch {
   const void* in;
@@ -67,7 +67,8 @@ struct BneckLaunch {
   void* out;
   uint32_t in_bytes, out_bytes;
   int32_t N, H, W;
-  int32_t tiles_x, tiles_y, tiles_total, tiles_per_wg, grid;
+  int32_t tiles_x, tiles_y, tiles_total, grid;
+  uint32_t* sched;               // dynamic tile queue (conv_device.h: tile_claim)
   unsigned long long* dbg_buf;   // development (SCPOSE_BNECK_DBG=1): cycles per phase and wave
 };
 
@@ -118,9 +119,13 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
   const int qoff = q * kXS;
   const uint32_t w2vo = (uint32_t)(((2 * ch) * 4 + q) * 16 + r) * 16u;   // this lane's slot in a conv2 weight fragment; + (s * 4 + mb) * 1024
 
-  const int wg = xcd_remap(blockIdx.x, p.grid);
-  const int t_begin = wg * p.tiles_per_wg;
-  const int t_end = min(p.tiles_total, t_begin + p.tiles_per_wg);
+  // tiles come from the launch's dynamic queue: this tile and the next are always known (the next one's x vectors are
+  // requested during this tile's phase C); the one after is claimed at the top of the tile and published through LDS
+  // in front of the tile's second barrier
+  int* tq = reinterpret_cast<int*>(bl + 64 + 64 + 256);
+  if (tid == 0) { tq[0] = tile_claim(p.sched, p.tiles_total); tq[1] = tq[0] < 0 ? -1 : tile_claim(p.sched, p.tiles_total); }
+  __syncthreads();
+  int t = tq[0], t_next = tq[1];
   auto decode = [&](int t, int& img, int& oy0, int& ox0) {
     img = t / tiles_per_img;
     const int rem = t - img * tiles_per_img;
@@ -167,20 +172,22 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
     request(std::integral_constant<int, 6>{}); request(std::integral_constant<int, 7>{});
   };
 
-  if (t_begin < t_end) {
-    locate(t_begin);
+  if (t >= 0) {
+    locate(t);
     request_head();
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                            // W1 and the biases are in LDS
+  __builtin_amdgcn_s_barrier();                            // W1 and the biases are in LDS (and every wave has read tq[0], tq[1])
 
   unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
   auto now = [&]() -> unsigned long long { return SCP_DBG_BUF(p) ? __builtin_amdgcn_s_memtime() : 0ull; };
   int xbuf = 0;
-  for (int t = t_begin; t < t_end; ++t, xbuf ^= 1) {
+  for (; t >= 0; t = t_next, t_next = tq[2], xbuf ^= 1) {   // tq[2]: published before this tile's second barrier, not rewritten before the next tile's
     int img, oy0, ox0;
     decode(t, img, oy0, ox0);
     const unsigned long long ts0 = now();
+    int t_after = -1;
+    if (tid == 0 && t_next >= 0) t_after = tile_claim(p.sched, p.tiles_total);   // returns under phases A and B
 
     // ---- A: conv1 (1x1, 256 -> 64) on the halo pixels -> t1: all four 16-channel blocks of the wave's columns ----
     frag_t w2f[18][2];                                     // conv2's weights of this wave: re-read per tile (below)
@@ -283,8 +290,9 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
       }
     }
     const unsigned long long ts3 = now();
+    if (tid == 0) tq[2] = t_after;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                          // t2 complete (and every wave is done with t1)
+    __builtin_amdgcn_s_barrier();                          // t2 complete (and every wave is done with t1); tq[2] published
     const unsigned long long ts4 = now();
 
     // ---- C: conv3 (1x1, 64 -> 256) + residual -> y ----
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < t_end) locate(t + 1);
+      if (t_next >= 0) locate(t_next);
       else { vo[0] = vo[1] = vo[2] = BUF_OOB; cx[0] = cx[1] = cx[2] = -1; }   // last tile: the requests still run (they read nothing), so that the
                                                            // ring is redefined on every path and is not live across phase B
       auto pair = [&](auto cpc) {
@@ -369,6 +377,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
       tph[0] += ts1 - ts0; tph[1] += ts2 - ts1; tph[2] += ts3 - ts2; tph[3] += ts4 - ts3; tph[4] += ts5 - ts4;
     }
   }
+  if (tid == 0) tile_retire(p.sched);
   if (SCP_DBG_BUF(p) && lane == 0)
     for (int k = 0; k < 6; ++k) SCP_DBG_BUF(p)[((size_t)blockIdx.x * 8 + wave) * 6 + k] = tph[k];
 }
@@ -436,7 +445,8 @@ static int32_t bneck_launch_one(const BneckLaunch& L, hipStream_t stream) {
 
 // cin = 256: identity residual; cin = 64: first Bottleneck (projection folded into conv3, see bottleneck_pack)
 int32_t bottleneck_launch(const void* in, const void* w1, const void* w2, const void* w3, const float* bias, int N, int H, int W,
-                          int cin, int dtype, void* out, hipStream_t stream) {
+                          int cin, int dtype, void* out, uint32_t* sched, hipStream_t stream) {
+  SCP_REQUIRE(sched, "bottleneck: null tile-queue words");
   // the kernel addresses its tensors through 32-bit buffer descriptors: batches whose 256-channel tensor reaches 4 GiB
   // (~900 frames at 96 x 96) run as several launches over frame ranges
   const bool proj = cin == 64;
@@ -454,10 +464,8 @@ int32_t bottleneck_launch(const void* in, const void* w1, const void* w2, const 
     L.N = n; L.H = H; L.W = W;
     L.tiles_x = (W + kT - 1) / kT; L.tiles_y = (H + kT - 1) / kT;
     L.tiles_total = n * L.tiles_x * L.tiles_y;
-    int grid = conv_device_cus();
-    if (grid > L.tiles_total) grid = L.tiles_total;
-    L.tiles_per_wg = (L.tiles_total + grid - 1) / grid;
-    L.grid = (L.tiles_total + L.tiles_per_wg - 1) / L.tiles_per_wg;
+    L.grid = conv_device_cus() < L.tiles_total ? conv_device_cus() : L.tiles_total;
+    L.sched = sched;
     { static const char* e = dev_env("SCPOSE_BNECK_DBG"); L.dbg_buf = (kDevBuild && e && atoi(e)) ? conv_dbg_buffer(stream) : nullptr; if (L.dbg_buf) conv_dbg_set_grid(L.grid); }
     int32_t rc;
     if (dtype == SCPOSE_DT_BF16) rc = proj ? bneck_launch_one<0, true>(L, stream) : bneck_launch_one<0, false>(L, stream);

@@ -86,6 +86,26 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
   return base + (b >> 3);
 }
 
+// Dynamic tile queue of the persistent kernels that other work may run beside (stem, layer1: bench.py's decode / PnP of
+// the previous step overlap them).  A static split of the tiles over the workgroups makes the launch as slow as its
+// unluckiest workgroup: a CU that another kernel holds for 0.7 ms delays its share by 0.7 ms.  Here every workgroup
+// claims its next tile from one device-wide counter instead (sched[0]; one returning atomic per tile, issued a whole
+// tile before its value is needed), so the tiles go to whichever CUs are free.  sched[1] counts finished workgroups;
+// the last one zeroes both words, which leaves the pair ready for the next launch (the pair is zero-initialised once,
+// when the engine is created; launches that share a pair are ordered on one stream).  Tile t's result does not depend on
+// who computes it.
+__device__ __forceinline__ int tile_claim(uint32_t* sched, int total) {
+  const uint32_t c = __hip_atomic_fetch_add(sched, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return c < (uint32_t)total ? (int)c : -1;
+}
+__device__ __forceinline__ void tile_retire(uint32_t* sched) {   // one lane per workgroup, after its last claim has returned
+  const uint32_t d = __hip_atomic_fetch_add(sched + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (d == gridDim.x - 1) {
+    __hip_atomic_store(sched, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(sched + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // DT: 0 = bf16, 1 = f16 (an int so that profiler kernel names demangle: conv_igemm_kernel<0,3,1,3,4>)
 template <int DT> struct DtOf { typedef __bf16 type; };
 template <> struct DtOf<1> { typedef _Float16 type; };

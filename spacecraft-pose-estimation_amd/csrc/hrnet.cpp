@@ -116,6 +116,7 @@ struct scpose_hrnet {
   struct Bneck { void* w1 = nullptr; void* w2 = nullptr; void* w3 = nullptr; float* bias = nullptr; int cin = 256; };   // fused Bottlenecks (bottleneck.hip)
   std::vector<Bneck> bnecks;
   float* d_head_bias = nullptr; // [4][16] folded biases of the hrnet_cms heads
+  uint32_t* d_sched = nullptr;  // 16 zero-initialised words per op: dynamic tile queues of the persistent kernels (conv_device.h: tile_claim)
   int head_k = 0, head_s = 1;   // transposed-conv kernel / stride of the heads (heat-map = S * branch-0 size)
   std::vector<scpose::TensorDesc> tensors;
   std::vector<scpose::Op> ops;
@@ -475,6 +476,8 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
     return SCPOSE_E_MISSING;
   }
   if (B.status != SCPOSE_OK) return B.status;
+  SCP_CHECK_HIP(hipMalloc(&net->d_sched, net->ops.size() * 16 * sizeof(uint32_t)));
+  SCP_CHECK_HIP(hipMemset(net->d_sched, 0, net->ops.size() * 16 * sizeof(uint32_t)));
 
   // liveness
   for (size_t i = 0; i < net->ops.size(); ++i) {
@@ -618,7 +621,7 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
                        net->desc.dtype, ptr(op.out), st);
     } else if (op.kind == OP_STEM2) {
       rc = stem_fused_launch(in, in_fmt, net->d_stemf_w1, net->d_stemf_w2, net->d_stemf_b1, net->d_stemf_b2, net->d_mean_std,
-                             n, h, w, net->desc.dtype, ptr(op.out), st);
+                             n, h, w, net->desc.dtype, ptr(op.out), net->d_sched + 16 * oi, st);
     } else if (op.kind == OP_CONV) {
       const TensorDesc& ti = net->tensors[op.in];
       void* out = op.out == -2 ? static_cast<void*>(heatmaps) : ptr(op.out);
@@ -634,7 +637,7 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
     } else if (op.kind == OP_BNECK) {
       const TensorDesc& ti = net->tensors[op.in];
       const scpose_hrnet::Bneck& bn = net->bnecks[op.conv];
-      rc = bottleneck_launch(ptr(op.in), bn.w1, bn.w2, bn.w3, bn.bias, n, h >> ti.ds, w >> ti.ds, bn.cin, net->desc.dtype, ptr(op.out), st);
+      rc = bottleneck_launch(ptr(op.in), bn.w1, bn.w2, bn.w3, bn.bias, n, h >> ti.ds, w >> ti.ds, bn.cin, net->desc.dtype, ptr(op.out), net->d_sched + 16 * oi, st);
     } else if (op.kind == OP_BLOCK) {
       const TensorDesc& ti = net->tensors[op.in];
       rc = block_launch(net->convs[op.conv], net->convs[op.conv2], ptr(op.in), n, h >> ti.ds, w >> ti.ds, ptr(op.out), st);
@@ -743,6 +746,7 @@ void hrnet_free(scpose_hrnet* net) {
   if (net->d_stemf_b1) (void)hipFree(net->d_stemf_b1);
   if (net->d_stemf_b2) (void)hipFree(net->d_stemf_b2);
   if (net->d_head_bias) (void)hipFree(net->d_head_bias);
+  if (net->d_sched) (void)hipFree(net->d_sched);
   for (auto& e : net->events) if (e) (void)hipEventDestroy(e);
   net->events.clear();
 }

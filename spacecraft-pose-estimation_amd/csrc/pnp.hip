@@ -693,17 +693,24 @@ __device__ int ransac_update_num_iters(double p, double ep, int model_points, in
   return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
 }
 
-__global__ __launch_bounds__(64) void pnp_kernel(const PnpArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* s_ut = smem;                       // 144 x kPW
+// One wave per frame, a few frames per workgroup (blockDim = 64 x frames; the waves share nothing but the CU).  A wave of
+// this kernel owns a whole SIMD (512 registers: the spills of the 12 x 12 solves live in AGPRs), so a CU that holds even one
+// frame cannot take a convolution workgroup of the next forward, which bench.py runs beside this kernel.
+__global__ __launch_bounds__(256) void pnp_kernel(const PnpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem_all[];
   const int J = a.J;                         // the per-point arrays are sized by the launch's J (pnp_launch), not by kMaxJ
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* smem = smem_all + (size_t)wv * (144 * kPW + J * 9);
+  double* s_ut = smem;                       // 144 x kPW
   double* s_obj = s_ut + 144 * kPW;          // J x 3
   double* s_u32 = s_obj + J * 3;             // J x 2  (undistorted, float32-rounded, * f + c)
   double* s_u64 = s_u32 + J * 2;             // J x 2
   double* s_img = s_u64 + J * 2;             // J x 2  raw float32 image points
 
-  const int lane = threadIdx.x;
-  const int frame = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int frame_raw = blockIdx.x * (blockDim.x >> 6) + wv;
+  const bool frame_valid = frame_raw < a.N;
+  const int frame = frame_valid ? frame_raw : a.N - 1;   // surplus waves of the last workgroup redo the last frame up to the barrier
   Cam cam;
   cam.fx = a.K[0]; cam.fy = a.K[4]; cam.cx = a.K[2]; cam.cy = a.K[5];
   for (int i = 0; i < 5; i++) cam.k[i] = a.dist ? a.dist[i] : 0.0;
@@ -731,7 +738,8 @@ __global__ __launch_bounds__(64) void pnp_kernel(const PnpArgs a) {
     s_u32[pos * 2] = (double)(float)x * cam.fx + cam.cx; s_u32[pos * 2 + 1] = (double)(float)y * cam.fy + cam.cy;
     s_img[pos * 2] = u; s_img[pos * 2 + 1] = v;
   }
-  __syncthreads();
+  __syncthreads();                           // (the only barrier: each wave's LDS staging is visible to its own lanes)
+  if (!frame_valid) return;
 
   double rvec[3] = {0, 0, 0}, tvec[3] = {0, 0, 0};
   int status;
@@ -865,12 +873,16 @@ int32_t pnp_launch(const float* kp_xyc, const double* landmarks, const double* K
   PnpArgs a{kp_xyc, landmarks, K, dist, rot, tvec, rvec, status, N, J, conf_thr0, thr_decay, min_pts, thr_iters,
             max_iters, reproj_err, confidence, 0};
   { static const char* e = dev_env("SCPOSE_PNP_SPEC"); a.dbg_no_spec = (kDevBuild && e && atoi(e) == 0) ? 1 : 0; }
-  // 36 864 B of work matrices + 72 B per landmark: 37 656 B at J = 11, so FOUR one-wave workgroups fit the 160 KB of a CU
-  // (J <= 56; with the arrays sized for kMaxJ = 64 it was 41 472 B and only three fitted)
-  const size_t lds = (size_t)(144 * kPW + J * 9) * sizeof(double);
-  static LdsOptIn big_lds;   // per device (common.h); opted in once for the largest J
-  { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(pnp_kernel), (int)((144 * kPW + kMaxJ * 9) * sizeof(double)), &big_lds); if (rc != SCPOSE_OK) return rc; }
-  hipLaunchKernelGGL(pnp_kernel, dim3(N), dim3(64), lds, stream, a);
+  // 36 864 B of work matrices + 72 B per landmark and frame (37 656 B at J = 11).  Two frames per workgroup: measured alone
+  // (256 frames, 10 % outliers) 0.77 ms against 0.80 ms for one and 1.02 ms for four frames per workgroup (four waves
+  // contend for one CU's LDS); beside the next forward all three cost the step the same 0.45-0.5 ms
+  const size_t per_frame = (size_t)(144 * kPW + J * 9) * sizeof(double);
+  int fpw = 2;
+  { static const char* e = dev_env("SCPOSE_PNP_FPW"); if (kDevBuild && e && atoi(e) >= 1 && atoi(e) <= 4 && atoi(e) * per_frame <= 160 * 1024) fpw = atoi(e); }   // development: frames per workgroup
+  const size_t lds = per_frame * fpw;
+  static LdsOptIn big_lds;   // per device (common.h); opted in once for the whole LDS
+  { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(pnp_kernel), 160 * 1024, &big_lds); if (rc != SCPOSE_OK) return rc; }
+  hipLaunchKernelGGL(pnp_kernel, dim3((N + fpw - 1) / fpw), dim3(64 * fpw), lds, stream, a);
   SCP_CHECK_HIP(hipGetLastError());
   return SCPOSE_OK;
 }

@@ -53,7 +53,8 @@ struct StemFusedLaunch {
   const float* mean_std; // [6] (uint8 input)
   void* out;
   int32_t N, H, W, Ho, Wo;
-  int32_t tiles_x, tiles_y, tiles_total, tiles_per_wg, grid;
+  int32_t tiles_x, tiles_y, tiles_total, grid;
+  uint32_t* sched;       // dynamic tile queue (conv_device.h: tile_claim)
 };
 
 // MFMA accumulator row (4 * (lane >> 4) + reg) -> channel within the 16-channel block (same map as conv_igemm.hip):
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(512, 2) void stem_fused_kernel(const StemFusedLaunc
   uint16_t* lut = reinterpret_cast<uint16_t*>(smem);
   char* in16 = smem + kLutBytes;
   char* mid = in16 + kInBytes;
+  int* tq = reinterpret_cast<int*>(mid + kMidBytes);   // tile queue words
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, r = lane & 15, half = lane >> 5, psel = q & 1;
@@ -123,9 +125,10 @@ __global__ __launch_bounds__(512, 2) void stem_fused_kernel(const StemFusedLaunc
     k2[s] = plane * kMS + (ky * kMW + kx) * 16;
   }
 
-  const int wg = xcd_remap(blockIdx.x, p.grid);
-  const int t_begin = wg * p.tiles_per_wg;
-  const int t_end = min(p.tiles_total, t_begin + p.tiles_per_wg);
+  // tiles come from the launch's dynamic queue (conv_device.h): this tile and the next are always known (the next patch is
+  // fetched under this tile's conv1); the one after is claimed at the top of the tile and published through LDS in front of
+  // the tile's last barrier
+  if (tid == 0) { tq[0] = tile_claim(p.sched, p.tiles_total); tq[1] = tq[0] < 0 ? -1 : tile_claim(p.sched, p.tiles_total); }
   auto decode = [&](int t, int& img, int& oy0, int& ox0) {
     img = t / tiles_per_img;
     const int rem = t - img * tiles_per_img;
@@ -199,15 +202,18 @@ __global__ __launch_bounds__(512, 2) void stem_fused_kernel(const StemFusedLaunc
     }
   };
 
-  __syncthreads();   // table, zeroed patch
-  if (t_begin < t_end) { fetch(t_begin); commit(t_begin); }
+  __syncthreads();   // table, zeroed patch, first two tile ids
+  int t = tq[0], t_next = tq[1];
+  if (t >= 0) { fetch(t); commit(t); }
   __syncthreads();
 
-  for (int t = t_begin; t < t_end; ++t) {
+  for (; t >= 0; t = t_next, t_next = tq[2]) {             // tq[2]: published before this tile's last barrier, rewritten after the next tile's first
     int img, oy0, ox0;
     decode(t, img, oy0, ox0);
-    const bool more = t + 1 < t_end;
-    if (more) fetch(t + 1);                                // global loads fly under conv1
+    const bool more = t_next >= 0;
+    int t_after = -1;
+    if (tid == 0 && more) t_after = tile_claim(p.sched, p.tiles_total);   // returns under conv1 / conv2
+    if (more) fetch(t_next);                               // global loads fly under conv1
 
     // ---- conv1 -> intermediate tile ----
 #pragma unroll 1
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void stem_fused_kernel(const StemFusedLaunc
       }
     }
     __syncthreads();                                       // intermediate tile complete; the staged patch is dead
-    if (more) commit(t + 1);                               // ... so the next patch goes in under conv2
+    if (more) commit(t_next);                              // ... so the next patch goes in under conv2
 
     // ---- conv2 -> output ----
     f32x4 acc[2][2];
@@ -293,11 +299,13 @@ __global__ __launch_bounds__(512, 2) void stem_fused_kernel(const StemFusedLaunc
         *reinterpret_cast<u32x4_t*>(static_cast<char*>(p.out) + (((size_t)img * 8 + plane) * plane_sz + (size_t)oy * p.Wo + ox) * 16) = ov;
       }
     }
-    __syncthreads();                                       // intermediate tile free again; next patch committed
+    if (tid == 0) tq[2] = t_after;
+    __syncthreads();                                       // intermediate tile free again; next patch committed; tq[2] published
   }
+  if (tid == 0) tile_retire(p.sched);
 }
 
-size_t stem_fused_lds_bytes() { return (size_t)kLutBytes + kInBytes + kMidBytes; }
+size_t stem_fused_lds_bytes() { return (size_t)kLutBytes + kInBytes + kMidBytes + 16; }
 
 // Host: pack the two BN-folded convolutions (OIHW f32) for the kernel.  w1: [64][3][3][3], w2: [64][64][3][3].
 void stem_fused_pack(const float* w1, const float* b1, const float* w2, const float* b2, int dtype, std::vector<uint16_t>* pw1,
@@ -335,7 +343,8 @@ void stem_fused_pack(const float* w1, const float* b1, const float* w2, const fl
 }
 
 int32_t stem_fused_launch(const void* in, int in_fmt, const void* w1, const void* w2, const float* b1, const float* b2,
-                          const float* mean_std, int N, int H, int W, int dtype, void* out, hipStream_t stream) {
+                          const float* mean_std, int N, int H, int W, int dtype, void* out, uint32_t* sched, hipStream_t stream) {
+  SCP_REQUIRE(sched, "stem: null tile-queue words");
   SCP_REQUIRE(H % 32 == 0 && W % 32 == 0, "stem: H=%d W=%d must be multiples of 32", H, W);
   SCP_REQUIRE(in_fmt == SCPOSE_IN_F32_NCHW || in_fmt == SCPOSE_IN_U8_NHWC, "stem: input format %d", in_fmt);
   SCP_REQUIRE(in_fmt == SCPOSE_IN_F32_NCHW || mean_std, "stem: u8 input needs mean/std");
@@ -345,10 +354,8 @@ int32_t stem_fused_launch(const void* in, int in_fmt, const void* w1, const void
   L.N = N; L.H = H; L.W = W; L.Ho = H / 4; L.Wo = W / 4;
   L.tiles_x = (L.Wo + kTW - 1) / kTW; L.tiles_y = (L.Ho + kTH - 1) / kTH;
   L.tiles_total = N * L.tiles_x * L.tiles_y;
-  int grid = conv_device_cus();
-  if (grid > L.tiles_total) grid = L.tiles_total;
-  L.tiles_per_wg = (L.tiles_total + grid - 1) / grid;
-  L.grid = (L.tiles_total + L.tiles_per_wg - 1) / L.tiles_per_wg;
+  L.grid = conv_device_cus() < L.tiles_total ? conv_device_cus() : L.tiles_total;
+  L.sched = sched;
   const size_t lds = stem_fused_lds_bytes();
 #define STEM_LAUNCH(DTV, FMTV)                                                                                     \
   do {                                                                                                             \
