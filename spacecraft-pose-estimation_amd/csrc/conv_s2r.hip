@@ -194,9 +194,148 @@ __global__ __launch_bounds__(512, 2) void conv_s2r_kernel(const S2rLaunch p) {
   }
 }
 
+
+// ---- Cin = 96 (12 input planes): 768-thread workgroups ---------------------------------------------------------------------
+// The 3x3 stride-2 layers with 96 input channels (fuse down paths of branch 1: 96 -> 96 / 192 / 384) have K = 864: one
+// 16-channel output block needs 27 k-steps x 4 VGPRs = 108 registers of weights, so a wave owns ONE block and a workgroup of
+// TWELVE waves (three per SIMD, 168 registers each) covers 192 output channels of an 8 x 8-pixel tile.  12 planes = 3 k-steps
+// per tap exactly, so the fragment address of k-step s is a per-lane base (k-group q -> plane q) plus a compile-time
+// immediate (planes 4 (s % 3) and tap s / 3).  LDS holds only the double-buffered input tile ([12 planes][17 x 17 pixels]:
+// 2 x 55.5 KB; wave w fills plane w), and a tile costs one barrier.  Cout = 96: the twelve waves are 6 blocks x 2 row sets;
+// Cout = 384: two passes, each on its own half of the workgroups (weights stay in registers for a workgroup's whole life).
+constexpr int k12T = 8, k12MW = 17, k12MPix = 17 * 17, k12MS = k12MPix * 16, k12XB = 12 * k12MS;
+
+struct S2r12Launch {
+  const void* in;
+  const void* w;         // [27 k-steps][Cout / 16 blocks][4 k-groups][16 rows][8]  (conv_s2r_pack)
+  const float* bias;     // MFMA row order
+  void* out;
+  uint32_t in_bytes, out_bytes;
+  int32_t N, H, W, Ho, Wo, cout_planes, relu;
+  int32_t tiles_x, tiles_y, tiles_total, npass, wgs_per_pass, tiles_per_wg;
+};
+
+template <int DT, int G>   // G: output-channel blocks per workgroup pass (12, or 6 with two row sets)
+__global__ __launch_bounds__(768, 3) void conv_s2r12_kernel(const S2r12Launch p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename DtOf<DT>::type T;
+  typedef typename FragOf<T>::type frag_t;
+  constexpr int KS = 27, RSETS = 12 / G, NCOL = 4 / RSETS;     // a wave's columns: pairs of tile rows (16 pixels each)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, r = lane & 15, half = lane >> 5, psel = q & 1;
+  const int g = wave % G, rset = wave / G;
+  const int HW = p.H * p.W;
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+  const int pass = blockIdx.x / p.wgs_per_pass, wgp = blockIdx.x - pass * p.wgs_per_pass;
+  const int nblocks = p.cout_planes >> 1, blk = pass * G + g;
+
+  frag_t wf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+    wf[s] = *reinterpret_cast<const frag_t*>(static_cast<const char*>(p.w) + ((((size_t)s * nblocks + blk) * 4 + q) * 16 + r) * 16);
+  const float4 bs = *reinterpret_cast<const float4*>(p.bias + blk * 16 + q * 4);
+
+  const int wg = xcd_remap(wgp, p.wgs_per_pass);
+  const int t_begin = wg * p.tiles_per_wg;
+  const int t_end = min(p.tiles_total, t_begin + p.tiles_per_wg);
+  auto decode = [&](int t, int& img, int& oy0, int& ox0) {
+    img = t / tiles_per_img;
+    const int rem = t - img * tiles_per_img;
+    const int ty = rem / p.tiles_x;
+    oy0 = ty * k12T; ox0 = (rem - ty * p.tiles_x) * k12T;
+  };
+  const buf_rsrc_t rs_in = make_buf(p.in, p.in_bytes), rs_out = make_buf(p.out, p.out_bytes);
+  // LDS-DMA of tile t into buffer b: wave w fills plane w, five 64-pixel pieces (the last one 33 pixels)
+  auto issue_x = [&](int t, int b) {
+    int img, oy0, ox0;
+    decode(t, img, oy0, ox0);
+    char* xl = smem + b * k12XB + wave * k12MS;
+#pragma unroll
+    for (int piece = 0; piece < (k12MPix + 63) / 64; ++piece) {
+      const int slot = piece * 64 + lane;
+      const int my = slot / k12MW, mx = slot - my * k12MW;
+      const int iy = 2 * oy0 - 1 + my, ix = 2 * ox0 - 1 + mx;
+      const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const uint32_t voff = ok ? (uint32_t)(img * 12 * HW + iy * p.W + ix) * 16u : BUF_OOB;   // padding: read as zeros
+      if (slot < k12MPix) dma16_buf(rs_in, voff, (uint32_t)(wave * HW) * 16u, xl + piece * 1024);   // lanes past the plane stay inactive
+    }
+  };
+
+  if (t_begin < t_end) issue_x(t_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // this lane's pixel inside a column: the column's two tile rows x 8 pixels
+  const int lrow = r >> 3, lpx = (r - lrow) & 7;   // second row rotated by one pixel: every ds_read_b128 lane group then hits 16 distinct banks
+  const int lbase = ((2 * lrow) * k12MW + 2 * lpx) * 16 + q * k12MS;
+  const size_t plane_sz = (size_t)p.Ho * p.Wo;
+  const uint32_t relu_floor = p.relu ? 0u : 0x80008000u;
+  int buf = 0;
+  for (int t = t_begin; t < t_end; ++t, buf ^= 1) {
+    int img, oy0, ox0;
+    decode(t, img, oy0, ox0);
+    if (t + 1 < t_end) issue_x(t + 1, buf ^ 1);            // streams in under this tile's MFMAs
+    const char* xl = smem + buf * k12XB + lbase;
+#pragma unroll 1
+    for (int c0 = 0; c0 < NCOL; c0 += 2) {
+      const int col0 = rset * NCOL + c0;                   // columns col0, col0 + 1: tile rows 2 col0 .. 2 col0 + 3
+      const char* bcol = xl + col0 * (4 * k12MW * 16);
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      auto koff = [](int s) { const int tap = s / 3, ky = tap / 3, kx = tap - 3 * ky; return 4 * (s % 3) * k12MS + (ky * k12MW + kx) * 16; };
+      frag_t bf[3][2];                                     // fragments two k-steps ahead (see conv_s2r_kernel)
+#pragma unroll
+      for (int s0 = 0; s0 < 2; ++s0)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) bf[s0][c] = *reinterpret_cast<const frag_t*>(bcol + c * (4 * k12MW * 16) + koff(s0));
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        if (s + 2 < KS) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c) bf[(s + 2) % 3][c] = *reinterpret_cast<const frag_t*>(bcol + c * (4 * k12MW * 16) + koff(s + 2));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0] = mfma16<T>(wf[s], bf[s % 3][0], acc[0]);
+        acc[1] = mfma16<T>(wf[s], bf[s % 3][1], acc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // epilogue: after the lane exchange the lower half-wave holds the 8 channels (plane 2 * block + psel) of column col0's
+      // pixel, the upper half-wave those of column col0 + 1's
+      uint32_t a[4], b[4];
+      a[0] = __float_as_uint(acc[0][0] + bs.x); a[1] = __float_as_uint(acc[0][1] + bs.y);
+      a[2] = __float_as_uint(acc[0][2] + bs.z); a[3] = __float_as_uint(acc[0][3] + bs.w);
+      b[0] = __float_as_uint(acc[1][0] + bs.x); b[1] = __float_as_uint(acc[1][1] + bs.y);
+      b[2] = __float_as_uint(acc[1][2] + bs.z); b[3] = __float_as_uint(acc[1][3] + bs.w);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(a[jj], b[jj], false, false);
+        a[jj] = sw[0]; b[jj] = sw[1];
+      }
+      u32x4_t ov;
+      ov[0] = relu2_16(pack2<T>(__uint_as_float(a[0]), __uint_as_float(a[1])), relu_floor);
+      ov[1] = relu2_16(pack2<T>(__uint_as_float(a[2]), __uint_as_float(a[3])), relu_floor);
+      ov[2] = relu2_16(pack2<T>(__uint_as_float(b[0]), __uint_as_float(b[1])), relu_floor);
+      ov[3] = relu2_16(pack2<T>(__uint_as_float(b[2]), __uint_as_float(b[3])), relu_floor);
+      const int oy = oy0 + 2 * (col0 + half) + lrow, ox = ox0 + lpx;
+      const bool store_ok = oy < p.Ho && ox < p.Wo;
+      const int plane = 2 * blk + psel;
+      const uint32_t voff = store_ok ? (uint32_t)(((size_t)img * p.cout_planes + plane) * plane_sz + (size_t)oy * p.Wo + ox) * 16u : BUF_OOB;
+      store16_buf(rs_out, voff, 0u, __builtin_bit_cast(u32x4, ov));
+    }
+    // next tile landed (this wave's plane) -- vmcnt(0), not a counted wait: stores may retire before older loads
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // ... and everybody is done with this buffer
+  }
+}
+
 // ---- host ----
 bool conv_s2r_config(int cin, int cout, int stride, int* planes, int* nblk, int* g) {
   if (stride == 1 && !(cin == 64 && cout == 64)) return false;   // stride 1: layer1's 3x3 (Bottleneck conv2, no residual)
+  if (cin == 96) {                              // conv_s2r12_kernel: one block per wave, 6 or 12 blocks per workgroup pass
+    if (stride != 2 || cout % 96 != 0) return false;
+    *planes = 12; *nblk = 1; *g = cout == 96 ? 6 : 12;
+    return true;
+  }
   if (cin != 32 && cin != 48 && cin != 64) return false;
   const int nb = cin == 48 ? 3 : 2;            // 16-channel blocks per wave: 48 / 32 output channels per group
   if (cout % (16 * nb) != 0) return false;
@@ -251,9 +390,40 @@ static int32_t s2r_dispatch(int planes, int g, int stride, const S2rLaunch& L, h
   return s2r_launch_one<DT, 8, 2, 4>(L, st);
 }
 
+template <int DT, int G>
+static int32_t s2r12_launch_one(const S2r12Launch& L, int grid, hipStream_t st) {
+  auto kern = conv_s2r12_kernel<DT, G>;
+  static LdsOptIn big;
+  { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(kern), 2 * k12XB, &big); if (rc != SCPOSE_OK) return rc; }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(768), 2 * k12XB, st, L);
+  SCP_CHECK_HIP(hipGetLastError());
+  return SCPOSE_OK;
+}
+
+static int32_t conv_s2r12_launch(const PackedConv& pc, int g, const void* in, int N, int H, int W, int relu, void* out, hipStream_t stream) {
+  S2r12Launch L{};
+  L.in = in; L.w = pc.d_ws2; L.bias = pc.d_bs2; L.out = out;
+  L.N = N; L.H = H; L.W = W; L.Ho = (H - 1) / 2 + 1; L.Wo = (W - 1) / 2 + 1;
+  L.in_bytes = (uint32_t)((size_t)N * 12 * H * W * 16);
+  L.out_bytes = (uint32_t)((size_t)N * (pc.cout / 8) * L.Ho * L.Wo * 16);
+  L.cout_planes = pc.cout / 8; L.relu = relu;
+  L.tiles_x = (L.Wo + k12T - 1) / k12T; L.tiles_y = (L.Ho + k12T - 1) / k12T;
+  L.tiles_total = N * L.tiles_x * L.tiles_y;
+  L.npass = pc.cout / (16 * g);
+  int per_pass = conv_device_cus() / L.npass;             // every pass gets its own share of the workgroups
+  if (per_pass < 1) per_pass = 1;
+  if (per_pass > L.tiles_total) per_pass = L.tiles_total;
+  L.tiles_per_wg = (L.tiles_total + per_pass - 1) / per_pass;
+  L.wgs_per_pass = (L.tiles_total + L.tiles_per_wg - 1) / L.tiles_per_wg;
+  const int grid = L.wgs_per_pass * L.npass;
+  if (pc.dtype == SCPOSE_DT_BF16) return g == 6 ? s2r12_launch_one<0, 6>(L, grid, stream) : s2r12_launch_one<0, 12>(L, grid, stream);
+  return g == 6 ? s2r12_launch_one<1, 6>(L, grid, stream) : s2r12_launch_one<1, 12>(L, grid, stream);
+}
+
 int32_t conv_s2r_launch(const PackedConv& pc, const void* in, int N, int H, int W, int relu, void* out, hipStream_t stream) {
   int planes, nblk, g;
   SCP_REQUIRE(conv_s2r_config(pc.cin, pc.cout, pc.stride, &planes, &nblk, &g) && pc.d_ws2, "conv s2r: %d->%d not eligible", pc.cin, pc.cout);
+  if (planes == 12) return conv_s2r12_launch(pc, g, in, N, H, W, relu, out, stream);
   S2rLaunch L{};
   L.in = in; L.w = pc.d_ws2; L.bias = pc.d_bs2; L.out = out;
   L.in_bytes = (uint32_t)((size_t)N * planes * H * W * 16);

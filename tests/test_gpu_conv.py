@@ -58,6 +58,14 @@ CASES = [
     (64, 64, 3, 2, 1, 1, 5, False, False),
     (64, 64, 3, 1, 20, 12, 3, False, True),     # register-weight kernel, stride 1 (layer1's 3x3), ragged map
     (64, 64, 3, 1, 16, 16, 2, True, False),     # ... with a residual it stays on the 32x32x16 kernel
+    # register-weight kernel for 96 input channels (conv_s2r12_kernel, 12 waves): Cout 96 (6 blocks x 2 row sets), 192, 384 (two
+    # passes), ragged / odd / one-pixel maps, enough tiles for several per workgroup
+    (96, 384, 3, 2, 24, 24, 2, False, True),
+    (96, 96, 3, 2, 48, 48, 2, False, True),
+    (96, 192, 3, 2, 18, 50, 3, False, False),
+    (96, 192, 3, 2, 9, 7, 2, False, True),
+    (96, 384, 3, 2, 1, 1, 5, False, False),
+    (96, 192, 3, 2, 96, 96, 8, False, True),
     # stride 2 with channel counts outside the register-weight kernel's grid: producer/consumer kernel, 2-plane chunks
     (48, 64, 3, 2, 24, 24, 2, False, True),
     (96, 96, 3, 2, 20, 12, 2, False, False),
@@ -175,6 +183,9 @@ EQUIVARIANCE = [  # cin cout k s H   N  res   -- one shape per kernel family at 
     (256, 48, 3, 1, 96, 32, False),
     (64, 256, 1, 1, 96, 32, True),     # conv_pipe 1x1, two workgroups per CU
     (48, 48, 3, 1, 96, 48, True),      # conv_pipe 3x3 (unfused branch-0 layer)
+    (96, 192, 3, 2, 48, 128, False),   # conv_s2r12 (12 waves, register weights)
+    (96, 384, 3, 2, 24, 256, False),   # ... two passes
+    (192, 384, 3, 2, 24, 128, False),  # conv_m32p stride 2 (Cin >= 192 stays there)
 ]
 
 
