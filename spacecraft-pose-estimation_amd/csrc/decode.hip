@@ -1,12 +1,12 @@
-// Heatmap decode: one wavefront per (frame, joint) map.
+// Heatmap decode: one 256-thread workgroup per (frame, joint) map.
 //
 // Replaces get_max_preds (landmark_regression/lib/core/inference.py:18-46), the quarter-pixel
 // refinement and back-transform of get_final_preds (:49-79) with transform_preds /
 // get_affine_transform(inv=1) / affine_transform (lib/utils/transforms.py:49-110), and the
 // [x, y, maxval] row assembly of validate() (lib/core/function.py:392-393).
 //
-// HBM-bound: each map (H*W f32) is read exactly once with 16 B/lane loads; the 64 lanes keep a
-// running (value, first index) pair and combine with 6 xor-shuffles.  Tie / NaN rules are
+// HBM-bound: each map (H*W f32) is read exactly once with 16 B/lane loads; every thread keeps a
+// running (value, first index) pair, waves combine with 6 xor-shuffles, the workgroup's four waves through LDS.  Tie / NaN rules are
 // numpy's: first occurrence wins, NaN counts as the maximum (first NaN wins).
 #include "common.h"
 
@@ -29,25 +29,41 @@ struct DecodeArgs {
   int post_process;
 };
 
+// One 256-thread workgroup per map: every thread issues all of its 16-byte loads before it compares anything (a 96 x 96
+// map is 9 loads per thread; with one wave per map and a load-compare loop the kernel kept 1 KB in flight per wave and
+// ran at 0.56 TB/s), reduces over its wave with xor-shuffles and over the four waves through LDS.
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int map = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (map >= a.N * a.J) return;  // whole wave exits together
+  __shared__ float s_v[4];
+  __shared__ int s_i[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int map = blockIdx.x;
   const int HW = a.H * a.W;
   const float* m = a.hm + (size_t)map * HW;
 
   float bv = -__builtin_inff();
   int bi = 0x7fffffff;
   if ((HW & 3) == 0) {
-    for (int i = lane * 4; i < HW; i += 256) {
-      const float4 v = *reinterpret_cast<const float4*>(m + i);
-      if (better(v.x, i, bv, bi)) { bv = v.x; bi = i; }
-      if (better(v.y, i + 1, bv, bi)) { bv = v.y; bi = i + 1; }
-      if (better(v.z, i + 2, bv, bi)) { bv = v.z; bi = i + 2; }
-      if (better(v.w, i + 3, bv, bi)) { bv = v.w; bi = i + 3; }
+    constexpr int U = 4;                                  // loads in flight per thread and round
+    for (int i0 = tid * 4; i0 < HW; i0 += 1024 * U) {
+      float4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * 1024;
+        v[u] = i < HW ? *reinterpret_cast<const float4*>(m + i) : make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff());
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * 1024;
+        if (i < HW) {
+          if (better(v[u].x, i, bv, bi)) { bv = v[u].x; bi = i; }
+          if (better(v[u].y, i + 1, bv, bi)) { bv = v[u].y; bi = i + 1; }
+          if (better(v[u].z, i + 2, bv, bi)) { bv = v[u].z; bi = i + 2; }
+          if (better(v[u].w, i + 3, bv, bi)) { bv = v[u].w; bi = i + 3; }
+        }
+      }
     }
   } else {
-    for (int i = lane; i < HW; i += 64) {
+    for (int i = tid; i < HW; i += 256) {
       const float v = m[i];
       if (better(v, i, bv, bi)) { bv = v; bi = i; }
     }
@@ -58,7 +74,12 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
     const int oi = __shfl_xor(bi, off, 64);
     if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
   }
-  if (lane != 0) return;
+  if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
+  __syncthreads();
+  if (tid != 0) return;
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (better(s_v[w], s_i[w], bv, bi)) { bv = s_v[w]; bi = s_i[w]; }
 
   // inference.py:37-45 -- idx as float32, x = idx % W, y = floor(idx / W), masked when !(max > 0)
   float cx = (float)(bi % a.W), cy = (float)(bi / a.W);
@@ -108,8 +129,7 @@ int32_t decode_launch(const float* hm, int N, int J, int H, int W, const float* 
   SCP_REQUIRE(!preds_xyc || (center && scale), "decode: center/scale required for image-space output");
   if (N == 0) return SCPOSE_OK;
   DecodeArgs a{hm, center, scale, preds_xyc, coords, maxvals, N, J, H, W, post_process};
-  const int maps = N * J;
-  hipLaunchKernelGGL(decode_kernel, dim3((maps + 3) / 4), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(decode_kernel, dim3(N * J), dim3(256), 0, stream, a);
   SCP_CHECK_HIP(hipGetLastError());
   return SCPOSE_OK;
 }
