@@ -50,7 +50,8 @@ constexpr int kCols1 = (kHPix + 15) / 16;      // 21 MFMA columns of conv1
 constexpr int kXS = (kHPix | 1) * 16;          // bytes of one t1 plane (325 slots: odd pitch)
 constexpr int kT2S = (kT * kT | 1) * 16;       // bytes of one t2 plane (257 slots)
 constexpr int kW1Bytes = 8 * 4 * 4 * 16 * 16;  // 32 KB
-constexpr int kLds = 8 * kXS + 8 * kT2S + kW1Bytes + (64 + 64 + 256) * 4 + 16;   // + the tile queue words
+constexpr int kW2LSteps = 12;                  // identity Bottleneck: k-steps of conv2's weights resident in LDS (48 KB); the other 6 stay in registers
+constexpr int kLds = 8 * kXS + 8 * kT2S + kW1Bytes + (64 + 64 + 256) * 4 + 16 + kW2LSteps * 4 * 1024;   // + the tile queue words + W2
 // first Bottleneck (PROJ): x has 64 channels, W1 is 8 KB, and the tile's 256 centre pixels of x (8 planes) are kept in LDS,
 // double-buffered, as the operand of the projection half of conv3
 constexpr int kW1BytesProj = 2 * 4 * 4 * 16 * 16;
@@ -123,6 +124,14 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
   // requested during this tile's phase C); the one after is claimed at the top of the tile and published through LDS
   // in front of the tile's second barrier
   int* tq = reinterpret_cast<int*>(bl + 64 + 64 + 256);
+  // conv2's weights: the first W2L k-steps (all four 16-channel blocks, 4 KB each) live in LDS, the rest in registers.  A wave
+  // used to re-read its 36 fragments (36 KB) from L2 for every tile -- 288 KB per tile and CU, 40 % of all the bytes the CU's
+  // vector-memory path moved, and phase C (residual loads, x requests, stores) is bound by exactly that path.  (The first
+  // Bottleneck's LDS is taken by the tile's copy of x: it keeps the register form.)
+  constexpr int W2L = PROJ ? 0 : kW2LSteps;
+  char* w2ll = reinterpret_cast<char*>(tq) + 16;
+  for (int o = tid * 16; o < W2L * 4 * 1024; o += 512 * 16)
+    *reinterpret_cast<u32x4*>(w2ll + o) = *reinterpret_cast<const u32x4*>(static_cast<const char*>(p.w2) + o);
   if (tid == 0) { tq[0] = tile_claim(p.sched, p.tiles_total); tq[1] = tq[0] < 0 ? -1 : tile_claim(p.sched, p.tiles_total); }
   __syncthreads();
   int t = tq[0], t_next = tq[1];
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
     if (tid == 0 && t_next >= 0) t_after = tile_claim(p.sched, p.tiles_total);   // returns under phases A and B
 
     // ---- A: conv1 (1x1, 256 -> 64) on the halo pixels -> t1: all four 16-channel blocks of the wave's columns ----
-    frag_t w2f[18][2];                                     // conv2's weights of this wave: re-read per tile (below)
+    frag_t w2f[18 - W2L][2];                               // conv2's weights of this wave that are not in LDS: re-read per tile (below)
     {
       f32x4 acc[4][3];
 #pragma unroll
@@ -246,10 +255,10 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
       // sporadically wrong (non-deterministic at the 1e-1 level; found by the determinism check of tools_dev/dump_tap.py).
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s2 = 0; s2 < 18; ++s2)
+      for (int s2 = W2L; s2 < 18; ++s2)
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
-          w2f[s2][mb] = __builtin_bit_cast(frag_t, load16_buf(rs_w2, w2vo, (uint32_t)((s2 * 4 + mb) * 1024)));
+          w2f[s2 - W2L][mb] = __builtin_bit_cast(frag_t, load16_buf(rs_w2, w2vo, (uint32_t)((s2 * 4 + mb) * 1024)));
       __builtin_amdgcn_sched_barrier(0);
     }
     const unsigned long long ts1 = now();
@@ -258,35 +267,64 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
     const unsigned long long ts2 = now();
 
     // ---- B: conv2 (3x3, 64 -> 64) on the 256 output pixels -> t2: tile rows wq, wq + 4, wq + 8, wq + 12 ----
+    // two row groups at a time where the weights come from LDS (one A fragment then feeds two MFMAs)
+    constexpr int CC = PROJ ? 1 : 2;
 #pragma unroll 1
-    for (int c = 0; c < 4; ++c) {
-      f32x4 acc[2];
+    for (int c0 = 0; c0 < 4; c0 += CC) {
+      f32x4 acc[2][CC];
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
         const float4 bs = *reinterpret_cast<const float4*>(bl + 64 + (2 * ch + mb) * 16 + q * 4);
-        acc[mb] = f32x4{bs.x, bs.y, bs.z, bs.w};
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) acc[mb][cc] = f32x4{bs.x, bs.y, bs.z, bs.w};
       }
-      const int py = wq + 4 * c, px = r;                   // output pixel of this lane
-      const int pix = py * kT + px;
-      const char* bq0 = t1l + (py * kHW + px) * 16 + qoff;
+      const int px = r;                                    // output pixels of this lane: rows wq + 4 (c0 + cc)
+      const char* bq0 = t1l + ((wq + 4 * c0) * kHW + px) * 16 + qoff;
+      const char* aq0 = w2ll + (2 * ch) * 1024 + lane * 16;
       auto k2imm = [](int s) { const int tap = s >> 1, ky = tap / 3, kx = tap - 3 * ky; return 4 * (s & 1) * kXS + (ky * kHW + kx) * 16; };
-      frag_t bq[3];                                       // fragments two k-steps ahead
-      bq[0] = *reinterpret_cast<const frag_t*>(bq0 + k2imm(0));
-      bq[1] = *reinterpret_cast<const frag_t*>(bq0 + k2imm(1));
+      frag_t bq[3][CC], aq[3][2];                          // fragments two k-steps ahead
+      auto fetch = [&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+        if constexpr (S < 18) {
 #pragma unroll
-      for (int s = 0; s < 18; ++s) {
-        if (s + 2 < 18) bq[(s + 2) % 3] = *reinterpret_cast<const frag_t*>(bq0 + k2imm(s + 2));
+          for (int cc = 0; cc < CC; ++cc) bq[S % 3][cc] = *reinterpret_cast<const frag_t*>(bq0 + cc * (4 * kHW * 16) + k2imm(S));
+          if constexpr (S < W2L) {
+            aq[S % 3][0] = *reinterpret_cast<const frag_t*>(aq0 + S * 4096);
+            aq[S % 3][1] = *reinterpret_cast<const frag_t*>(aq0 + S * 4096 + 1024);
+          }
+        }
+      };
+      fetch(std::integral_constant<int, 0>{});
+      fetch(std::integral_constant<int, 1>{});
+      auto kstep = [&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+        fetch(std::integral_constant<int, S + 2>{});
         __builtin_amdgcn_sched_barrier(0);
-        acc[0] = mfma16<T>(w2f[s][0], bq[s % 3], acc[0]);
-        acc[1] = mfma16<T>(w2f[s][1], bq[s % 3], acc[1]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        uint2 o;
-        o.x = relu2_16(pack2<T>(acc[mb][0], acc[mb][1]), 0u);
-        o.y = relu2_16(pack2<T>(acc[mb][2], acc[mb][3]), 0u);
-        *reinterpret_cast<uint2*>(t2l + (2 * (2 * ch + mb) + psel) * kT2S + pix * 16 + 8 * (q >> 1)) = o;
+        for (int mb = 0; mb < 2; ++mb) {
+          frag_t a;
+          if constexpr (S < W2L) a = aq[S % 3][mb]; else a = w2f[S - W2L][mb];
+#pragma unroll
+          for (int cc = 0; cc < CC; ++cc) acc[mb][cc] = mfma16<T>(a, bq[S % 3][cc], acc[mb][cc]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      kstep(std::integral_constant<int, 0>{}); kstep(std::integral_constant<int, 1>{}); kstep(std::integral_constant<int, 2>{});
+      kstep(std::integral_constant<int, 3>{}); kstep(std::integral_constant<int, 4>{}); kstep(std::integral_constant<int, 5>{});
+      kstep(std::integral_constant<int, 6>{}); kstep(std::integral_constant<int, 7>{}); kstep(std::integral_constant<int, 8>{});
+      kstep(std::integral_constant<int, 9>{}); kstep(std::integral_constant<int, 10>{}); kstep(std::integral_constant<int, 11>{});
+      kstep(std::integral_constant<int, 12>{}); kstep(std::integral_constant<int, 13>{}); kstep(std::integral_constant<int, 14>{});
+      kstep(std::integral_constant<int, 15>{}); kstep(std::integral_constant<int, 16>{}); kstep(std::integral_constant<int, 17>{});
+#pragma unroll
+      for (int cc = 0; cc < CC; ++cc) {
+        const int pix = (wq + 4 * (c0 + cc)) * kT + px;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          uint2 o;
+          o.x = relu2_16(pack2<T>(acc[mb][cc][0], acc[mb][cc][1]), 0u);
+          o.y = relu2_16(pack2<T>(acc[mb][cc][2], acc[mb][cc][3]), 0u);
+          *reinterpret_cast<uint2*>(t2l + (2 * (2 * ch + mb) + psel) * kT2S + pix * 16 + 8 * (q >> 1)) = o;
+        }
       }
     }
     const unsigned long long ts3 = now();
