@@ -1,4 +1,5 @@
-"""Time the fused BasicBlock kernel: python tools_dev/time_block.py C H N"""
+"""Time the fused BasicBlock kernel: python tools_dev/time_block.py C H N [randn|relu|zero]   (input data: the kernel's
+speed depends on it -- the chip holds a lower clock on full-range random operands than on post-ReLU or zero tensors)"""
 import _dev  # noqa: F401  (enables the library's development switches when SCPOSE_* variables are set)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +9,9 @@ ops = import_module("spacecraft-pose-estimation_amd.ops")
 C, H, N = [int(v) for v in sys.argv[1:4]]
 w1 = torch.randn(C, C, 3, 3) / (C * 9) ** 0.5; w2 = torch.randn(C, C, 3, 3) / (C * 9) ** 0.5
 c1 = ops.Conv(w1, torch.zeros(C)); c2 = ops.Conv(w2, torch.zeros(C))
-x = torch.randn(N, C // 8, H, H, 8, device="cuda").bfloat16()
+data = sys.argv[4] if len(sys.argv) > 4 else "randn"
+x = torch.randn(N, C // 8, H, H, 8, device="cuda")
+x = {"randn": x, "relu": x.clamp(min=0), "zero": x * 0}[data].bfloat16()
 for _ in range(3): y = ops.basic_block(c1, c2, x)
 torch.cuda.synchronize()
 st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -19,4 +22,5 @@ us = st.elapsed_time(en) / 20 * 1e3
 if int(os.environ.get("SCPOSE_DBG", "0")) & 8:
     import ctypes
     ctypes.CDLL(ops.nat.LIB_PATH).scpose_dbg_dump()
+print("data=%s " % data, end="")
 print("fused block C=%d %dx%d N=%d: %.1f us  %.1f TFLOP/s (both convs)" % (C, H, H, N, us, 2 * 2.0 * C * C * 9 * H * H * N / us / 1e6))
