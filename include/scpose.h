@@ -82,11 +82,12 @@ typedef struct scpose_hrnet_desc {
   int32_t num_stages;          /* always 3 (STAGE2..STAGE4) */
   int32_t num_modules[3];      /* EXTRA.STAGEk.NUM_MODULES */
   int32_t num_branches[3];     /* EXTRA.STAGEk.NUM_BRANCHES (2,3,4) */
-  int32_t num_blocks[3][4];    /* EXTRA.STAGEk.NUM_BLOCKS (BASIC blocks per branch) */
-  int32_t num_channels[3][4];  /* EXTRA.STAGEk.NUM_CHANNELS */
+  int32_t num_blocks[3][4];    /* EXTRA.STAGEk.NUM_BLOCKS (blocks per branch) */
+  int32_t num_channels[3][4];  /* EXTRA.STAGEk.NUM_CHANNELS (the block's planes: a BOTTLENECK branch carries 4x as many channels) */
   int32_t dtype;               /* SCPOSE_DT_* */
   float mean[3], std[3];       /* Normalize() constants for SCPOSE_IN_U8_NHWC */
   int32_t head;                /* SCPOSE_HEAD_*: which member of the model family (cfg.MODEL.NAME) */
+  int32_t block[3];            /* EXTRA.STAGEk.BLOCK (blocks_dict, pose_hrnet.py:266-269): 0 BASIC, 1 BOTTLENECK (expansion 4) */
 } scpose_hrnet_desc;
 
 typedef struct scpose_hrnet* scpose_hrnet_t;

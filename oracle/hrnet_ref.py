@@ -67,10 +67,10 @@ def with_model(cfg, name):
     return out
 
 
-def _wN_cfg(c, num_joints, image, modules=(1, 4, 3)):
+def _wN_cfg(c, num_joints, image, modules=(1, 4, 3), block="BASIC", blocks=4):
     def stage(nb, nm):
-        return {"NUM_MODULES": nm, "NUM_BRANCHES": nb, "BLOCK": "BASIC",
-                "NUM_BLOCKS": [4] * nb, "NUM_CHANNELS": [c * (2 ** i) for i in range(nb)],
+        return {"NUM_MODULES": nm, "NUM_BRANCHES": nb, "BLOCK": block,
+                "NUM_BLOCKS": [blocks] * nb, "NUM_CHANNELS": [c * (2 ** i) for i in range(nb)],
                 "FUSE_METHOD": "SUM"}
     return {"MODEL": {"NAME": "pose_hrnet", "NUM_JOINTS": num_joints, "INIT_WEIGHTS": False,
                       "PRETRAINED": "", "IMAGE_SIZE": [image, image],
@@ -83,6 +83,12 @@ def _wN_cfg(c, num_joints, image, modules=(1, 4, 3)):
 def tiny_cfg(num_joints=11, image=64, c=16, modules=(1, 1, 1)):
     """Small HRNet of the same topology (for fast CPU tests)."""
     return _wN_cfg(c, num_joints, image, modules)
+
+
+def bneck_cfg(num_joints=11, image=64, c=16, modules=(1, 1, 1), blocks=2):
+    """STAGEk.BLOCK = BOTTLENECK (blocks_dict, pose_hrnet.py:266-269): branch b carries 4 * c * 2^b channels.  No shipped YAML
+    uses it; the reference module builds and runs it (tests/golden/hrnet_bneck_reference_outputs.npz)."""
+    return _wN_cfg(c, num_joints, image, modules, block="BOTTLENECK", blocks=blocks)
 
 
 # ----------------------------------------------------------------------------- key/shape census
@@ -140,11 +146,15 @@ def state_dict_spec(cfg):
         for m in range(scfg["NUM_MODULES"]):
             multi = head_of(cfg) is not None or not (last_stage and m == scfg["NUM_MODULES"] - 1)
             mp = "%s.%d" % (stname, m)
-            if scfg["BLOCK"] != "BASIC":
-                raise NotImplementedError("stage blocks other than BASIC are not used by any shipped config")
             for b in range(nb):
                 for k in range(scfg["NUM_BLOCKS"][b]):
                     p = "%s.branches.%d.%d" % (mp, b, k)
+                    if scfg["BLOCK"] == "BOTTLENECK":      # pose_hrnet.py:60-98, :142-154: in = out = 4 * planes, no downsample
+                        pl = scfg["NUM_CHANNELS"][b]
+                        _conv(sd, p + ".conv1", pl, cur[b], 1); _bn(sd, p + ".bn1", pl)
+                        _conv(sd, p + ".conv2", pl, pl, 3); _bn(sd, p + ".bn2", pl)
+                        _conv(sd, p + ".conv3", cur[b], pl, 1); _bn(sd, p + ".bn3", cur[b])
+                        continue
                     _conv(sd, p + ".conv1", cur[b], cur[b], 3); _bn(sd, p + ".bn1", cur[b])
                     _conv(sd, p + ".conv2", cur[b], cur[b], 3); _bn(sd, p + ".bn2", cur[b])
             for i in range(nb if multi else 1):
@@ -314,6 +324,11 @@ def forward(sd, cfg, x, emulate=None, taps=None):
                 t = xs[b]
                 for k in range(scfg["NUM_BLOCKS"][b]):
                     p = "%s.branches.%d.%d" % (mp, b, k)
+                    if scfg["BLOCK"] == "BOTTLENECK":      # pose_hrnet.py:78-98 with identity residual
+                        u = A.conv_bn(t, p + ".conv1", p + ".bn1", relu=True)
+                        u = A.conv_bn(u, p + ".conv2", p + ".bn2", relu=True)
+                        t = A.conv_bn(u, p + ".conv3", p + ".bn3", relu=True, residual=t)
+                        continue
                     u = A.conv_bn(t, p + ".conv1", p + ".bn1", relu=True)
                     t = A.conv_bn(u, p + ".conv2", p + ".bn2", relu=True, residual=t)
                 xs[b] = t

@@ -37,6 +37,7 @@ class HrnetDesc(ctypes.Structure):
         ("mean", c_float * 3),
         ("std", c_float * 3),
         ("head", c_int32),
+        ("block", c_int32 * 3),
     ]
 
 

@@ -228,6 +228,16 @@ struct Builder {
     push(op);
     return op.out;
   }
+  // Bottleneck as a STAGE block (EXTRA.STAGEk.BLOCK = BOTTLENECK, pose_hrnet.py:266-269, :142-154): 4 * planes channels in and out,
+  // identity residual.  256 -> 64 -> 256 runs on the fused layer1 kernel, anything else as its three convolutions.
+  int stage_bottleneck(int x, const std::string& p, int planes) {
+    if (status != SCPOSE_OK) return -1;
+    static const char* bn_env = dev_env("SCPOSE_BNECK_FUSED");
+    if (planes == 64 && net->tensors[x].C == 256 && bottleneck_fusable(256, 64, 256) && !(bn_env && atoi(bn_env) == 0)) return bottleneck(x, p);
+    int y = conv(x, p + ".conv1", p + ".bn1", planes, 1, 1, true);
+    y = conv(y, p + ".conv2", p + ".bn2", planes, 3, 1, true);
+    return conv(y, p + ".conv3", p + ".bn3", 4 * planes, 1, 1, true, x);
+  }
   // BasicBlock relu(conv2(relu(conv1(x))) + x): one fused launch when the pair qualifies, else two convolutions
   int basic_block(int x, const std::string& p, int C) {
     if (status != SCPOSE_OK) return -1;
@@ -390,7 +400,9 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
   std::vector<int> pre{256};
   for (int si = 0; si < 3; ++si) {
     const int nb = d.num_branches[si];
+    const bool bneck_stage = d.block[si] == 1;
     std::vector<int> cur(d.num_channels[si], d.num_channels[si] + nb);
+    if (bneck_stage) for (int& c : cur) c *= 4;          // num_channels * block.expansion (pose_hrnet.py:393-400)
     const std::string tname = fmt("transition%d", si + 1);
     std::vector<int> xs;
     B.parallel_begin();   // transition convs: independent of each other (lane = branch they create)
@@ -420,7 +432,7 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
         int t = xs[b];
         for (int k = 0; k < d.num_blocks[si][b]; ++k) {
           const std::string p = fmt("%s.branches.%d.%d", mp.c_str(), b, k);
-          t = B.basic_block(t, p, cur[b]);
+          t = bneck_stage ? B.stage_bottleneck(t, p, d.num_channels[si][b]) : B.basic_block(t, p, cur[b]);
         }
         xs[b] = t;
       }
@@ -772,16 +784,19 @@ extern "C" int32_t scpose_hrnet_create(const scpose_hrnet_desc* desc, const char
     SCP_REQUIRE(desc->num_joints <= 16, "hrnet_create: the hrnet_cms heads support NUM_JOINTS <= 16 (got %d)", desc->num_joints);
   }
   for (int s = 0; s < 3; ++s) {
+    SCP_REQUIRE(desc->block[s] == 0 || desc->block[s] == 1, "hrnet_create: STAGE%d BLOCK code %d (0 BASIC, 1 BOTTLENECK)", s + 2, desc->block[s]);
     SCP_REQUIRE(desc->num_branches[s] == s + 2, "hrnet_create: STAGE%d NUM_BRANCHES=%d (expected %d)", s + 2, desc->num_branches[s], s + 2);
     SCP_REQUIRE(desc->num_modules[s] >= 1, "hrnet_create: STAGE%d NUM_MODULES=%d", s + 2, desc->num_modules[s]);
     for (int b = 0; b < desc->num_branches[s]; ++b) {
       SCP_REQUIRE(desc->num_channels[s][b] > 0 && desc->num_channels[s][b] % 16 == 0,
                   "hrnet_create: STAGE%d NUM_CHANNELS[%d]=%d must be a positive multiple of 16", s + 2, b, desc->num_channels[s][b]);
       SCP_REQUIRE(desc->num_blocks[s][b] >= 1, "hrnet_create: STAGE%d NUM_BLOCKS[%d]=%d", s + 2, b, desc->num_blocks[s][b]);
-      if (s > 0 && b < desc->num_branches[s - 1])
-        SCP_REQUIRE(desc->num_channels[s][b] == desc->num_channels[s - 1][b],
+      if (s > 0 && b < desc->num_branches[s - 1]) {   // channels a branch carries: planes * block.expansion
+        const int was = desc->num_channels[s - 1][b] * (desc->block[s - 1] == 1 ? 4 : 1), is = desc->num_channels[s][b] * (desc->block[s] == 1 ? 4 : 1);
+        SCP_REQUIRE(was == is,
                     "hrnet_create: STAGE%d branch %d changes channel count (%d -> %d); the reference forward (:445) cannot run that either",
-                    s + 2, b, desc->num_channels[s - 1][b], desc->num_channels[s][b]);
+                    s + 2, b, was, is);
+      }
     }
   }
   Weights W;

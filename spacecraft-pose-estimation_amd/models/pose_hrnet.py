@@ -59,10 +59,12 @@ def _bottleneck(cin, planes, downsample):
     return m
 
 
-def _hr_module(channels, num_blocks, multi_scale_output):
+def _hr_module(channels, num_blocks, multi_scale_output, bottleneck=False):
     nb = len(channels)
     m = _Params()
-    m.branches = nn.ModuleList([nn.Sequential(*[_basic_block(channels[b]) for _ in range(num_blocks[b])]) for b in range(nb)])
+    # STAGEk.BLOCK = BOTTLENECK (blocks_dict, pose_hrnet.py:266-269): channels[b] = 4 * planes in and out, identity residual (:142-154)
+    block = (lambda c: _bottleneck(c, c // 4, False)) if bottleneck else _basic_block
+    m.branches = nn.ModuleList([nn.Sequential(*[block(channels[b]) for _ in range(num_blocks[b])]) for b in range(nb)])
     rows = []
     for i in range(nb if multi_scale_output else 1):
         row = []
@@ -99,9 +101,10 @@ class PoseHighResolutionNet(nn.Module):
         pre = [256]
         for si, name in enumerate(("STAGE2", "STAGE3", "STAGE4")):
             scfg = extra[name]
-            if str(scfg["BLOCK"]) != "BASIC":
-                raise ValueError("%s.BLOCK=%s: stage blocks other than BASIC are not supported" % (name, scfg["BLOCK"]))
-            cur = [int(c) for c in scfg["NUM_CHANNELS"]]
+            if str(scfg["BLOCK"]) not in ("BASIC", "BOTTLENECK"):
+                raise ValueError("%s.BLOCK=%s: stage blocks are BASIC or BOTTLENECK (blocks_dict, pose_hrnet.py:266-269)" % (name, scfg["BLOCK"]))
+            bneck = str(scfg["BLOCK"]) == "BOTTLENECK"
+            cur = [int(c) * (4 if bneck else 1) for c in scfg["NUM_CHANNELS"]]     # num_channels * block.expansion (:393-400)
             trans = []
             for i in range(len(cur)):
                 if i < len(pre):
@@ -115,7 +118,7 @@ class PoseHighResolutionNet(nn.Module):
             setattr(self, "transition%d" % (si + 1), nn.ModuleList(trans))
             nm = int(scfg["NUM_MODULES"])
             mods = [_hr_module(cur, [int(b) for b in scfg["NUM_BLOCKS"]],
-                               self.HEAD is not None or not (name == "STAGE4" and m == nm - 1)) for m in range(nm)]
+                               self.HEAD is not None or not (name == "STAGE4" and m == nm - 1), bneck) for m in range(nm)]
             setattr(self, "stage%d" % (si + 2), nn.Sequential(*mods))
             pre = cur
         self._make_head(pre, int(cfg["MODEL"]["NUM_JOINTS"]), int(extra["FINAL_CONV_KERNEL"]))

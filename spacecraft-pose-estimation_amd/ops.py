@@ -251,8 +251,9 @@ def desc_from_cfg(cfg, dtype="bf16", mean=(0.485, 0.456, 0.406), std=(0.229, 0.2
     d.num_stages = 3
     for si, name in enumerate(("STAGE2", "STAGE3", "STAGE4")):
         s = extra[name]
-        if str(s["BLOCK"]) != "BASIC":
-            raise nat.NativeError("%s.BLOCK=%s: only BASIC stage blocks are supported (all shipped configs)" % (name, s["BLOCK"]))
+        if str(s["BLOCK"]) not in ("BASIC", "BOTTLENECK"):
+            raise nat.NativeError("%s.BLOCK=%s: stage blocks are BASIC or BOTTLENECK" % (name, s["BLOCK"]))
+        d.block[si] = 1 if str(s["BLOCK"]) == "BOTTLENECK" else 0
         d.num_modules[si] = int(s["NUM_MODULES"])
         d.num_branches[si] = int(s["NUM_BRANCHES"])
         for b in range(int(s["NUM_BRANCHES"])):

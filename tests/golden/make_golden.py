@@ -69,6 +69,25 @@ def hrnet_vectors():
     np.savez_compressed(os.path.join(HERE, "hrnet_reference_outputs.npz"), **out)
 
 
+def hrnet_bneck_vectors():
+    """STAGEk.BLOCK = BOTTLENECK through the reference module (pose_hrnet.py:266-269, :393-400): two small configurations."""
+    m = ref_pose_hrnet()
+    cases = {"bneck16_64": (R.bneck_cfg(c=16), 64, 2, 21, 22), "bneck32_64": (R.bneck_cfg(c=32, modules=(1, 2, 1), blocks=1), 64, 1, 23, 24)}
+    out = {}
+    for name, (cfg, size, n, wseed, xseed) in cases.items():
+        net = m.get_pose_net(cfg, False).eval()
+        sd = R.make_state_dict(cfg, seed=wseed)
+        net.load_state_dict(sd, strict=True)
+        x = torch.randn(n, 3, size, size, generator=torch.Generator().manual_seed(xseed))
+        with torch.no_grad():
+            y = net(x)
+        out[name + "/heatmaps"] = y.numpy()
+        out[name + "/meta"] = np.array([size, n, wseed, xseed], dtype=np.int64)
+        out[name + "/num_keys"] = np.array([len(sd)], dtype=np.int64)
+        print(name, tuple(y.shape), float(y.std()))
+    np.savez_compressed(os.path.join(HERE, "hrnet_bneck_reference_outputs.npz"), **out)
+
+
 class AttrDict(dict):
     """dict with attribute access, recursively (hrnet_cms reads cfg.MODEL.EXTRA as well as cfg['MODEL'])."""
 
@@ -197,6 +216,7 @@ def host_vectors():
 if __name__ == "__main__":
     torch.manual_seed(0)
     hrnet_vectors()
+    hrnet_bneck_vectors()
     cms_vectors()
     decode_vectors()
     host_vectors()

@@ -135,6 +135,36 @@ def test_forward_matches_reference_golden_heatmaps(gpu_ops):
             eng.close()
 
 
+BNECK_CONFIGS = {
+    "bneck16_64": (R.bneck_cfg(c=16), 64, 2, 21, 22, True),
+    "bneck32_64": (R.bneck_cfg(c=32, modules=(1, 2, 1), blocks=1), 64, 1, 23, 24, True),
+    "bneck64_64": (R.bneck_cfg(c=64, blocks=1), 64, 2, 25, 26, False),   # branch 0: 256 channels, planes 64 -> the fused layer1 kernel
+}
+
+
+@pytest.mark.parametrize("name", list(BNECK_CONFIGS))
+def test_forward_with_bottleneck_stage_blocks(gpu_ops, name):
+    """EXTRA.STAGEk.BLOCK = BOTTLENECK (blocks_dict, pose_hrnet.py:266-269; no shipped YAML uses it): HIP vs the oracle's storage
+    model and fp32 arithmetic, and -- where the reference module produced the vector -- directly vs tests/golden/hrnet_bneck_reference_outputs.npz."""
+    import os
+    import numpy as np
+    cfg, size, n, wseed, xseed, golden = BNECK_CONFIGS[name]
+    sd = R.make_state_dict(cfg, seed=wseed)
+    x = torch.randn(n, 3, size, size, generator=torch.Generator().manual_seed(xseed))
+    eng = gpu_ops.HrnetEngine(cfg, sd, dtype="bf16")
+    got = eng(x.cuda()).cpu()
+    with torch.no_grad():
+        emu = R.forward(sd, cfg, x, emulate="bf16")
+        ref = R.forward(sd, cfg, x)
+    print("%s: rel-L2 vs bf16-model oracle %.3e, vs fp32 %.3e" % (name, _rel(got, emu), _rel(got, ref)))
+    assert torch.isfinite(got).all() and _rel(got, emu) <= E_LOGIC_BF16 and _rel(got, ref) <= E_PREC_BF16
+    if golden:
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", "hrnet_bneck_reference_outputs.npz"))
+        assert _rel(got, torch.from_numpy(g[name + "/heatmaps"])) <= E_PREC_BF16
+    assert torch.equal(eng(x.cuda()).cpu(), got)          # deterministic
+    eng.close()
+
+
 def test_forward_f16_and_u8_input(gpu_ops):
     """fp16 MFMA variant (BASELINE config 5) and the fused ToTensor+Normalize uint8 path."""
     cfg = R.tiny_cfg()

@@ -161,6 +161,12 @@ def test_module_tree_state_dict_and_cpu_refusal(P):
         net(torch.zeros(1, 3, 64, 64))                                  # fails loudly, never an eager fallback
     with pytest.raises(ValueError):
         P.pose_hrnet.get_pose_net(cfg, True)
+    # STAGEk.BLOCK = BOTTLENECK (blocks_dict, pose_hrnet.py:266-269): same keys, in the same order, as the reference module registers
+    bcfg = R.bneck_cfg(c=16)
+    bsd = R.make_state_dict(bcfg, seed=2)
+    bnet = P.pose_hrnet.get_pose_net(bcfg, False).eval()
+    assert list(bnet.state_dict().keys()) == list(bsd.keys())
+    bnet.load_state_dict(bsd, strict=True)
 
 
 def test_synthetic_checkpoint_equals_oracle_recipe(P):
