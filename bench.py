@@ -82,9 +82,11 @@ def parse():
     ap.add_argument("--events", action="store_true",
                     help="BASELINE configs[4] side line: HRNet-W32 256x256, f16 MFMA kernels, mixed RGB + event-frame batch")
     ap.add_argument("--graph", type=int, default=-1,
-                    help="1: un-profiled steps replay the forward from a hipGraph with concurrent branches (scpose_hrnet_graph_*); "
-                         "0: eager launches; default: 1 for batches <= 128 (W32 batch 64: -24 %%, W48 batch 128: -2 %%), 0 above "
-                         "(at batch 256 every kernel fills the chip and concurrent lanes only contend: measured +0.4 ms)")
+                    help="un-profiled steps replay the forward from a hipGraph (scpose_hrnet_graph_*): 1 = every independent group of ops "
+                         "on concurrent lanes (branches of a module, fuse rows, transition convolutions), 2 = only the fuse rows and "
+                         "transition convolutions (short HBM-bound launches) side by side, the branches one after the other; 0: eager "
+                         "launches; default: 1 for batches <= 128 (W32 batch 64: -19 %%), 2 above (W48 batch 256: -0.3 ms; the "
+                         "MFMA-bound branch kernels each fill the chip and only contend when run side by side)")
     ap.add_argument("--chained", action="store_true",
                     help="feed the PnP stage with the decoded (random-weight) keypoints instead of synthetic ones")
     return ap.parse_args()
@@ -173,7 +175,7 @@ def main():
     eng = ops.HrnetEngine(cfg, sd, dtype=args.dtype, device=dev)
     B = args.batch
     if args.graph < 0:
-        args.graph = 1 if B <= 128 else 0
+        args.graph = 1 if B <= 128 else 2
     hh = image // 4
 
     # ---- synthetic inputs, resident in HBM before the timed region (shard = rank's slice) ----
@@ -195,7 +197,7 @@ def main():
     host_buf = [torch.empty((world * B, 13), dtype=torch.float64).pin_memory() for _ in range(2)] if rank == 0 else None
     side = torch.cuda.Stream(device=dev)
     # captured forward, one graph per output buffer (same kernels, same results; scpose.h: scpose_hrnet_graph_*)
-    graphs = [eng.capture(frames, out=heat[k], concurrent=True) for k in range(2)] if args.graph else None
+    graphs = [eng.capture(frames, out=heat[k], concurrent=args.graph) for k in range(2)] if args.graph else None
     done = [None, None]
     counter = [0]
 
@@ -344,7 +346,7 @@ def main():
                            "; %d frames per step frame-sharded over %d GPUs%s" % (world * B, world, " = BASELINE configs[3]" if world * B == 2048 and world == 8 else "") if world > 1 else ""),
                        "frames_per_step": world * B, "parallelism": "frame-sharded x%d, all-gather of (R,t,status); PnP/gather/D2H of step i overlap the forward of step i+1" % world,
                        "pnp_input": "decoded" if args.chained else "synthetic projected landmarks, 1 px noise, 10% outliers",
-                       "forward": ("hipGraph replay with concurrent branches (%d nodes)" % graphs[0].nodes) if graphs else "eager launches",
+                       "forward": ("hipGraph replay, %s on concurrent lanes (%d nodes)" % ("branches, fuse rows and transitions" if args.graph == 1 else "fuse rows and transitions", graphs[0].nodes)) if graphs else "eager launches",
                        "roofline_pass": "%d eager steps with per-launch HIP events, after the timed region" % prof_steps,
                        "launches_per_forward": st["launches"], "gflop_per_frame": round(st["flops_per_frame"] / 1e9, 3),
                        "act_mbytes_per_frame": round(st["act_bytes_per_frame"] / 1e6, 2)},

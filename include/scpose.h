@@ -128,7 +128,10 @@ int32_t scpose_hrnet_forward(scpose_hrnet_t h, const void* in, int32_t in_fmt, i
  * ~280 kernels disappears, and with concurrent != 0 the ops that do not depend on each other -- the branches of a
  * HighResolutionModule (pose_hrnet.py:247-253), the rows of its fuse layer (:254-265), the transition convolutions
  * (:333-372) -- are recorded on parallel graph branches, so that the small-grid kernels of the low-resolution
- * branches fill the CUs the high-resolution ones leave idle.  Results are bit-identical to scpose_hrnet_forward.
+ * branches fill the CUs the high-resolution ones leave idle.  concurrent == 2 puts only the fuse rows and the transition
+ * convolutions side by side (many short HBM-bound launches) and runs the branches one after the other: the choice for
+ * batches whose branch kernels each fill the chip (W48 384x384 batch 256: -0.3 ms; with concurrent == 1 the MFMA-bound
+ * branch kernels contend and the forward gets slower).  Results are bit-identical to scpose_hrnet_forward.
  * The concurrent memory plan keeps a tensor alive until every op that may run beside its last reader has finished:
  * size the workspace with scpose_hrnet_graph_workspace_bytes (>= scpose_hrnet_workspace_bytes).
  * create runs one eager forward on an internal stream (it needs valid input in `in`) and synchronises it; launch

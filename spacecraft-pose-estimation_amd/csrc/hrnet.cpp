@@ -91,6 +91,7 @@ struct Op {
   // (the branches of a HighResolutionModule, pose_hrnet.py:247-253; the fuse rows :254-265; the transition convs
   // :333-372); epochs are separated by a join of all lanes.  The serial forward ignores both.
   int epoch, lane;
+  int par_kind;      // what the epoch's lanes are: 0 serial, 1 the branches of a module, 2 fuse rows, 3 transition convolutions
 };
 
 }  // namespace scpose
@@ -100,6 +101,7 @@ struct scpose_hrnet_lanes {
   hipStream_t side[3] = {nullptr, nullptr, nullptr};   // lanes 1..3 (lane 0 is the stream the forward is launched on)
   std::vector<hipEvent_t> fork;                         // one per parallel epoch, recorded on lane 0
   std::vector<hipEvent_t> join;                         // three per parallel epoch, recorded on lanes 1..3
+  unsigned kinds = 0xe;                                 // bit k: epochs of Op::par_kind k run on lanes (1 branches, 2 fuse rows, 3 transitions)
 };
 
 struct scpose_hrnet {
@@ -137,12 +139,13 @@ struct Builder {
   int32_t status = SCPOSE_OK;
   int epoch = 0, lane = 0;        // stamped on every op pushed (see Op::epoch)
   bool serial = true;             // true: every op opens its own epoch (stem, layer1, heads)
+  int par_kind = 0;
   void push(Op op) {
     if (serial) ++epoch;
-    op.epoch = epoch; op.lane = serial ? 0 : lane;
+    op.epoch = epoch; op.lane = serial ? 0 : lane; op.par_kind = serial ? 0 : par_kind;
     net->ops.push_back(op);
   }
-  void parallel_begin() { ++epoch; serial = false; lane = 0; }   // the ops pushed until parallel_end() share one epoch
+  void parallel_begin(int kind) { ++epoch; serial = false; lane = 0; par_kind = kind; }   // the ops pushed until parallel_end() share one epoch
   void parallel_end() { serial = true; lane = 0; }
 
   int new_tensor(int C, int ds) {
@@ -405,7 +408,7 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
     if (bneck_stage) for (int& c : cur) c *= 4;          // num_channels * block.expansion (pose_hrnet.py:393-400)
     const std::string tname = fmt("transition%d", si + 1);
     std::vector<int> xs;
-    B.parallel_begin();   // transition convs: independent of each other (lane = branch they create)
+    B.parallel_begin(3);   // transition convs: independent of each other (lane = branch they create)
     for (int i = 0; i < nb; ++i) {
       B.lane = i;
       if (i < (int)pre.size()) {
@@ -426,7 +429,7 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
     for (int m = 0; m < d.num_modules[si]; ++m) {
       const bool multi = d.head != SCPOSE_HEAD_FINAL_LAYER || !(si == 2 && m == d.num_modules[si] - 1);
       const std::string mp = fmt("stage%d.%d", si + 2, m);
-      B.parallel_begin();   // the branches of the module: one lane each
+      B.parallel_begin(1);   // the branches of the module: one lane each
       for (int b = 0; b < nb; ++b) {
         B.lane = b;
         int t = xs[b];
@@ -438,7 +441,7 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
       }
       B.parallel_end();
       std::vector<int> outs;
-      B.parallel_begin();   // the fuse rows: row i (its up / down paths, then its sum) on lane i
+      B.parallel_begin(2);   // the fuse rows: row i (its up / down paths, then its sum) on lane i
       for (int i = 0; i < (multi ? nb : 1); ++i) {
         B.lane = i;
         std::vector<int> terms, shifts;
@@ -613,7 +616,8 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
       { const int32_t rc = join_lanes(); if (rc != SCPOSE_OK) return rc; }
       cur_epoch = op.epoch;
       unsigned used = 0;
-      for (size_t k = oi; k < net->ops.size() && net->ops[k].epoch == cur_epoch; ++k) used |= 1u << net->ops[k].lane;
+      for (size_t k = oi; k < net->ops.size() && net->ops[k].epoch == cur_epoch; ++k)
+        if (lanes->kinds & (1u << net->ops[k].par_kind)) used |= 1u << net->ops[k].lane;
       used &= ~1u;
       if (used) {
         ++par_index;
@@ -624,7 +628,7 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
         open_lanes = used;
       }
     }
-    st = (lanes && op.lane > 0) ? lanes->side[op.lane - 1] : st0;
+    st = (lanes && op.lane > 0 && (lanes->kinds & (1u << op.par_kind))) ? lanes->side[op.lane - 1] : st0;
     if (profile) SCP_CHECK_HIP(hipEventRecord(net->events[opi], st));
     ++opi;
     int32_t rc = SCPOSE_OK;
@@ -899,6 +903,7 @@ extern "C" int32_t scpose_hrnet_graph_create(scpose_hrnet_t h, const void* in, i
 #define GC(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return fail(SCPOSE_E_HIP); } } while (0)
   GC(hipStreamCreateWithFlags(&g->cap, hipStreamNonBlocking));
   if (concurrent) {
+    g->lanes.kinds = concurrent == 2 ? 0xcu : 0xeu;   // 2: only the fuse rows and transition convolutions run side by side
     int npar = 0, last = -1;
     for (const Op& op : h->ops) if (op.lane > 0 && op.epoch != last) { ++npar; last = op.epoch; }
     for (auto& st : g->lanes.side) GC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));

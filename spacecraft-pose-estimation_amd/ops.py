@@ -340,8 +340,9 @@ class HrnetEngine:
 
     def capture(self, x, out=None, concurrent=True):
         """Record the forward of the input BUFFER x (uint8 NHWC or float32 NCHW, fixed shape) into a hipGraph and return
-        an HrnetGraph: refill x in place (x.copy_(...)), call .replay(), read .out.  concurrent=True records the
-        independent ops (module branches, fuse rows, transition convs) on parallel graph branches."""
+        an HrnetGraph: refill x in place (x.copy_(...)), call .replay(), read .out.  concurrent=True (1) records the
+        independent ops (module branches, fuse rows, transition convs) on parallel graph branches; concurrent=2 only the
+        fuse rows and transition convs (large batches, whose branch kernels each fill the chip); 0 / False none."""
         _need_cuda(x)
         if not x.is_contiguous():
             raise nat.NativeError("capture: the input buffer must be contiguous (it is bound by address)")
@@ -441,7 +442,7 @@ class HrnetGraph:
         g = c_void_p()
         with torch.cuda.device(x.device):
             nat.check(nat.lib().scpose_hrnet_graph_create(engine._h, _ptr(x), fmt, n, h, w, _ptr(out), _ptr(self._ws), self._ws.numel(),
-                                                          int(bool(concurrent)), ctypes.byref(g)), "hrnet_graph_create")
+                                                          int(concurrent), ctypes.byref(g)), "hrnet_graph_create")
         self._g = g
         k = c_int32()
         nat.check(nat.lib().scpose_hrnet_graph_nodes(self._g, ctypes.byref(k)), "hrnet_graph_nodes")

@@ -321,7 +321,7 @@ def test_captured_forward_is_bit_identical(gpu_ops, name):
     xa = torch.randint(0, 256, (n, size, size, 3), generator=g, dtype=torch.uint8).cuda()
     xb = torch.randint(0, 256, (n, size, size, 3), generator=g, dtype=torch.uint8).cuda()
     ya, yb = eng(xa).clone(), eng(xb).clone()
-    for concurrent in (False, True):
+    for concurrent in (False, True, 2):      # 2: only the fuse rows / transition convolutions on concurrent lanes
         buf = xa.clone()
         gr = eng.capture(buf, concurrent=concurrent)
         assert gr.nodes >= eng.stats(size, size)["launches"]

@@ -29,9 +29,9 @@ def bench(fn, iters=20):
 ref = eng(x).clone()
 print("%s N=%d %dx%d %s" % (which, n, size, size, dtype))
 print("  eager               %.3f ms" % bench(lambda: eng(x)))
-for conc in (False, True):
+for conc in (0, 1, 2):     # 0 serial, 1 every parallel epoch on lanes, 2 only the fuse rows and transition convolutions
     g = eng.capture(x, concurrent=conc)
     ms = bench(g.replay)
     print("  graph%s %.3f ms  (%d nodes, bit-identical: %s, workspace %.2f GB vs %.2f GB)" % (
-        " + concurrent" if conc else "             ", ms, g.nodes, torch.equal(g.replay(), ref), g._ws.numel() / 1e9, eng.workspace_bytes(n, size, size) / 1e9))
+        ("             ", " + concurrent", " + fuse lanes")[conc], ms, g.nodes, torch.equal(g.replay(), ref), g._ws.numel() / 1e9, eng.workspace_bytes(n, size, size) / 1e9))
     g.close()
