@@ -427,7 +427,9 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
               }
             }
           }
-          asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA's result visible to the VALU
+          // last MFMA's result visible to the VALU -- only the tile's last stage is followed by VALU reads of the accumulators
+          // (the epilogue); between stages the next MFMA takes its accumulator as SrcC, which the hardware interlocks
+          if (last) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
           for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -447,13 +449,26 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
           auto fetch = [&](int b, int buf) {
 #pragma unroll
             for (int n = 0; n < NR; ++n) {
-              ra[buf][n] = make_uint2(0u, 0u); rb[buf][n] = make_uint2(0u, 0u);
-              if (p.res) {
-                ra[buf][n] = *reinterpret_cast<const uint2*>(slot_a(b, n));
-                rb[buf][n] = *reinterpret_cast<const uint2*>(slot_a(b, n) + PXCAP * 16);
-              }
+              ra[buf][n] = *reinterpret_cast<const uint2*>(slot_a(b, n));
+              rb[buf][n] = *reinterpret_cast<const uint2*>(slot_a(b, n) + PXCAP * 16);
             }
           };
+          if (!p.res) {   // no residual (conv1 of a BasicBlock, transitions): round, ReLU, write -- a third of the VALU work of the path below
+#pragma unroll
+            for (int b = 0; b < 2 * MR; ++b) {
+              const int m = b >> 1, g = b & 1;
+#pragma unroll
+              for (int n = 0; n < NR; ++n) {
+                uint2 oa, ob;
+                oa.x = relu2_16(pack2<T>(acc[m][n][8 * g + 0], acc[m][n][8 * g + 1]), relu_floor); oa.y = relu2_16(pack2<T>(acc[m][n][8 * g + 2], acc[m][n][8 * g + 3]), relu_floor);
+                ob.x = relu2_16(pack2<T>(acc[m][n][8 * g + 4], acc[m][n][8 * g + 5]), relu_floor); ob.y = relu2_16(pack2<T>(acc[m][n][8 * g + 6], acc[m][n][8 * g + 7]), relu_floor);
+                if (pvalid[n]) {
+                  *reinterpret_cast<uint2*>(slot_a(b, n)) = oa;
+                  *reinterpret_cast<uint2*>(slot_a(b, n) + PXCAP * 16) = ob;
+                }
+              }
+            }
+          } else {
           fetch(0, 0);
 #pragma unroll
           for (int b = 0; b < 2 * MR; ++b) {
@@ -475,6 +490,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
                 *reinterpret_cast<uint2*>(slot_a(b, n) + PXCAP * 16) = ob;
               }
             }
+          }
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
