@@ -241,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
 #pragma unroll
     for (int m = 0; m < MREP; ++m)
 #pragma unroll
-      for (int n = 0; n < 3; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int n = 0; n < 3; ++n) acc[m][n] = f32x4{bs1[m].x, bs1[m].y, bs1[m].z, bs1[m].w};   // accumulators start at the bias of their rows
     kloop(std::integral_constant<int, 3>{}, w1l, xl, kA, offA, acc);
     const unsigned long long t1 = now();
     // residual slots of this lane's output pixel (the centre of the input tile), kept in registers until the end
@@ -255,10 +255,9 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
       const bool inimg = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
 #pragma unroll
       for (int m = 0; m < MREP; ++m) {
-        const float4 bs = bs1[m];
         uint2 o;
-        o.x = relu2_16(pack2<T>(acc[m][n][0] + bs.x, acc[m][n][1] + bs.y), 0u);
-        o.y = relu2_16(pack2<T>(acc[m][n][2] + bs.z, acc[m][n][3] + bs.w), 0u);
+        o.x = relu2_16(pack2<T>(acc[m][n][0], acc[m][n][1]), 0u);
+        o.y = relu2_16(pack2<T>(acc[m][n][2], acc[m][n][3]), 0u);
         if (!inimg) o = make_uint2(0u, 0u);              // conv2's zero padding
         if (okA[n])
           *reinterpret_cast<uint2*>(ml + (2 * m + psel) * MS + ((n * 8 + wave) * 16 + r) * 16 + 8 * (q >> 1)) = o;
@@ -272,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
 
     // ---- C: conv2 -> output ----
 #pragma unroll
-    for (int m = 0; m < MREP; ++m) { acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int m = 0; m < MREP; ++m) { acc[m][0] = f32x4{bs2[m].x, bs2[m].y, bs2[m].z, bs2[m].w}; acc[m][1] = acc[m][0]; }
     const unsigned long long t4 = now();
     kloop(std::integral_constant<int, 2>{}, w2l, ml, kB, offB, acc);
     const unsigned long long t5 = now();
@@ -280,12 +279,11 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
     const bool store_ok = oy < p.H && ox < p.W;
 #pragma unroll
     for (int m = 0; m < MREP; ++m) {
-      const float4 bs = bs2[m];
       uint32_t a[4], b[4];
-      a[0] = __float_as_uint(acc[m][0][0] + bs.x); a[1] = __float_as_uint(acc[m][0][1] + bs.y);
-      a[2] = __float_as_uint(acc[m][0][2] + bs.z); a[3] = __float_as_uint(acc[m][0][3] + bs.w);
-      b[0] = __float_as_uint(acc[m][1][0] + bs.x); b[1] = __float_as_uint(acc[m][1][1] + bs.y);
-      b[2] = __float_as_uint(acc[m][1][2] + bs.z); b[3] = __float_as_uint(acc[m][1][3] + bs.w);
+      a[0] = __float_as_uint(acc[m][0][0]); a[1] = __float_as_uint(acc[m][0][1]);
+      a[2] = __float_as_uint(acc[m][0][2]); a[3] = __float_as_uint(acc[m][0][3]);
+      b[0] = __float_as_uint(acc[m][1][0]); b[1] = __float_as_uint(acc[m][1][1]);
+      b[2] = __float_as_uint(acc[m][1][2]); b[3] = __float_as_uint(acc[m][1][3]);
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const auto sw = __builtin_amdgcn_permlane32_swap(a[jj], b[jj], false, false);

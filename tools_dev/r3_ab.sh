@@ -1,11 +1,6 @@
 cd $GRAFT_REPO_ROOT
-python3 -m pytest tests/test_gpu_conv.py -m gpu -x -q 2>&1 | tail -2
-for rep in 1 2 3; do
-for cfg in "96 96 3 1 48 256 nores relu" "192 192 3 1 24 256 nores relu"; do
-echo -n "base: "; SCPOSE_DEV=1 SCPOSE_LIB=tools_dev/ab/libscpose_base.so python3 tools_dev/time_conv.py $cfg 2>&1 | tail -1
-echo -n "new:  "; python3 tools_dev/time_conv.py $cfg 2>&1 | tail -1
-done; done
-for rep in 1 2 3; do
-echo -n "base: "; SCPOSE_DEV=1 SCPOSE_LIB=tools_dev/ab/libscpose_base.so MODES=fwd python3 tools_dev/step_breakdown.py 2>&1 | tail -2 | tr '\n' ' '; echo
-echo -n "new:  "; MODES=fwd python3 tools_dev/step_breakdown.py 2>&1 | tail -2 | tr '\n' ' '; echo
+export ITERS=300
+for rep in 1 2 3 4 5; do
+echo -n "base: "; SCPOSE_DEV=1 SCPOSE_LIB=tools_dev/ab/libscpose_base.so python3 tools_dev/time_block.py 48 96 256 relu 2>&1 | tail -1
+echo -n "new:  "; python3 tools_dev/time_block.py 48 96 256 relu 2>&1 | tail -1
 done

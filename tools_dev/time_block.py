@@ -16,9 +16,10 @@ for _ in range(3): y = ops.basic_block(c1, c2, x)
 torch.cuda.synchronize()
 st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 st.record()
-for _ in range(20): y = ops.basic_block(c1, c2, x)
+IT = int(os.environ.get("ITERS", "20"))
+for _ in range(IT): y = ops.basic_block(c1, c2, x)
 en.record(); torch.cuda.synchronize()
-us = st.elapsed_time(en) / 20 * 1e3
+us = st.elapsed_time(en) / IT * 1e3
 if int(os.environ.get("SCPOSE_DBG", "0")) & 8:
     import ctypes
     ctypes.CDLL(ops.nat.LIB_PATH).scpose_dbg_dump()

@@ -18,7 +18,7 @@ for _ in range(3): y = conv(x, residual=r, relu=True)
 torch.cuda.synchronize()
 st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 st.record()
-it = 20
+it = int(os.environ.get("ITERS", "20"))
 for _ in range(it): y = conv(x, residual=r, relu=True)
 en.record(); torch.cuda.synchronize()
 us = st.elapsed_time(en) / it * 1e3
