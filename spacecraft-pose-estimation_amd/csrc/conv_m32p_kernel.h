@@ -313,12 +313,10 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
     // consumers: LDS reads, MFMAs, epilogue into the retire buffer
     // =====================================================================================
     int pixoff[NR];
-    bool pvalid[NR];
 #pragma unroll
     for (int n = 0; n < NR; ++n) {
       int ps, py, px;
       pixel_of((wave * NR + n) * 32 + r, ps, py, px);
-      pvalid[n] = ps >= 0;
       pixoff[n] = ps >= 0 ? (ps * HP + (py * STRIDE) * p.halo_w + px * STRIDE) * 16 : 0;
     }
     f32x16 acc[MR][NR];
@@ -462,10 +460,8 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
                 uint2 oa, ob;
                 oa.x = relu2_16(pack2<T>(acc[m][n][8 * g + 0], acc[m][n][8 * g + 1]), relu_floor); oa.y = relu2_16(pack2<T>(acc[m][n][8 * g + 2], acc[m][n][8 * g + 3]), relu_floor);
                 ob.x = relu2_16(pack2<T>(acc[m][n][8 * g + 4], acc[m][n][8 * g + 5]), relu_floor); ob.y = relu2_16(pack2<T>(acc[m][n][8 * g + 6], acc[m][n][8 * g + 7]), relu_floor);
-                if (pvalid[n]) {
-                  *reinterpret_cast<uint2*>(slot_a(b, n)) = oa;
-                  *reinterpret_cast<uint2*>(slot_a(b, n) + PXCAP * 16) = ob;
-                }
+                *reinterpret_cast<uint2*>(slot_a(b, n)) = oa;          // padding pixels (no tile pixel behind this lane) write their own
+                *reinterpret_cast<uint2*>(slot_a(b, n) + PXCAP * 16) = ob;   // slots too: the producers never store those (BUF_OOB / ~0 offsets)
               }
             }
           } else {
@@ -485,10 +481,8 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
               uint2 oa, ob;
               oa.x = relu2_16(pack2<T>(v[0], v[1]), relu_floor); oa.y = relu2_16(pack2<T>(v[2], v[3]), relu_floor);
               ob.x = relu2_16(pack2<T>(v[4], v[5]), relu_floor); ob.y = relu2_16(pack2<T>(v[6], v[7]), relu_floor);
-              if (pvalid[n]) {
-                *reinterpret_cast<uint2*>(slot_a(b, n)) = oa;
-                *reinterpret_cast<uint2*>(slot_a(b, n) + PXCAP * 16) = ob;
-              }
+              *reinterpret_cast<uint2*>(slot_a(b, n)) = oa;            // (padding pixels: see above)
+              *reinterpret_cast<uint2*>(slot_a(b, n) + PXCAP * 16) = ob;
             }
           }
           }
