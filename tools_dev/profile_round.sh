@@ -28,7 +28,10 @@ run_passes() {   # <name> <passes> <bench args...>
     rocprofv3 --pmc $C -d $d/$p -o p --output-format csv -- $B > /dev/null 2> $d/$p.err
   done
 }
-run_passes w48_b256 "fetch write mfma ldsa ldsb"
+# headline workload: eager launches (--graph 0) under the profiler -- the same kernels as the captured forward bench.py replays by
+# default, but dispatched in launch order and one at a time, so that a dispatch can be attributed to its kernel class and its
+# duration is its own (in the captured forward the fuse rows run side by side and stretch each other)
+run_passes w48_b256 "fetch write mfma ldsa ldsb" --graph 0
 run_passes w32_b64 "fetch write mfma" --model w32 --batch 64
 run_passes events_b64 "fetch write mfma" --events --batch 64
 cd $root
