@@ -330,22 +330,6 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
       for (int c = 0; c < p.nchunks; ++c, ++wc) {
         const unsigned long long t0 = now();
         const bool last = c == p.nchunks - 1;
-        if (c == 0) {   // accumulators start at the bias of their rows: row(j) = 8*(j/4) + 4*half + j%4
-#pragma unroll
-          for (int m = 0; m < MR; ++m) {
-            const float* bp = bias_l + mb * MT + m * 32 + 4 * half;
-            float bv[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * q);
-              bv[4 * q] = b4.x; bv[4 * q + 1] = b4.y; bv[4 * q + 2] = b4.z; bv[4 * q + 3] = b4.w;
-            }
-#pragma unroll
-            for (int n = 0; n < NR; ++n)
-#pragma unroll
-              for (int j = 0; j < 16; ++j) acc[m][n][j] = bv[j];
-          }
-        }
         {  // MFMA loop: plane pairs x KK taps, taps unrolled so that every LDS offset is an immediate
           const int npp = SCP_DBG(p, 1) ? 0 : (SCP_DBG(p, 256) ? 2 : 1) * (p.cp >> 1);   // dbg 256: every stage's MFMA loop twice (timing experiment, wrong results)
           const uint32_t xl = (uint32_t)(size_t)(xl0 + xb * p.lds_x) + half * p.plane_stride;
@@ -383,12 +367,30 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
                 for (int m = 0; m < MR; ++m) mfma32_acc<T, false>(acc[m][n], a[m], b[n]);
           };
           if (npp > 0) {
+            set_row(0, 0);
+            issue(std::integral_constant<int, 0>{}, a0, b0);     // the first fragments fly while the accumulators are initialised
+          }
+          if (c == 0) {   // accumulators start at the bias of their rows: row(j) = 8*(j/4) + 4*half + j%4
+  #pragma unroll
+            for (int m = 0; m < MR; ++m) {
+              const float* bp = bias_l + mb * MT + m * 32 + 4 * half;
+              float bv[16];
+  #pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * q);
+                bv[4 * q] = b4.x; bv[4 * q + 1] = b4.y; bv[4 * q + 2] = b4.z; bv[4 * q + 3] = b4.w;
+              }
+  #pragma unroll
+              for (int n = 0; n < NR; ++n)
+  #pragma unroll
+                for (int j = 0; j < 16; ++j) acc[m][n][j] = bv[j];
+            }
+          }
+          if (npp > 0) {
 #pragma unroll
             for (int m = 0; m < MR; ++m)
 #pragma unroll
               for (int n = 0; n < NR; ++n) mfma_input_fence<false>(acc[m][n]);
-            set_row(0, 0);
-            issue(std::integral_constant<int, 0>{}, a0, b0);
             landed(a0, b0);
           }
           for (int pp = 0; pp < npp; ++pp) {
