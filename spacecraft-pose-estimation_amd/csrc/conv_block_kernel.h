@@ -274,6 +274,11 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
     for (int m = 0; m < MREP; ++m) { acc[m][0] = f32x4{bs2[m].x, bs2[m].y, bs2[m].z, bs2[m].w}; acc[m][1] = acc[m][0]; }
     const unsigned long long t4 = now();
     kloop(std::integral_constant<int, 2>{}, w2l, ml, kB, offB, acc);
+    // The next input tile (requested after the first barrier, a whole conv2 ago) must have landed before the barrier that ends the
+    // tile.  Wait for it HERE, in front of this tile's output stores: a wave's vector-memory operations are counted together and stores
+    // may retire before older loads, so the only safe wait is vmcnt(0) -- and behind the stores that would be a wait for their
+    // acknowledgement (hundreds of cycles per tile) instead of for a DMA that has long arrived.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long t5 = now();
     const int oy = oy0 + opy, ox = ox0 + opx;
     const bool store_ok = oy < p.H && ox < p.W;
@@ -308,11 +313,9 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
         *reinterpret_cast<u32x4*>(static_cast<char*>(p.out) + (((size_t)img * PLANES + 2 * m + psel) * HW + (size_t)oy * p.W + ox) * 16) = ov;
     }
     const unsigned long long t6 = now();
-    // next input tile landed (this wave's share).  (A counted wait that skips this tile's output stores -- they are younger
-    // than the DMA -- was tried and is WRONG: stores may retire before older loads, so "at most MREP outstanding" does not
-    // imply that the DMA has landed; it showed up as sporadic infinities in the W48 384x384 parity test.  Deferring the
-    // conv2 epilogue of waves 4-7 into the next tile (a stagger between the two waves of a SIMD) measured no gain either.)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // (the next input tile has landed: waited for in front of the stores, above.  Deferring the conv2 epilogue of waves 4-7 into the
+    // next tile -- a stagger between the two waves of a SIMD -- measured no gain.)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                   // ... and the intermediate tile is free again
     if (SCP_DBG_BUF(p)) {   // [conv1 loop][conv1 epilogue][barrier][DMA issue][conv2 loop][conv2 epilogue + end wait/barrier]
       const unsigned long long t7 = now();
