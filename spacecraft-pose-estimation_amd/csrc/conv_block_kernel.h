@@ -242,7 +242,10 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
     for (int m = 0; m < MREP; ++m)
 #pragma unroll
       for (int n = 0; n < 3; ++n) acc[m][n] = f32x4{bs1[m].x, bs1[m].y, bs1[m].z, bs1[m].w};   // accumulators start at the bias of their rows
-    kloop(std::integral_constant<int, 3>{}, w1l, xl, kA, offA, acc);
+    // 21 columns over 8 waves: waves 0-4 have a third column, waves 5-7 do not (their third accumulators are never written out);
+    // they run the two-column loop instead of spending 42 MFMAs per tile on a column nobody reads
+    if (wave < 5) kloop(std::integral_constant<int, 3>{}, w1l, xl, kA, offA, acc);
+    else kloop(std::integral_constant<int, 2>{}, w1l, xl, kA, offA, acc);
     const unsigned long long t1 = now();
     // residual slots of this lane's output pixel (the centre of the input tile), kept in registers until the end
     u32x4 resv[MREP];
