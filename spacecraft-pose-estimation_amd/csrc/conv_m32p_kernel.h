@@ -320,6 +320,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
       pixoff[n] = ps >= 0 ? (ps * HP + (py * STRIDE) * p.halo_w + px * STRIDE) * 16 : 0;
     }
     f32x16 acc[MR][NR];
+    const bool wave_idle = wave * NR * 32 >= P;   // wave-uniform
     int wc = 0, xb = 0;
     __syncthreads();   // matches the producers' prologue barrier
 
@@ -331,7 +332,9 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
         const unsigned long long t0 = now();
         const bool last = c == p.nchunks - 1;
         {  // MFMA loop: plane pairs x KK taps, taps unrolled so that every LDS offset is an immediate
-          const int npp = SCP_DBG(p, 1) ? 0 : (SCP_DBG(p, 256) ? 2 : 1) * (p.cp >> 1);   // dbg 256: every stage's MFMA loop twice (timing experiment, wrong results)
+          // a consumer wave whose pixel slots all lie past the work item's pixels (two 12 x 12 images fill 288 of 384 slots: all of
+          // wave 3's) has nothing to compute: it only keeps the barriers
+          const int npp = (SCP_DBG(p, 1) || wave_idle) ? 0 : (SCP_DBG(p, 256) ? 2 : 1) * (p.cp >> 1);   // dbg 256: every stage's MFMA loop twice (timing experiment, wrong results)
           const uint32_t xl = (uint32_t)(size_t)(xl0 + xb * p.lds_x) + half * p.plane_stride;
           const int cidx = c;
           uint32_t wa = (uint32_t)(size_t)(wl0 + (w_resident ? cidx : (wc & 1)) * p.lds_w) + (half * MT + r) * 16;
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
             for (int n = 0; n < NR; ++n) mfma_result_fence<false>(acc[m][n]);
         }
         const unsigned long long t1 = now();
-        if (last) {  // retire: RO <- ReLU(acc + residual), in place.  Before any lane exchange a lane holds
+        if (last && !wave_idle) {  // retire: RO <- ReLU(acc + residual), in place.  Before any lane exchange a lane holds
                      // channels [4*half, 4*half+4) of the two planes 2g and 2g+1 of its pixel: it reads and
                      // writes those two 8-byte half-slots directly, so no permlane and no bias add are needed.
           // residual half-slots are read one (m, g) batch ahead of the batch being finalised: the
