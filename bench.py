@@ -239,8 +239,9 @@ def main():
             done[k] = torch.cuda.Event()
             done[k].record(side)
         if profile:   # per-launch HIP events of this forward (blocks the host until the forward has finished)
-            for rec in eng.profile_read():
-                key = (rec["kind"], rec["a"], rec["cin"], rec["cout"])
+            recs = eng.profile_read()
+            for rec, cls in zip(recs, eng.kernel_classes(recs)):
+                key = (rec["kind"], rec["a"], rec["cin"], rec["cout"], cls)
                 e = prof_ms.setdefault(key, [0.0, 0, 0.0, 0.0])
                 e[0] += rec["ms"]; e[1] += 1; e[2] += rec["flops_per_frame"] * B; e[3] += rec["bytes_per_frame"] * B
         return host_buf[k] if rank == 0 else None
@@ -288,7 +289,7 @@ def main():
         def describe(key, ms, calls, flops, byts):
             """One kernel class against ITS roofline.  flops / byts: algorithmic work of the profiled launches (bytes =
             what the launch itself must move: a fused BasicBlock counts its input once + its output once)."""
-            kind, a, cin, cout = key
+            kind, a, cin, cout, cls = key
             name = {0: "stem_conv1_kernel (3->64 3x3 s2, f32 VALU)", 2: "fuse_sum_kernel (%d terms, C=%d)" % (a, cin),
                     3: "conv_block_kernel: fused BasicBlock 2 x (3x3 s1 %d->%d), input read once + output written once" % (cin, cout),
                     4: "head_gather_kernel (k%d s%d, C=%d)" % (a // 10, a % 10, cin),
@@ -309,11 +310,11 @@ def main():
             # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes; summary committed under
             # profiles/): only reported when it was measured on exactly these kernel sources, batch, dtype and image
             r["traffic"] = None
-            tr = traffic_db.get("%d:%d:%d:%d" % key)
+            tr = traffic_db.get(cls)
             if tr and tr.get("src_sha") == sha and tr.get("batch") == B and tr.get("dtype") == args.dtype and tr.get("image") == image:
                 r["traffic"] = tr["fetch_bytes"] + tr["write_bytes"]
                 r["traffic_unit"] = "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE), %s" % tr["kernel"]
-            r.update({"class": "%d:%d:%d:%d" % key, "kernel": name, "launches": calls, "avg_launch_us": round(ms / calls * 1e3, 2),
+            r.update({"class": cls, "kernel": name, "launches": calls, "avg_launch_us": round(ms / calls * 1e3, 2),
                       "share_of_forward": round(ms / total_ms, 4), "algorithmic_bytes_per_launch": byts / calls,
                       "algorithmic_flops_per_launch": flops / calls, "flop_per_byte": round(ai, 1),
                       "also_tflops": round(flops / sec / 1e12, 2), "also_gbs": round(byts / sec / 1e9, 1)})

@@ -69,7 +69,8 @@ struct BneckLaunch {
   uint32_t in_bytes, out_bytes;
   int32_t N, H, W;
   int32_t tiles_x, tiles_y, tiles_total, grid;
-  uint32_t* sched;               // dynamic tile queue (conv_device.h: tile_claim)
+  uint32_t* sched;               // dynamic tile queue (conv_device.h: tile_claim_xcd)
+  int32_t xcd_local;
   unsigned long long* dbg_buf;   // development (SCPOSE_BNECK_DBG=1): cycles per phase and wave
 };
 
@@ -132,7 +133,9 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
   char* w2ll = reinterpret_cast<char*>(tq) + 16;
   for (int o = tid * 16; o < W2L * 4 * 1024; o += 512 * 16)
     *reinterpret_cast<u32x4*>(w2ll + o) = *reinterpret_cast<const u32x4*>(static_cast<const char*>(p.w2) + o);
-  if (tid == 0) { tq[0] = tile_claim(p.sched, p.tiles_total); tq[1] = tq[0] < 0 ? -1 : tile_claim(p.sched, p.tiles_total); }
+  const int xcd = xcc_id();
+  auto claim = [&]() { return p.xcd_local ? tile_claim_xcd(p.sched, xcd, p.N, tiles_per_img) : tile_claim(p.sched + 9, p.tiles_total); };
+  if (tid == 0) { tq[0] = claim(); tq[1] = tq[0] < 0 ? -1 : claim(); }
   __syncthreads();
   int t = tq[0], t_next = tq[1];
   auto decode = [&](int t, int& img, int& oy0, int& ox0) {
@@ -196,10 +199,20 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
     decode(t, img, oy0, ox0);
     const unsigned long long ts0 = now();
     int t_after = -1;
-    if (tid == 0 && t_next >= 0) t_after = tile_claim(p.sched, p.tiles_total);   // returns under phases A and B
+    if (tid == 0 && t_next >= 0) t_after = claim();   // returns under phases A and B
 
     // ---- A: conv1 (1x1, 256 -> 64) on the halo pixels -> t1: all four 16-channel blocks of the wave's columns ----
     frag_t w2f[18 - W2L][2];                               // conv2's weights of this wave that are not in LDS: re-read per tile (below)
+    // phase C's residual vectors (the tile's centre pixels of x, 64 registers): requested at the end of phase A, so that
+    // they arrive under conv2 -- requested at the start of phase C their latency (2-3 us under load, with nothing else
+    // for the wave to do: conv3 is 64 MFMAs) was exposed on every tile.  The ring of x vectors is dead during phase B,
+    // which is where the registers come from.
+    const uint32_t pl_bytes = (uint32_t)HW * 16u;
+    auto out_off = [&](int cp) -> uint32_t {
+      const int oy = oy0 + 2 * cp + half, ox = ox0 + r;
+      return (oy < p.H && ox < p.W) ? (uint32_t)((img * 32 + psel) * HW + oy * p.W + ox) * 16u : BUF_OOB;
+    };
+    u32x4 rv[PROJ ? 1 : 8][2];
     {
       f32x4 acc[4][3];
 #pragma unroll
@@ -260,6 +273,15 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
         for (int mb = 0; mb < 2; ++mb)
           w2f[s2 - W2L][mb] = __builtin_bit_cast(frag_t, load16_buf(rs_w2, w2vo, (uint32_t)((s2 * 4 + mb) * 1024)));
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!PROJ) {
+#pragma unroll
+        for (int cp = 0; cp < 8; ++cp) {
+          const uint32_t o = out_off(cp);
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb) rv[cp][mb] = load16_buf(rs_in, o, (uint32_t)(2 * (2 * wave + mb)) * pl_bytes);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     const unsigned long long ts1 = now();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -338,21 +360,6 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
     // lower half-wave owns the pixel of the even row, the upper half-wave that of the odd one, each lane the 8 channels
     // of plane 2 * block + psel
     {
-      const uint32_t pl_bytes = (uint32_t)HW * 16u;
-      auto out_off = [&](int cp) -> uint32_t {
-        const int oy = oy0 + 2 * cp + half, ox = ox0 + r;
-        return (oy < p.H && ox < p.W) ? (uint32_t)((img * 32 + psel) * HW + oy * p.W + ox) * 16u : BUF_OOB;
-      };
-      // every residual vector of the tile (64 registers) before the first store
-      u32x4 rv[PROJ ? 1 : 8][2];
-      if constexpr (!PROJ) {
-#pragma unroll
-        for (int cp = 0; cp < 8; ++cp) {
-          const uint32_t o = out_off(cp);
-#pragma unroll
-          for (int mb = 0; mb < 2; ++mb) rv[cp][mb] = load16_buf(rs_in, o, (uint32_t)(2 * (2 * wave + mb)) * pl_bytes);
-        }
-      }
       __builtin_amdgcn_sched_barrier(0);
       if (t_next >= 0) locate(t_next);
       else { vo[0] = vo[1] = vo[2] = BUF_OOB; cx[0] = cx[1] = cx[2] = -1; }   // last tile: the requests still run (they read nothing), so that the
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
       tph[0] += ts1 - ts0; tph[1] += ts2 - ts1; tph[2] += ts3 - ts2; tph[3] += ts4 - ts3; tph[4] += ts5 - ts4;
     }
   }
-  if (tid == 0) tile_retire(p.sched);
+  if (tid == 0) { if (p.xcd_local) tile_retire_xcd(p.sched); else tile_retire(p.sched + 9); }
   if (SCP_DBG_BUF(p) && lane == 0)
     for (int k = 0; k < 6; ++k) SCP_DBG_BUF(p)[((size_t)blockIdx.x * 8 + wave) * 6 + k] = tph[k];
 }
@@ -504,6 +511,7 @@ int32_t bottleneck_launch(const void* in, const void* w1, const void* w2, const 
     L.tiles_total = n * L.tiles_x * L.tiles_y;
     L.grid = conv_device_cus() < L.tiles_total ? conv_device_cus() : L.tiles_total;
     L.sched = sched;
+    { static const char* e = dev_env("SCPOSE_BNECK_GLOBALQ"); L.xcd_local = !(e && atoi(e)); }
     { static const char* e = dev_env("SCPOSE_BNECK_DBG"); L.dbg_buf = (kDevBuild && e && atoi(e)) ? conv_dbg_buffer(stream) : nullptr; if (L.dbg_buf) conv_dbg_set_grid(L.grid); }
     int32_t rc;
     if (dtype == SCPOSE_DT_BF16) rc = proj ? bneck_launch_one<0, true>(L, stream) : bneck_launch_one<0, false>(L, stream);

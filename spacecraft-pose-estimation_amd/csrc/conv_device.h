@@ -106,6 +106,35 @@ __device__ __forceinline__ void tile_retire(uint32_t* sched) {   // one lane per
   }
 }
 
+// XCD-local form of the queue (kernels whose neighbouring tiles share cache lines: the 1-pixel halo of a 16-byte-per-pixel
+// row starts 16 bytes in front of a line): one counter per XCD (sched[0..7]; sched[8] counts finished workgroups), XCD k
+// owns the tiles of images k, k + 8, ... in raster order, so the 32 CUs of an XCD work on ~32 consecutive tiles of the
+// same one or two images at the same time and the lines two tiles share are fetched into that XCD's L2 once.  A
+// workgroup whose own list is exhausted takes tiles from the next XCD's list (CUs held by another kernel delay nothing).
+__device__ __forceinline__ int xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return (int)(v & 7u);
+}
+__device__ __forceinline__ int tile_claim_xcd(uint32_t* sched, int xcd, int n_img, int tiles_per_img) {
+  for (int j = 0; j < 8; ++j) {
+    const int k = (xcd + j) & 7;
+    const int cnt = ((n_img - k + 7) >> 3) * tiles_per_img;
+    if (cnt <= 0) continue;
+    const uint32_t c = __hip_atomic_fetch_add(sched + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c < (uint32_t)cnt) {
+      const int ii = (int)c / tiles_per_img;
+      return (ii * 8 + k) * tiles_per_img + ((int)c - ii * tiles_per_img);
+    }
+  }
+  return -1;
+}
+__device__ __forceinline__ void tile_retire_xcd(uint32_t* sched) {
+  const uint32_t d = __hip_atomic_fetch_add(sched + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (d == gridDim.x - 1)
+    for (int k = 0; k < 9; ++k) __hip_atomic_store(sched + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // DT: 0 = bf16, 1 = f16 (an int so that profiler kernel names demangle: conv_igemm_kernel<0,3,1,3,4>)
 template <int DT> struct DtOf { typedef __bf16 type; };
 template <> struct DtOf<1> { typedef _Float16 type; };

@@ -408,6 +408,24 @@ class HrnetEngine:
 
     __call__ = forward
 
+    @staticmethod
+    def kernel_classes(recs):
+        """Class name of every record of profile_read(): 'kind:a:cin:cout', with '@<output pixels per frame>' appended where one
+        forward runs the same layer shape at two map sizes (the 48->48 stride-2 convs of the 96x96 -> 12x12 fuse chain), so
+        that per-class statistics never mix launches with different work."""
+        base = ["%d:%d:%d:%d" % (r["kind"], r["a"], r["cin"], r["cout"]) for r in recs]
+        work = {}
+        for b, r in zip(base, recs):
+            work.setdefault(b, set()).add((r["flops_per_frame"], r["bytes_per_frame"]))
+        out = []
+        for b, r in zip(base, recs):
+            if len(work[b]) > 1 and r["kind"] == 1:
+                k = r["a"] // 10
+                out.append("%s@%d" % (b, round(r["flops_per_frame"] / (2.0 * r["cin"] * r["cout"] * k * k))))
+            else:
+                out.append(b)
+        return out
+
     def close(self):
         # captured graphs bake in this engine's packed-weight pointers: destroy them first, so that no graph can replay
         # kernels that read freed weights (their replay() raises afterwards)

@@ -29,8 +29,8 @@ def op_classes():
     x = torch.randint(0, 256, (batch, image, image, 3), dtype=torch.uint8, device="cuda")
     eng.forward(x, profile=True)
     recs = eng.profile_read()
-    return ["%d:%d:%d:%d" % (r["kind"], r["a"], r["cin"], r["cout"]) for r in recs], \
-           {"%d:%d:%d:%d" % (r["kind"], r["a"], r["cin"], r["cout"]): (r["flops_per_frame"] * batch, r["bytes_per_frame"] * batch) for r in recs}
+    names = eng.kernel_classes(recs)
+    return names, {c: (r["flops_per_frame"] * batch, r["bytes_per_frame"] * batch) for c, r in zip(names, recs)}
 
 
 def find(sub, pat):

@@ -16,7 +16,8 @@ x = torch.randint(0, 256, (n, size, size, 3), dtype=torch.uint8, device="cuda")
 for tap in ("stem2", "layer1"):
     for _ in range(2): eng.forward_tap(x, tap)
     torch.cuda.synchronize(); t = time.time()
-    for _ in range(5): eng.forward_tap(x, tap)
-    torch.cuda.synchronize(); print("%s: %.3f ms" % (tap, (time.time() - t) / 5 * 1e3))
+    it = int(os.environ.get("ITERS", "5"))
+    for _ in range(it): eng.forward_tap(x, tap)
+    torch.cuda.synchronize(); print("%s: %.3f ms" % (tap, (time.time() - t) / it * 1e3))
 if os.environ.get("SCPOSE_BNECK_DBG"):
     ctypes.CDLL(ops.nat.LIB_PATH).scpose_dbg_dump()
