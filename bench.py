@@ -87,6 +87,9 @@ def parse():
                          "transition convolutions (short HBM-bound launches) side by side, the branches one after the other; 0: eager "
                          "launches; default: 1 for batches <= 128 (W32 batch 64: -19 %%), 2 above (W48 batch 256: -0.3 ms; the "
                          "MFMA-bound branch kernels each fill the chip and only contend when run side by side)")
+    ap.add_argument("--fused-decode", type=int, default=1,
+                    help="1: key points from scpose_hrnet_forward_decode (decode inside the network's last kernel, no heat-map round trip); "
+                         "0: scpose_hrnet_forward, then scpose_decode on the side stream")
     ap.add_argument("--chained", action="store_true",
                     help="feed the PnP stage with the decoded (random-weight) keypoints instead of synthetic ones")
     return ap.parse_args()
@@ -197,7 +200,14 @@ def main():
     host_buf = [torch.empty((world * B, 13), dtype=torch.float64).pin_memory() for _ in range(2)] if rank == 0 else None
     side = torch.cuda.Stream(device=dev)
     # captured forward, one graph per output buffer (same kernels, same results; scpose.h: scpose_hrnet_graph_*)
-    graphs = [eng.capture(frames, out=heat[k], concurrent=args.graph) for k in range(2)] if args.graph else None
+    # --fused-decode 1 (default): scpose_hrnet_forward_decode -- the key points come out of the network's last kernel
+    # (head_fused.hip: last fuse sum + final_layer + decode in one pass), no heat-map is written or re-read
+    fused = bool(args.fused_decode) and eng.tail_fused(B, image, image)
+    if args.graph:
+        graphs = [eng.capture_decode(frames, center, scale, True, concurrent=args.graph) if fused
+                  else eng.capture(frames, out=heat[k], concurrent=args.graph) for k in range(2)]
+    else:
+        graphs = None
     done = [None, None]
     counter = [0]
 
@@ -214,8 +224,12 @@ def main():
         if timed:
             fwd_start = torch.cuda.Event(enable_timing=True)
             fwd_start.record(main)
+        kp = None
         if graphs is not None and not profile:
-            graphs[k].replay()
+            out = graphs[k].replay()
+            kp = out if fused else None
+        elif fused and not profile:
+            kp = eng.forward_decode(frames, center, scale, True)
         else:
             eng.forward(frames, out=heat[k], profile=profile)
         fwd_done = torch.cuda.Event(enable_timing=timed)
@@ -224,7 +238,8 @@ def main():
             fwd_events.append((fwd_start, fwd_done))
         with torch.cuda.stream(side):
             side.wait_event(fwd_done)
-            kp = ops.decode(heat[k], center, scale, True)
+            if kp is None:
+                kp = ops.decode(heat[k], center, scale, True)
             rot, tv, st = ops.pnp_epnp_ransac(kp if args.chained else kp_syn, lm, Kc, dc)
             block[k][:, 0:9] = rot.view(B, 9)
             block[k][:, 9:12] = tv
@@ -291,6 +306,7 @@ def main():
             what the launch itself must move: a fused BasicBlock counts its input once + its output once)."""
             kind, a, cin, cout, cls = key
             name = {0: "stem_conv1_kernel (3->64 3x3 s2, f32 VALU)", 2: "fuse_sum_kernel (%d terms, C=%d)" % (a, cin),
+                    7: "head_fused_kernel: last fuse sum (%d terms) + final_layer 1x1 %d->%d in one pass" % (a, cin, cout),
                     3: "conv_block_kernel: fused BasicBlock 2 x (3x3 s1 %d->%d), input read once + output written once" % (cin, cout),
                     4: "head_gather_kernel (k%d s%d, C=%d)" % (a // 10, a % 10, cin),
                     5: "stem_fused_kernel: conv1 + conv2 of the stem (3->64->64, both 3x3 s2), image read once + output written once",
@@ -325,7 +341,7 @@ def main():
         roof["profiled_steps"] = prof_steps
         roof["src_sha"] = sha
         # the next kernel classes by share of the forward, each against its own roofline (same definitions);
-        # class = kind:10*ksize+stride|nterms:Cin:Cout (kind 0 stem, 1 conv, 2 fuse sum, 3 fused BasicBlock, 4 head gather, 5 fused stem, 6 fused Bottleneck)
+        # class = kind:10*ksize+stride|nterms:Cin:Cout (kind 0 stem, 1 conv, 2 fuse sum, 3 fused BasicBlock, 4 head gather, 5 fused stem, 6 fused Bottleneck, 7 fused tail; '@pixels' where a layer shape runs at two map sizes)
         roof["next_classes"] = [{k: v for k, v in describe(k2, *v2).items()
                                  if k in ("class", "share_of_forward", "avg_launch_us", "bound", "achieved", "unit", "frac", "frac_of_sustained", "traffic")}
                                 for k2, v2 in ranked[1:6]]
@@ -348,6 +364,8 @@ def main():
                        "frames_per_step": world * B, "parallelism": "frame-sharded x%d, all-gather of (R,t,status); PnP/gather/D2H of step i overlap the forward of step i+1" % world,
                        "pnp_input": "decoded" if args.chained else "synthetic projected landmarks, 1 px noise, 10% outliers",
                        "forward": ("hipGraph replay, %s on concurrent lanes (%d nodes)" % ("branches, fuse rows and transitions" if args.graph == 1 else "fuse rows and transitions", graphs[0].nodes)) if graphs else "eager launches",
+                       "decode": "inside the network's last kernel (scpose_hrnet_forward_decode: last fuse sum + final_layer + arg-max / quarter-pixel / back-transform, no heat-map written)" if fused
+                                 else "scpose_decode on the heat-maps, on the side stream",
                        "roofline_pass": "%d eager steps with per-launch HIP events, after the timed region" % prof_steps,
                        "launches_per_forward": st["launches"], "gflop_per_frame": round(st["flops_per_frame"] / 1e9, 3),
                        "act_mbytes_per_frame": round(st["act_bytes_per_frame"] / 1e6, 2)},

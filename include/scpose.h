@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SCPOSE_ABI_VERSION 4
+#define SCPOSE_ABI_VERSION 5
 
 enum {
   SCPOSE_OK = 0,
@@ -123,6 +123,19 @@ int32_t scpose_hrnet_forward(scpose_hrnet_t h, const void* in, int32_t in_fmt, i
                              int32_t height, int32_t width, float* heatmaps, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+/* Forward + decode in one call: the key points of validate() / the pose exporter without a heat-map round trip through HBM.
+ * Replaces the pair model(input) -> get_final_preds(output, center, scale) of landmark_regression/lib/core/function.py:376-393
+ * (lib/core/inference.py:18-79, lib/utils/transforms.py:49-110); arguments as scpose_hrnet_forward and scpose_decode.
+ * For pose_hrnet with FINAL_CONV_KERNEL == 1 the last fuse sum, final_layer and the decode run as one pass over the
+ * branch-0 tensor (head_fused.hip): `heatmaps` may then be NULL and nothing is written for them; when it is given it
+ * receives exactly what scpose_hrnet_forward writes.  Other heads (3x3 final layer, hrnet_cms) need `heatmaps` and run
+ * forward + scpose_decode back to back on `stream`.  preds_xyc is bit-identical to scpose_decode(scpose_hrnet_forward(...)). */
+int32_t scpose_hrnet_tail_fused(scpose_hrnet_t h, int32_t n, int32_t height, int32_t width, int32_t* fused);   /* 1: heatmaps may be NULL */
+int32_t scpose_hrnet_forward_decode(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n, int32_t height,
+                                    int32_t width, const float* center, const float* scale, int32_t post_process,
+                                    float* preds_xyc, float* heatmaps, void* workspace, size_t workspace_bytes,
+                                    void* stream);
+
 /* Captured forward.  The launch list of one forward for a FIXED (input buffer, batch shape, heat-map buffer, workspace)
  * is recorded once into a hipGraph and replayed with one call: for small batches the host-side launch cost of the
  * ~280 kernels disappears, and with concurrent != 0 the ops that do not depend on each other -- the branches of a
@@ -141,6 +154,11 @@ int32_t scpose_hrnet_graph_workspace_bytes(scpose_hrnet_t h, int32_t n, int32_t 
 int32_t scpose_hrnet_graph_create(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n, int32_t height,
                                   int32_t width, float* heatmaps, void* workspace, size_t workspace_bytes,
                                   int32_t concurrent, scpose_hrnet_graph_t* out);
+/* the captured form of scpose_hrnet_forward_decode (center / scale / preds_xyc / heatmaps are baked in like `in`) */
+int32_t scpose_hrnet_graph_create_decode(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n, int32_t height,
+                                         int32_t width, const float* center, const float* scale, int32_t post_process,
+                                         float* preds_xyc, float* heatmaps, void* workspace, size_t workspace_bytes,
+                                         int32_t concurrent, scpose_hrnet_graph_t* out);
 int32_t scpose_hrnet_graph_launch(scpose_hrnet_graph_t g, void* stream);
 int32_t scpose_hrnet_graph_nodes(scpose_hrnet_graph_t g, int32_t* nodes);   /* kernel + dependency nodes captured */
 int32_t scpose_hrnet_graph_destroy(scpose_hrnet_graph_t g);
@@ -159,7 +177,8 @@ int32_t scpose_hrnet_forward_tap(scpose_hrnet_t h, const void* in, int32_t in_fm
  * every launch and after the last one, then per-launch milliseconds, algorithmic FLOPs and
  * bytes per frame and a kernel signature {kind, 10*ksize+stride | nterms, Cin, Cout} with kind
  * 0 stem conv1 alone (two-layer stem), 1 convolution, 2 fuse sum, 3 fused BasicBlock, 4 head gather
- * (hrnet_cms), 5 fused stem (conv1 + conv2), 6 fused Bottleneck.  profile_read blocks on the last event.  Call with ms == NULL to get *count. */
+ * (hrnet_cms), 5 fused stem (conv1 + conv2), 6 fused Bottleneck, 7 fused tail (last fuse sum + final_layer; the fuse op it absorbs
+ * reports no work).  profile_read blocks on the last event.  Call with ms == NULL to get *count. */
 int32_t scpose_hrnet_forward_profiled(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n,
                                       int32_t height, int32_t width, float* heatmaps,
                                       void* workspace, size_t workspace_bytes, void* stream);

@@ -21,7 +21,7 @@ if os.environ.get("SCPOSE_DEV") == "1":
 
 DT_BF16, DT_F16 = 0, 1
 IN_F32_NCHW, IN_U8_NHWC = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class HrnetDesc(ctypes.Structure):
@@ -55,6 +55,11 @@ SYMBOLS = {
                                      POINTER(c_double)]),
     "scpose_hrnet_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                        c_void_p, c_size_t, c_void_p]),
+    "scpose_hrnet_tail_fused": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_int32)]),
+    "scpose_hrnet_forward_decode": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
+                                              c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "scpose_hrnet_graph_create_decode": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
+                                                   c_void_p, c_void_p, c_void_p, c_size_t, c_int32, POINTER(c_void_p)]),
     "scpose_hrnet_graph_workspace_bytes": (c_int32, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_size_t)]),
     "scpose_hrnet_graph_create": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_size_t,
                                             c_int32, POINTER(c_void_p)]),

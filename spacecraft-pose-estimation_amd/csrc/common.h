@@ -232,6 +232,13 @@ int32_t blocked_to_nchw_launch(const void* src, int N, int C, int H, int W, int 
                                hipStream_t stream);
 
 // ---- decode / pnp --------------------------------------------------------------------------
+// head_fused.hip: last fuse sum + final_layer (+ decode) in one pass (pose_hrnet.py:256-263, :458; lib/core/inference.py:18-79)
+void head_fused_pack(const float* w, const float* b, int J, int C, int dtype, uint16_t* wfrag, float* bias);
+size_t head_fused_part_bytes(int n);
+bool head_fused_supported(int nterms, int C, int J, int N, int H, int W);
+int32_t head_fused_launch(const void* const* terms, const int32_t* shifts, int nterms, int N, int C, int H, int W, int J,
+                          int dtype, const void* wfrag, const float* bias, float* hm, float* part_v, int32_t* part_i,
+                          const float* center, const float* scale, int post_process, float* preds, hipStream_t stream);
 int32_t decode_launch(const float* hm, int N, int J, int H, int W, const float* center,
                       const float* scale, int post_process, float* preds_xyc, float* coords,
                       float* maxvals, hipStream_t stream);

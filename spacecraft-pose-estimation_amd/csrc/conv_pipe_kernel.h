@@ -79,12 +79,16 @@ __device__ __forceinline__ void store16_buf(buf_rsrc_t r, uint32_t voff, uint32_
 __device__ __forceinline__ u32x4 load16_buf(buf_rsrc_t r, uint32_t voff, uint32_t soff) {   // out-of-range lanes read zeros
   return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
 }
+__device__ __forceinline__ void store4_buf(buf_rsrc_t r, uint32_t voff, uint32_t v) {   // out-of-range lanes are dropped
+  __builtin_amdgcn_raw_buffer_store_b32(v, r, voff, 0u, 0);
+}
 #else   // host pass: the resource type does not exist there; these are never called
 struct buf_rsrc_t {};
 __device__ inline buf_rsrc_t make_buf(const void*, uint32_t) { return buf_rsrc_t{}; }
 __device__ inline void dma16_buf(buf_rsrc_t, uint32_t, uint32_t, void*) {}
 __device__ inline void store16_buf(buf_rsrc_t, uint32_t, uint32_t, u32x4) {}
 __device__ inline u32x4 load16_buf(buf_rsrc_t, uint32_t, uint32_t) { return u32x4{0u, 0u, 0u, 0u}; }
+__device__ inline void store4_buf(buf_rsrc_t, uint32_t, uint32_t) {}
 #endif
 
 // OCC = resident workgroups per CU the variant is built for: 2 caps the wave at 256 registers

@@ -9,14 +9,9 @@
 // running (value, first index) pair, waves combine with 6 xor-shuffles, the workgroup's four waves through LDS.  Tie / NaN rules are
 // numpy's: first occurrence wins, NaN counts as the maximum (first NaN wins).
 #include "common.h"
+#include "decode_device.h"   // better(), decode_coords / decode_refines / decode_refine / decode_to_image (shared with head_fused.hip)
 
 namespace scpose {
-
-__device__ __forceinline__ bool better(float v1, int i1, float v2, int i2) {
-  const bool n1 = v1 != v1, n2 = v2 != v2;
-  if (n1 || n2) return (n1 && n2) ? (i1 < i2) : n1;
-  return v1 > v2 || (v1 == v2 && i1 < i2);
-}
 
 struct DecodeArgs {
   const float* hm;
@@ -81,44 +76,16 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
   for (int w = 1; w < 4; ++w)
     if (better(s_v[w], s_i[w], bv, bi)) { bv = s_v[w]; bi = s_i[w]; }
 
-  // inference.py:37-45 -- idx as float32, x = idx % W, y = floor(idx / W), masked when !(max > 0)
-  float cx = (float)(bi % a.W), cy = (float)(bi / a.W);
-  if (!(bv > 0.0f)) { cx = 0.f; cy = 0.f; }
+  float cx, cy;
+  decode_coords(bv, bi, a.W, cx, cy);
   if (a.maxvals) a.maxvals[map] = bv;
   if (a.coords) { a.coords[map * 2] = cx; a.coords[map * 2 + 1] = cy; }
   if (!a.preds_xyc) return;
-
-  if (a.post_process) {  // inference.py:56-69 (strict inequalities, sign(0) = 0)
-    const int px = (int)floorf(cx + 0.5f), py = (int)floorf(cy + 0.5f);
-    if (1 < px && px < a.W - 1 && 1 < py && py < a.H - 1) {
-      const float dx = m[py * a.W + px + 1] - m[py * a.W + px - 1];
-      const float dy = m[(py + 1) * a.W + px] - m[(py - 1) * a.W + px];
-      const float sx = dx != dx ? dx : (dx > 0.f ? 1.f : (dx < 0.f ? -1.f : 0.f));
-      const float sy = dy != dy ? dy : (dy > 0.f ? 1.f : (dy < 0.f ? -1.f : 0.f));
-      cx += sx * 0.25f;
-      cy += sy * 0.25f;
-    }
-  }
-
-  // transforms.py:57-89 with rot = 0, inv = 1, output_size = (W, H).  The three float32 point
-  // pairs the reference hands to cv2.getAffineTransform are rebuilt with the same float32
-  // roundings; the affine map they define is then solved in closed form in float64:
-  //   dst: (W/2,H/2) (W/2,H/2-W/2) (0,H/2-W/2)  ->  src: (cx,cy) (cx,s1y) (s2x,s1y)
+  int px, py;
+  if (a.post_process && decode_refines(cx, cy, a.H, a.W, px, py))
+    decode_refine(m[py * a.W + px + 1], m[py * a.W + px - 1], m[(py + 1) * a.W + px], m[(py - 1) * a.W + px], cx, cy);
   const int n = map / a.J;
-  const float ccx = a.center[n * 2], ccy = a.center[n * 2 + 1];
-  const float src_w = __fmul_rn(a.scale[n * 2], 200.0f);       // scale_tmp[0]
-  const float s1y = __fadd_rn(ccy, -0.5f * src_w);              // src[1,1]
-  const float d = __fsub_rn(ccy, s1y);                          // direct[1] of get_3rd_point
-  const float s2x = __fsub_rn(ccx, d);                          // src[2,0]
-  const double half_w = 0.5 * (double)a.W, half_h = 0.5 * (double)a.H;
-  const double a00 = ((double)ccx - (double)s2x) / half_w;
-  const double a11 = ((double)ccy - (double)s1y) / half_w;
-  const double xi = (double)ccx + a00 * ((double)cx - half_w);
-  const double yi = (double)ccy + a11 * ((double)cy - half_h);
-  float* o = a.preds_xyc + (size_t)map * 3;
-  o[0] = (float)xi;
-  o[1] = (float)yi;
-  o[2] = bv;
+  decode_to_image(cx, cy, bv, a.H, a.W, a.center + n * 2, a.scale + n * 2, a.preds_xyc + (size_t)map * 3);
 }
 
 int32_t decode_launch(const float* hm, int N, int J, int H, int W, const float* center,

@@ -120,6 +120,11 @@ struct scpose_hrnet {
   float* d_head_bias = nullptr; // [4][16] folded biases of the hrnet_cms heads
   uint32_t* d_sched = nullptr;  // 16 zero-initialised words per op: dynamic tile queues of the persistent kernels (conv_device.h: tile_claim)
   int head_k = 0, head_s = 1;   // transposed-conv kernel / stride of the heads (heat-map = S * branch-0 size)
+  // fused tail (head_fused.hip): the last fuse sum and final_layer run as one kernel -- ops[fuse_op] is skipped and
+  // ops[conv_op] launches head_fused with the fuse op's terms -- unless the forward stops at the fuse op's output
+  // (scpose_hrnet_forward_tap) or the shape is not supported
+  struct HeadFused { bool ok = false; int fuse_op = -1, conv_op = -1; void* d_w = nullptr; float* d_b = nullptr;
+                     float* d_part_v = nullptr; int32_t* d_part_i = nullptr; int part_cap = 0; bool active = false; } headf;
   std::vector<scpose::TensorDesc> tensors;
   std::vector<scpose::Op> ops;
   std::vector<std::pair<std::string, int>> taps;   // named intermediate tensors (scpose_hrnet_forward_tap): name -> tensor id
@@ -475,6 +480,24 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
   }
   if (B.status == SCPOSE_OK && d.head == SCPOSE_HEAD_FINAL_LAYER) {
     B.conv(ylist[0], "final_layer", "", d.num_joints, d.final_conv_kernel, 1, false, -1, true, true);
+    const int nops = (int)net->ops.size();
+    if (B.status == SCPOSE_OK && d.final_conv_kernel == 1 && nops >= 2 && net->ops[nops - 2].kind == OP_FUSE &&
+        net->ops[nops - 2].out == ylist[0] && net->ops[nops - 1].in == ylist[0] &&
+        head_fused_supported(net->ops[nops - 2].nterms, net->tensors[ylist[0]].C, d.num_joints, 1, 32, 32)) {
+      const int C = net->tensors[ylist[0]].C;
+      const float* fw = W.get("final_layer.weight", (int64_t)d.num_joints * C);
+      const float* fb = W.get("final_layer.bias", d.num_joints);
+      if (fw && fb) {
+        std::vector<uint16_t> wf(2 * 4 * 16 * 8);
+        float bias[16];
+        head_fused_pack(fw, fb, d.num_joints, C, d.dtype, wf.data(), bias);
+        SCP_CHECK_HIP(hipMalloc(&net->headf.d_w, wf.size() * 2));
+        SCP_CHECK_HIP(hipMalloc(&net->headf.d_b, sizeof(bias)));
+        SCP_CHECK_HIP(hipMemcpy(net->headf.d_w, wf.data(), wf.size() * 2, hipMemcpyHostToDevice));
+        SCP_CHECK_HIP(hipMemcpy(net->headf.d_b, bias, sizeof(bias), hipMemcpyHostToDevice));
+        net->headf.ok = true; net->headf.fuse_op = nops - 2; net->headf.conv_op = nops - 1;
+      }
+    }
   } else if (B.status == SCPOSE_OK) {
     const bool cms = d.head == SCPOSE_HEAD_CMS;
     net->head_k = cms ? 5 : 3;
@@ -581,10 +604,40 @@ size_t hrnet_plan(scpose_hrnet* net, int n, int h, int w, int mode = 0) {
   return top;
 }
 
+// Key points straight from the forward (scpose_hrnet_forward_decode): the decode of lib/core/inference.py:49-79 runs inside
+// the fused tail when the network has one, else as decode.hip's kernel on the heat-maps behind the last layer.
+struct HeadDecode {
+  const float* center;
+  const float* scale;
+  int post_process;
+  float* preds;
+};
+
+// does a forward of this shape run the fused tail (head_fused.hip)?
+bool hrnet_tail_fused(const scpose_hrnet* net, int n, int h, int w) {
+  if (!net->headf.ok) return false;
+  static const char* e = dev_env("SCPOSE_NO_HEAD_FUSE");
+  const Op& fo = net->ops[net->headf.fuse_op];
+  const TensorDesc& ty = net->tensors[fo.out];
+  return !(e && atoi(e)) && head_fused_supported(fo.nterms, ty.C, net->desc.num_joints, n, h >> ty.ds, w >> ty.ds);
+}
+
 int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int h, int w,
                       float* heatmaps, void* ws, size_t ws_bytes, hipStream_t st, bool profile, int stop_tensor = -1,
-                      int mode = 0, const scpose_hrnet_lanes* lanes = nullptr) {
+                      int mode = 0, const scpose_hrnet_lanes* lanes = nullptr, const HeadDecode* dec = nullptr) {
   SCP_REQUIRE(n > 0, "hrnet_forward: batch %d", n);
+  const bool fused_tail = hrnet_tail_fused(net, n, h, w) && stop_tensor != net->ops[net->headf.fuse_op].out;
+  net->headf.active = fused_tail;
+  SCP_REQUIRE(heatmaps || (dec && fused_tail) || stop_tensor >= 0,
+              "hrnet_forward: this network's tail is not fused for this shape -- key points need a heat-map buffer");
+  if (dec && fused_tail && net->headf.part_cap < n) {   // partial maxima of the strips (grown on demand, outside any capture: graph_create runs an eager forward first)
+    if (net->headf.d_part_v) (void)hipFree(net->headf.d_part_v);
+    if (net->headf.d_part_i) (void)hipFree(net->headf.d_part_i);
+    net->headf.d_part_v = nullptr; net->headf.d_part_i = nullptr; net->headf.part_cap = 0;
+    SCP_CHECK_HIP(hipMalloc(&net->headf.d_part_v, head_fused_part_bytes(n)));
+    SCP_CHECK_HIP(hipMalloc(&net->headf.d_part_i, head_fused_part_bytes(n)));
+    net->headf.part_cap = n;
+  }
   SCP_REQUIRE(h % 32 == 0 && w % 32 == 0 && h > 0 && w > 0, "hrnet_forward: H=%d W=%d must be multiples of 32", h, w);
   const size_t need = hrnet_plan(net, n, h, w, mode);
   if (ws_bytes < need || !ws) {
@@ -632,7 +685,18 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
     if (profile) SCP_CHECK_HIP(hipEventRecord(net->events[opi], st));
     ++opi;
     int32_t rc = SCPOSE_OK;
-    if (op.kind == OP_STEM) {
+    if (fused_tail && (int)oi == net->headf.fuse_op) {
+      // nothing: its sum is formed in registers by the next op
+    } else if (fused_tail && (int)oi == net->headf.conv_op) {
+      const Op& fo = net->ops[net->headf.fuse_op];
+      const TensorDesc& ty = net->tensors[fo.out];
+      const void* terms[4];
+      for (int k = 0; k < fo.nterms; ++k) terms[k] = ptr(fo.term[k]);
+      rc = head_fused_launch(terms, fo.shift, fo.nterms, n, ty.C, h >> ty.ds, w >> ty.ds, net->desc.num_joints, net->desc.dtype,
+                             net->headf.d_w, net->headf.d_b, heatmaps, dec ? net->headf.d_part_v : nullptr,
+                             dec ? net->headf.d_part_i : nullptr, dec ? dec->center : nullptr, dec ? dec->scale : nullptr,
+                             dec ? dec->post_process : 0, dec ? dec->preds : nullptr, st);
+    } else if (op.kind == OP_STEM) {
       rc = stem_launch(in, in_fmt, net->d_stem_w, net->d_stem_b, net->d_mean_std, n, h, w,
                        net->desc.dtype, ptr(op.out), st);
     } else if (op.kind == OP_STEM2) {
@@ -669,6 +733,13 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
   }
   if (lanes) { const int32_t rc = join_lanes(); if (rc != SCPOSE_OK) return rc; }
   st = st0;
+  if (dec && !fused_tail && stop_tensor < 0) {   // unfused tail: decode.hip on the heat-maps
+    int32_t hh = 0, hw = 0;
+    hh = h / 4 * net->head_s; hw = w / 4 * net->head_s;
+    const int32_t rc = decode_launch(heatmaps, n, net->desc.num_joints, hh, hw, dec->center, dec->scale, dec->post_process,
+                                     dec->preds, nullptr, nullptr, st);
+    if (rc != SCPOSE_OK) return rc;
+  }
   if (profile) {
     SCP_CHECK_HIP(hipEventRecord(net->events[opi], st));
     net->events_valid = true;
@@ -682,7 +753,20 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
 static void op_work(const scpose_hrnet* net, const Op& op, int h, int w, double* f, double* by, int32_t sig[4], bool unfused = false) {
   *f = 0; *by = 0;
   sig[0] = op.kind; sig[1] = sig[2] = sig[3] = 0;
-  if (op.kind == OP_STEM) {
+  if (!unfused && net->headf.active && &op == &net->ops[net->headf.fuse_op]) {
+    // fused tail (head_fused.hip): this op launched nothing; its work is accounted under the next one
+    const TensorDesc& to = net->tensors[op.out];
+    sig[1] = op.nterms; sig[2] = to.C; sig[3] = to.C;
+  } else if (!unfused && net->headf.active && &op == &net->ops[net->headf.conv_op]) {
+    // last fuse sum + final_layer in one launch: the fuse row's terms in, the f32 heat-maps out (kind 7)
+    const Op& fo = net->ops[net->headf.fuse_op];
+    const TensorDesc& to = net->tensors[fo.out];
+    const double ho = h >> to.ds, wo = w >> to.ds, J = net->desc.num_joints;
+    *f = 2.0 * to.C * J * ho * wo;
+    *by = J * ho * wo * 4;
+    for (int k = 0; k < fo.nterms; ++k) *by += to.C * (ho / (1 << fo.shift[k])) * (wo / (1 << fo.shift[k])) * 2;
+    sig[0] = 7; sig[1] = fo.nterms; sig[2] = to.C; sig[3] = (int)J;
+  } else if (op.kind == OP_STEM) {
     *f = 2.0 * 27 * 64 * (h / 2) * (w / 2);
     *by = (double)64 * (h / 2) * (w / 2) * 2 + 3.0 * h * w;   // u8 in (f32 in: 4x) + 16-bit out
     sig[1] = 32; sig[2] = 3; sig[3] = 64;
@@ -741,7 +825,7 @@ void hrnet_stats(scpose_hrnet* net, int h, int w, int* launches, double* flops, 
     if (op.kind == OP_STEM || op.kind == OP_STEM2) ob -= 3.0 * h * w;   // network input is not an inter-layer activation
     f += of; by += ob;
   }
-  if (launches) *launches = (int)net->ops.size();
+  if (launches) *launches = (int)net->ops.size() - (hrnet_tail_fused(net, 1, h, w) ? 1 : 0);   // the fused tail absorbs the last fuse row
   if (flops) *flops = f;
   if (bytes) *bytes = by;
 }
@@ -763,6 +847,10 @@ void hrnet_free(scpose_hrnet* net) {
   if (net->d_stemf_b2) (void)hipFree(net->d_stemf_b2);
   if (net->d_head_bias) (void)hipFree(net->d_head_bias);
   if (net->d_sched) (void)hipFree(net->d_sched);
+  if (net->headf.d_w) (void)hipFree(net->headf.d_w);
+  if (net->headf.d_b) (void)hipFree(net->headf.d_b);
+  if (net->headf.d_part_v) (void)hipFree(net->headf.d_part_v);
+  if (net->headf.d_part_i) (void)hipFree(net->headf.d_part_i);
   for (auto& e : net->events) if (e) (void)hipEventDestroy(e);
   net->events.clear();
 }
@@ -864,6 +952,25 @@ extern "C" int32_t scpose_hrnet_forward(scpose_hrnet_t h, const void* in, int32_
                        static_cast<hipStream_t>(stream), false);
 }
 
+extern "C" int32_t scpose_hrnet_tail_fused(scpose_hrnet_t h, int32_t n, int32_t height, int32_t width, int32_t* fused) {
+  SCP_REQUIRE(h && fused, "hrnet_tail_fused: null argument");
+  SCP_REQUIRE(n > 0 && height > 0 && width > 0 && height % 32 == 0 && width % 32 == 0,
+              "hrnet_tail_fused: n=%d H=%d W=%d (H, W multiples of 32)", n, height, width);
+  *fused = hrnet_tail_fused(h, n, height, width) ? 1 : 0;
+  return SCPOSE_OK;
+}
+
+extern "C" int32_t scpose_hrnet_forward_decode(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n, int32_t height,
+                                               int32_t width, const float* center, const float* scale, int32_t post_process,
+                                               float* preds_xyc, float* heatmaps, void* workspace, size_t workspace_bytes,
+                                               void* stream) {
+  SCP_REQUIRE(h && in && center && scale && preds_xyc, "hrnet_forward_decode: null argument");
+  SCP_REQUIRE(h->desc.head == SCPOSE_HEAD_FINAL_LAYER || heatmaps, "hrnet_forward_decode: the hrnet_cms heads need a heat-map buffer");
+  const scpose::HeadDecode dec{center, scale, post_process, preds_xyc};
+  return hrnet_forward(h, in, in_fmt, n, height, width, heatmaps, workspace, workspace_bytes,
+                       static_cast<hipStream_t>(stream), false, -1, 0, nullptr, &dec);
+}
+
 struct scpose_hrnet_graph {
   scpose_hrnet* net = nullptr;
   hipGraph_t graph = nullptr;
@@ -892,10 +999,9 @@ extern "C" int32_t scpose_hrnet_graph_workspace_bytes(scpose_hrnet_t h, int32_t 
   return SCPOSE_OK;
 }
 
-extern "C" int32_t scpose_hrnet_graph_create(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n, int32_t height,
-                                             int32_t width, float* heatmaps, void* workspace, size_t workspace_bytes,
-                                             int32_t concurrent, scpose_hrnet_graph_t* out) {
-  SCP_REQUIRE(h && in && heatmaps && workspace && out, "hrnet_graph_create: null argument");
+static int32_t graph_create(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n, int32_t height,
+                            int32_t width, float* heatmaps, void* workspace, size_t workspace_bytes,
+                            int32_t concurrent, const scpose::HeadDecode* dec, scpose_hrnet_graph_t* out) {
   scpose_hrnet_graph* g = new (std::nothrow) scpose_hrnet_graph();
   if (!g) { set_error("hrnet_graph_create: out of host memory"); return SCPOSE_E_NOMEM; }
   g->net = h;
@@ -916,13 +1022,13 @@ extern "C" int32_t scpose_hrnet_graph_create(scpose_hrnet_t h, const void* in, i
   // tilings and kernel instantiations per layer): per-device kernel attributes (hipFuncSetAttribute), the zero page and the
   // tile memos all exist before hipStreamBeginCapture, so the capture records nothing but launches (scpose.h contract).
   int32_t rc = hrnet_forward(h, in, in_fmt, n, height, width, heatmaps, workspace, workspace_bytes, g->cap, false, -1, 1,
-                             concurrent ? &g->lanes : nullptr);
+                             concurrent ? &g->lanes : nullptr, dec);
   if (rc != SCPOSE_OK) return fail(rc);
   GC(hipStreamSynchronize(g->cap));   // the lanes were joined to g->cap at their epoch boundaries
   if (concurrent) for (auto& st : g->lanes.side) GC(hipStreamSynchronize(st));
   GC(hipStreamBeginCapture(g->cap, hipStreamCaptureModeThreadLocal));
   rc = hrnet_forward(h, in, in_fmt, n, height, width, heatmaps, workspace, workspace_bytes, g->cap, false, -1, 1,
-                     concurrent ? &g->lanes : nullptr);
+                     concurrent ? &g->lanes : nullptr, dec);
   const hipError_t ce = hipStreamEndCapture(g->cap, &g->graph);
   if (rc != SCPOSE_OK) return fail(rc);
   if (ce != hipSuccess) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ce)); return fail(SCPOSE_E_HIP); }
@@ -932,6 +1038,23 @@ extern "C" int32_t scpose_hrnet_graph_create(scpose_hrnet_t h, const void* in, i
 #undef GC
   *out = g;
   return SCPOSE_OK;
+}
+
+extern "C" int32_t scpose_hrnet_graph_create(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n, int32_t height,
+                                             int32_t width, float* heatmaps, void* workspace, size_t workspace_bytes,
+                                             int32_t concurrent, scpose_hrnet_graph_t* out) {
+  SCP_REQUIRE(h && in && heatmaps && workspace && out, "hrnet_graph_create: null argument");
+  return graph_create(h, in, in_fmt, n, height, width, heatmaps, workspace, workspace_bytes, concurrent, nullptr, out);
+}
+
+extern "C" int32_t scpose_hrnet_graph_create_decode(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n, int32_t height,
+                                                    int32_t width, const float* center, const float* scale, int32_t post_process,
+                                                    float* preds_xyc, float* heatmaps, void* workspace, size_t workspace_bytes,
+                                                    int32_t concurrent, scpose_hrnet_graph_t* out) {
+  SCP_REQUIRE(h && in && center && scale && preds_xyc && workspace && out, "hrnet_graph_create_decode: null argument");
+  SCP_REQUIRE(h->desc.head == SCPOSE_HEAD_FINAL_LAYER || heatmaps, "hrnet_graph_create_decode: the hrnet_cms heads need a heat-map buffer");
+  const scpose::HeadDecode dec{center, scale, post_process, preds_xyc};
+  return graph_create(h, in, in_fmt, n, height, width, heatmaps, workspace, workspace_bytes, concurrent, &dec, out);
 }
 
 extern "C" int32_t scpose_hrnet_graph_launch(scpose_hrnet_graph_t g, void* stream) {

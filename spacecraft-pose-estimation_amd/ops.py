@@ -338,6 +338,66 @@ class HrnetEngine:
         self._last_hw = (h, w)
         return out
 
+    def tail_fused(self, n, h, w):
+        """True when a forward of this shape runs the last fuse sum + final_layer (+ decode) as one kernel (head_fused.hip)."""
+        k = c_int32()
+        nat.check(nat.lib().scpose_hrnet_tail_fused(self._h, n, h, w, ctypes.byref(k)), "hrnet_tail_fused")
+        return bool(k.value)
+
+    def forward_decode(self, x, center, scale, post_process=True, heatmaps=False):
+        """Key points straight from the forward (scpose_hrnet_forward_decode): (N, J, 3) [x_img, y_img, maxval], bit-identical
+        to decode(forward(x), center, scale, post_process).  For pose_hrnet with a 1x1 final layer no heat-map is written
+        unless heatmaps=True (then (preds, heatmaps) is returned); other heads always go through a heat-map buffer."""
+        _need_cuda(x, center, scale)
+        x = x.contiguous()
+        if x.dtype == torch.uint8:
+            n, h, w, c = x.shape
+            fmt = nat.IN_U8_NHWC
+        else:
+            x = x.float()
+            n, c, h, w = x.shape
+            fmt = nat.IN_F32_NCHW
+        if c != 3:
+            raise nat.NativeError("HRNet input must have 3 channels, got %d" % c)
+        need = self.workspace_bytes(n, h, w)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        oh, ow = self.heatmap_size(h, w)
+        hm = None
+        if heatmaps or not self.tail_fused(n, h, w):
+            hm = torch.empty((n, self.num_joints, oh, ow), dtype=torch.float32, device=x.device)
+        cc = center.contiguous().float(); ss = scale.contiguous().float()
+        preds = torch.empty((n, self.num_joints, 3), dtype=torch.float32, device=x.device)
+        nat.check(nat.lib().scpose_hrnet_forward_decode(self._h, _ptr(x), fmt, n, h, w, _ptr(cc), _ptr(ss), int(bool(post_process)),
+                                                        _ptr(preds), _ptr(hm) if hm is not None else None, _ptr(self._ws),
+                                                        self._ws.numel(), _stream()), "hrnet_forward_decode")
+        self._last_hw = (h, w)
+        return (preds, hm) if heatmaps else preds
+
+    def capture_decode(self, x, center, scale, post_process=True, concurrent=True, heatmaps=False):
+        """capture() for forward_decode: x, center and scale are bound by address (refill them in place); .replay() returns
+        the bound (N, J, 3) key-point buffer; .heatmaps is the bound heat-map buffer when one exists."""
+        _need_cuda(x, center, scale)
+        for t, name in ((x, "input"), (center, "center"), (scale, "scale")):
+            if not t.is_contiguous():
+                raise nat.NativeError("capture_decode: the %s buffer must be contiguous (it is bound by address)" % name)
+        if center.dtype != torch.float32 or scale.dtype != torch.float32:
+            raise nat.NativeError("capture_decode: center / scale must be float32")
+        if x.dtype == torch.uint8:
+            n, h, w, c = x.shape
+            fmt = nat.IN_U8_NHWC
+        elif x.dtype == torch.float32:
+            n, c, h, w = x.shape
+            fmt = nat.IN_F32_NCHW
+        else:
+            raise nat.NativeError("capture_decode: input must be uint8 NHWC or float32 NCHW")
+        oh, ow = self.heatmap_size(h, w)
+        hm = None
+        if heatmaps or not self.tail_fused(n, h, w):
+            hm = torch.empty((n, self.num_joints, oh, ow), dtype=torch.float32, device=x.device)
+        preds = torch.empty((n, self.num_joints, 3), dtype=torch.float32, device=x.device)
+        return HrnetGraph(self, x, fmt, (n, h, w), preds, concurrent, decode=(center, scale, bool(post_process), hm))
+
     def capture(self, x, out=None, concurrent=True):
         """Record the forward of the input BUFFER x (uint8 NHWC or float32 NCHW, fixed shape) into a hipGraph and return
         an HrnetGraph: refill x in place (x.copy_(...)), call .replay(), read .out.  concurrent=True (1) records the
@@ -449,7 +509,7 @@ class HrnetEngine:
 class HrnetGraph:
     """A captured forward (scpose_hrnet_graph_*): fixed input / output / workspace buffers, one launch per replay."""
 
-    def __init__(self, engine, x, fmt, nhw, out, concurrent):
+    def __init__(self, engine, x, fmt, nhw, out, concurrent, decode=None):
         n, h, w = nhw
         b = c_size_t()
         nat.check(nat.lib().scpose_hrnet_graph_workspace_bytes(engine._h, n, h, w, ctypes.byref(b)), "hrnet_graph_workspace_bytes")
@@ -458,9 +518,17 @@ class HrnetGraph:
         torch.cuda.synchronize(x.device)     # create runs one eager forward on an internal stream: every pending write to x / out,
                                              # on any stream of x's device (not only the current one), must have landed
         g = c_void_p()
+        self.heatmaps = None
         with torch.cuda.device(x.device):
-            nat.check(nat.lib().scpose_hrnet_graph_create(engine._h, _ptr(x), fmt, n, h, w, _ptr(out), _ptr(self._ws), self._ws.numel(),
-                                                          int(concurrent), ctypes.byref(g)), "hrnet_graph_create")
+            if decode is None:
+                nat.check(nat.lib().scpose_hrnet_graph_create(engine._h, _ptr(x), fmt, n, h, w, _ptr(out), _ptr(self._ws), self._ws.numel(),
+                                                              int(concurrent), ctypes.byref(g)), "hrnet_graph_create")
+            else:   # out = the key-point buffer; the decode's inputs are bound like x
+                self.center, self.scale, post, self.heatmaps = decode
+                nat.check(nat.lib().scpose_hrnet_graph_create_decode(
+                    engine._h, _ptr(x), fmt, n, h, w, _ptr(self.center), _ptr(self.scale), int(post), _ptr(out),
+                    _ptr(self.heatmaps) if self.heatmaps is not None else None, _ptr(self._ws), self._ws.numel(), int(concurrent),
+                    ctypes.byref(g)), "hrnet_graph_create_decode")
         self._g = g
         k = c_int32()
         nat.check(nat.lib().scpose_hrnet_graph_nodes(self._g, ctypes.byref(k)), "hrnet_graph_nodes")
