@@ -154,6 +154,20 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
     mxA[n] = okA[n] ? pidx - myA[n] * 18 : 0;
     offA[n] = (myA[n] * 20 + mxA[n]) * 16;
   }
+  // A tile whose left neighbour was this workgroup's previous tile re-uses that tile's two rightmost intermediate columns
+  // (the same image pixels: they are copied inside LDS between the tiles) and evaluates conv1 only on its 18 x 16 new
+  // pixels: one MFMA column per intermediate row (18 columns instead of 21; five of the six tiles of a 96-pixel row).
+  // The chip is power-limited in this kernel: 12 % fewer conv1 MFMAs are time, not just idle issue slots.
+  int offN[3], myN[3], slotN[3];
+  bool okN[3];
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    const int c = n * 8 + wave;            // intermediate row
+    okN[n] = c < 18;
+    myN[n] = okN[n] ? c : 0;
+    offN[n] = (myN[n] * 20 + 2 + r) * 16;
+    slotN[n] = (myN[n] * 18 + 2 + r) * 16;
+  }
   // phase C columns: output pixels (n*8 + wave)*16 + r, n = 0..1; after the lane exchange the lower half-wave
   // owns column 0's pixel, the upper half-wave column 1's
   int offB[2];
@@ -236,6 +250,7 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
     int img, oy0, ox0;
     decode(t, img, oy0, ox0);
     f32x4 acc[MREP][3];
+    const bool narrow = t > t_begin && ox0 > 0;          // columns 0, 1 of the intermediate tile are already there (see offN)
 
     // ---- A: conv1 -> intermediate tile ----
 #pragma unroll
@@ -244,8 +259,8 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
       for (int n = 0; n < 3; ++n) acc[m][n] = f32x4{bs1[m].x, bs1[m].y, bs1[m].z, bs1[m].w};   // accumulators start at the bias of their rows
     // 21 columns over 8 waves: waves 0-4 have a third column, waves 5-7 do not (their third accumulators are never written out);
     // they run the two-column loop instead of spending 42 MFMAs per tile on a column nobody reads
-    if (wave < 5) kloop(std::integral_constant<int, 3>{}, w1l, xl, kA, offA, acc);
-    else kloop(std::integral_constant<int, 2>{}, w1l, xl, kA, offA, acc);
+    if (wave < (narrow ? 2 : 5)) kloop(std::integral_constant<int, 3>{}, w1l, xl, kA, narrow ? offN : offA, acc);
+    else kloop(std::integral_constant<int, 2>{}, w1l, xl, kA, narrow ? offN : offA, acc);
     const unsigned long long t1 = now();
     // residual slots of this lane's output pixel (the centre of the input tile), kept in registers until the end
     u32x4 resv[MREP];
@@ -254,16 +269,18 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
       resv[m] = *reinterpret_cast<const u32x4*>(xl + (2 * m + psel) * XS + ((opy + 2) * 20 + opx + 2) * 16);
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
-      const int gy = oy0 - 1 + myA[n], gx = ox0 - 1 + mxA[n];
+      const int gy = oy0 - 1 + (narrow ? myN[n] : myA[n]), gx = ox0 - 1 + (narrow ? 2 + r : mxA[n]);
       const bool inimg = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      const bool okn = narrow ? okN[n] : okA[n];
+      const int slot = narrow ? slotN[n] : ((n * 8 + wave) * 16 + r) * 16;
 #pragma unroll
       for (int m = 0; m < MREP; ++m) {
         uint2 o;
         o.x = relu2_16(pack2<T>(acc[m][n][0], acc[m][n][1]), 0u);
         o.y = relu2_16(pack2<T>(acc[m][n][2], acc[m][n][3]), 0u);
         if (!inimg) o = make_uint2(0u, 0u);              // conv2's zero padding
-        if (okA[n])
-          *reinterpret_cast<uint2*>(ml + (2 * m + psel) * MS + ((n * 8 + wave) * 16 + r) * 16 + 8 * (q >> 1)) = o;
+        if (okn)
+          *reinterpret_cast<uint2*>(ml + (2 * m + psel) * MS + slot + 8 * (q >> 1)) = o;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -318,8 +335,22 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
     const unsigned long long t6 = now();
     // (the next input tile has landed: waited for in front of the stores, above.  Deferring the conv2 epilogue of waves 4-7 into the
     // next tile -- a stagger between the two waves of a SIMD -- measured no gain.)
+    // the two rightmost intermediate columns become the next tile's two leftmost ones when that tile is this one's right
+    // neighbour: read here (the intermediate tile is read-only in this phase), written behind the barrier (nobody reads
+    // the intermediate tile then, and conv1 of the next tile writes columns 2..17 only)
+    bool keep_next = false;
+    u32x4 keep = {0u, 0u, 0u, 0u};
+    if (t + 1 < t_end) {
+      int img1, oy1, ox1;
+      decode(t + 1, img1, oy1, ox1);
+      keep_next = ox1 > 0;
+    }
+    const int kpl = tid / 36, krem = tid - kpl * 36;                // plane, (row, column 16 / 17)
+    const bool keeper = keep_next && tid < PLANES * 36;
+    if (keeper) keep = *reinterpret_cast<const u32x4*>(ml + kpl * MS + ((krem >> 1) * 18 + 16 + (krem & 1)) * 16);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                   // ... and the intermediate tile is free again
+    if (keeper) *reinterpret_cast<u32x4*>(ml + kpl * MS + ((krem >> 1) * 18 + (krem & 1)) * 16) = keep;
     if (SCP_DBG_BUF(p)) {   // [conv1 loop][conv1 epilogue][barrier][DMA issue][conv2 loop][conv2 epilogue + end wait/barrier]
       const unsigned long long t7 = now();
       tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; tph[3] += t4 - t3; tph[4] += t5 - t4; tph[5] += t7 - t5;
