@@ -2,7 +2,7 @@
 #include <stdlib.h>
 #include <type_traits>
 
-#include "conv_block_kernel.h"
+#include "conv_block2_kernel.h"
 
 namespace scpose {
 
@@ -43,6 +43,12 @@ int32_t block_launch(const PackedConv& c1, const PackedConv& c2, const void* in,
     L.dbg_buf = (dbg & 8) ? conv_dbg_buffer(stream) : nullptr;
     if (dbg & 8) conv_dbg_set_grid(L.grid); }
   const int mrep = c1.cin / 16;
+  // second form (conv_block2_kernel.h: one layer per wave, weights in registers) unless the tensor needs 64-bit addressing
+  static const char* v1 = dev_env("SCPOSE_BLOCK_V1");
+  if (L.bytes != 0 && !(v1 && atoi(v1))) {
+    if (c1.dtype == SCPOSE_DT_BF16) return mrep == 3 ? block2_launch_one<0, 3>(L, stream) : block2_launch_one<0, 2>(L, stream);
+    return mrep == 3 ? block2_launch_one<1, 3>(L, stream) : block2_launch_one<1, 2>(L, stream);
+  }
   if (c1.dtype == SCPOSE_DT_BF16) {
     if (mrep == 3) return block_launch_one<0, 3>(L, stream);
     return block_launch_one<0, 2>(L, stream);

@@ -112,6 +112,7 @@ extern "C" void scpose_dbg_dump(void) {
   int nw = 0;
   for (int i = 0; i < g_dbg_grid * 8; ++i) { double t = 0; for (int k = 0; k < 6; ++k) { sum[k] += (double)h[i * 6 + k]; t += (double)h[i * 6 + k]; } nw += t > 0; }
   for (int k = 0; k < 6; ++k) tot += sum[k];
+  printf("  (%d workgroups, %d waves with stamps)\n", g_dbg_grid, nw);
   for (int k = 0; k < 6; ++k) printf("  %-26s %10.0f cycles/wave  %5.1f%%\n", names[k], sum[k] / (nw ? nw : 1), 100 * sum[k] / tot);
   // role-split kernels: waves 0-3 and 4-7 of each workgroup separately (slot meaning differs per role)
   for (int role = 0; role < 2; ++role) {
