@@ -132,6 +132,8 @@ __global__ __launch_bounds__(512, 2) void conv_block2_kernel(const BlockLaunch p
     });
   };
 
+  // (s_setprio 3 on the conv2 waves shortens their k-loops 4.5k -> 3.4k cycles per tile and lengthens their epilogues and the
+  // conv1 waves' loops by as much: no gain, not kept)
   if (role == 1 && ntiles > 0) issue_x(t_begin, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
