@@ -68,23 +68,28 @@ __global__ __launch_bounds__(512, 2) void conv_block2_kernel(const BlockLaunch p
   // input tile (20 x 20 halo of the 16 x 16 outputs) by LDS-DMA: issued by the four conv2 waves (they have the shorter step:
   // 672 against 882 MFMAs per tile), pixel slots rtid and rtid + 256.  (An LDS-DMA instruction blocks its wave while the path
   // is busy; splitting the planes between the two layers' waves made BOTH block as long: +4 %.)
-  auto issue_x = [&](int t, int b) {
+  // slot group i (pixel slots rtid + 256 i) of tile t: the lane's offset in x, or BUF_OOB (padding: read as zeros)
+  auto x_voff = [&](int t, int i) -> uint32_t {
     int img, oy0, ox0;
     decode(t, img, oy0, ox0);
-    char* xl = xl0 + b * (PLANES * XS);
     int rt = rtid;
     asm volatile("" : "+v"(rt));   // per-lane geometry is recomputed per tile, not hoisted out of the tile loop: the registers belong to the weights
+    const int slot = rt + 256 * i;
+    const int hy = slot / 20, hx = slot - hy * 20;
+    const int iy = oy0 - 2 + hy, ix = ox0 - 2 + hx;
+    const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    return ok ? (uint32_t)(img * PLANES * HW + iy * p.W + ix) * 16u : BUF_OOB;
+  };
+  auto x_dma = [&](uint32_t voff, int i, int pl, int b) {   // one LDS-DMA instruction: plane pl of slot group i into buffer b
+    if (rtid + 256 * i < 400)    // lanes past the plane's last slot stay inactive: their LDS write would land in the next plane
+      dma16_buf(rs_in, voff, (uint32_t)(pl * HW) * 16u, xl0 + b * (PLANES * XS) + pl * XS + (rw * 64 + 256 * i) * 16);
+  };
+  auto issue_x = [&](int t, int b) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int slot = rt + 256 * i;
-      const int hy = slot / 20, hx = slot - hy * 20;
-      const int iy = oy0 - 2 + hy, ix = ox0 - 2 + hx;
-      const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      const uint32_t voff = ok ? (uint32_t)(img * PLANES * HW + iy * p.W + ix) * 16u : BUF_OOB;   // padding: read as zeros
-      if (slot < 400) {   // lanes past the plane's last slot stay inactive: their LDS write would land in the next plane
+      const uint32_t voff = x_voff(t, i);
 #pragma unroll
-        for (int pl = 0; pl < PLANES; ++pl) dma16_buf(rs_in, voff, (uint32_t)(pl * HW) * 16u, xl + pl * XS + (rw * 64 + 256 * i) * 16);
-      }
+      for (int pl = 0; pl < PLANES; ++pl) x_dma(voff, i, pl, b);
     }
   };
 
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void conv_block2_kernel(const BlockLaunch p
 
   // k-loop: NCOL columns, the layer's A fragments from registers, B fragments two k-steps ahead (a k-step is 3-6 MFMAs = 48-96
   // cycles on this wave's pipe: less than an LDS read takes when the other seven waves read too)
-  auto kloop = [&](auto ncol_c, auto role_c, const char* tile, const int* pixoff, f32x4 (*acc)[3]) {
+  auto kloop = [&](auto ncol_c, auto role_c, const char* tile, const int* pixoff, f32x4 (*acc)[3], auto&& side) {
     constexpr int NCOL = decltype(ncol_c)::value;
     constexpr int ROLE = decltype(role_c)::value;
     constexpr int PS = ROLE ? MS : XS, ROWW = ROLE ? 18 : 20;
@@ -128,6 +133,7 @@ __global__ __launch_bounds__(512, 2) void conv_block2_kernel(const BlockLaunch p
       for (int m = 0; m < MREP; ++m)
 #pragma unroll
         for (int n = 0; n < NCOL; ++n) acc[m][n] = mfma16<T>(wf[S][m], bf[S % 3][n], acc[m][n]);
+      side(sc);                       // (conv2 waves: one LDS-DMA instruction of the next input tile behind this k-step's MFMAs)
       __builtin_amdgcn_sched_barrier(0);
     });
   };
@@ -191,8 +197,9 @@ __global__ __launch_bounds__(512, 2) void conv_block2_kernel(const BlockLaunch p
             for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{b4.x, b4.y, b4.z, b4.w};   // accumulators start at the bias of their rows
           }
           const unsigned long long s1 = now();
-          if (ncol == 2) kloop(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, xl, pixoff, acc);
-          else kloop(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, xl, pixoff, acc);
+          auto none = [](auto) {};
+          if (ncol == 2) kloop(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, xl, pixoff, acc, none);
+          else kloop(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, xl, pixoff, acc, none);
           const unsigned long long s2 = now();
           tph[1] += s2 - s1;
 #pragma unroll
@@ -217,7 +224,11 @@ __global__ __launch_bounds__(512, 2) void conv_block2_kernel(const BlockLaunch p
       }
     } else {
       const unsigned long long s0 = now();
-      if (i + 1 < ntiles) issue_x(t_begin + i + 1, (i + 1) & 1);   // that buffer held tile i - 1: conv1 finished reading it a barrier ago
+      // the next input tile (its buffer held tile i - 1: conv1 finished reading it a barrier ago) is requested from inside the k-loops
+      // below, one LDS-DMA instruction per k-step: an LDS-DMA instruction blocks its wave while the path is busy (~140 cycles each
+      // with four waves issuing), which the MFMAs already issued for the k-step cover -- up front, the twelve of them cost
+      // the conv2 waves 1 700 cycles per tile.  Step 0 has no k-loop: there the tile is requested here.
+      if (i == 0 && 1 < ntiles) issue_x(t_begin + 1, 1);
       // the two rightmost intermediate columns of tile i - 1 are the two leftmost ones of tile i when that is its right neighbour
       // (the same image pixels): copied from this step's read-only intermediate buffer into the one conv1 is filling, whose
       // conv1 then skips them (NARROW below)
@@ -259,7 +270,14 @@ __global__ __launch_bounds__(512, 2) void conv_block2_kernel(const BlockLaunch p
             acc[m][0] = f32x4{b4.x, b4.y, b4.z, b4.w}; acc[m][1] = acc[m][0];
           }
           const unsigned long long s1 = now();
-          kloop(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, ml, pixoff, acc);
+          // (slot group = pass; all twelve in the first pass would need one more register than there is)
+          const bool dma_on = i + 1 < ntiles;
+          const uint32_t xv = dma_on ? x_voff(t_begin + i + 1, pass) : BUF_OOB;
+          auto side = [&](auto sc) {
+            constexpr int S = decltype(sc)::value;
+            if constexpr (S < PLANES) { if (dma_on) x_dma(xv, pass, S, (i + 1) & 1); }
+          };
+          kloop(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, ml, pixoff, acc, side);
           const unsigned long long s2 = now();
           tph[1] += s2 - s1;
 #pragma unroll
