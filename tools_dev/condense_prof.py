@@ -28,7 +28,7 @@ def op_classes():
     eng = ops.HrnetEngine(cfg, syn.random_checkpoint(cfg, 0), dtype=dtype)
     x = torch.randint(0, 256, (batch, image, image, 3), dtype=torch.uint8, device="cuda")
     eng.forward(x, profile=True)
-    recs = eng.profile_read()
+    recs = [r for r in eng.profile_read() if not (r["kind"] == 2 and r["bytes_per_frame"] == 0)]   # the fuse row the fused tail absorbs launches nothing
     names = eng.kernel_classes(recs)
     return names, {c: (r["flops_per_frame"] * batch, r["bytes_per_frame"] * batch) for c, r in zip(names, recs)}
 

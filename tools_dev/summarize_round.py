@@ -27,7 +27,25 @@ def q(s):
     return '"%s"' % s if "," in s else s
 
 
-main = json.load(open(os.path.join(g, "w48_b256", "summary.json")))
+def _plain_names(summary):
+    """Classes condensed with an '@pixels' suffix that is not needed (one map size per layer shape) get their plain name back."""
+    names = [e["class"] for e in summary.get("class_stats", [])]
+    ren = {}
+    for c in names:
+        base = c.split("@")[0]
+        if "@" in c and sum(1 for d in names if d.split("@")[0] == base) == 1:
+            ren[c] = base
+    if not ren:
+        return summary
+    for e in summary["class_stats"]:
+        e["class"] = ren.get(e["class"], e["class"])
+    for key in ("work_per_launch", "pmc"):
+        if key in summary:
+            summary[key] = {ren.get(k, k): v for k, v in summary[key].items()}
+    return summary
+
+
+main = _plain_names(json.load(open(os.path.join(g, "w48_b256", "summary.json"))))
 work = main["work_per_launch"]
 pmc = main["pmc"]
 rows = ["class,kernel,launches_per_forward,dispatches,median_us,p95_us,mean_us,min_us,max_us,share_of_forward,alg_GFLOP_per_launch,alg_MB_per_launch,TFLOPs_at_median,GBs_at_median"]
