@@ -270,7 +270,10 @@ __global__ __launch_bounds__(512, 2) void conv_block2_kernel(const BlockLaunch p
             acc[m][0] = f32x4{b4.x, b4.y, b4.z, b4.w}; acc[m][1] = acc[m][0];
           }
           const unsigned long long s1 = now();
-          // (slot group = pass; all twelve in the first pass would need one more register than there is)
+          // (slot group = pass; all twelve in the first pass would need one more register than there is.  One per k-step in the
+          // FIRST six k-steps of the pass: spread over every other k-step the block takes 241 instead of 206 us -- both layers'
+          // k-loops slow down while DMA data is arriving, and the tile lands later.  Issuing them and the residual loads as
+          // inline asm with hand-counted waits, so that the compiler's conservative waits behind LDS-DMA disappear: no change.)
           const bool dma_on = i + 1 < ntiles;
           const uint32_t xv = dma_on ? x_voff(t_begin + i + 1, pass) : BUF_OOB;
           auto side = [&](auto sc) {
