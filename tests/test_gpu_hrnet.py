@@ -395,3 +395,24 @@ def test_fused_bottleneck_matches_oracle(gpu_ops, h, w, n, dt):
     print("layer1 %dx%d %s: worst %.1f ulps, mean %.3f ulps" % (h, w, dt, u.max().item(), u.mean().item()))
     assert u.max().item() <= max_ulps and u.mean().item() <= mean_ulps
     eng.close()
+
+
+@pytest.mark.parametrize("n", [1, 7, 9, 17])
+def test_layer1_is_batch_invariant_under_the_xcd_local_tile_queue(gpu_ops, n):
+    """The Bottleneck kernels take their tiles from per-XCD queues (conv_device.h: tile_claim_xcd: XCD k owns the tiles of images
+    k, k + 8, ...; empty lists steal from the next XCD's) and the fused BasicBlock runs conv1 of tile i beside conv2 of tile
+    i - 1 (conv_block2_kernel.h): a frame's result must not depend on how many frames share the launch -- batches that leave
+    XCD lists empty (n < 8), uneven (9, 17) or single -- nor on the run."""
+    cfg = R.w32_cfg()
+    sd = R.make_state_dict(cfg, seed=31)
+    g = torch.Generator().manual_seed(100 + n)
+    u8 = torch.randint(0, 256, (n, 96, 160, 3), generator=g, dtype=torch.uint8).cuda()
+    eng = gpu_ops.HrnetEngine(cfg, sd, dtype="bf16")
+    for tap in ("layer1", "stage2.0.out0"):
+        full = eng.forward_tap(u8, tap)
+        again = eng.forward_tap(u8, tap)
+        assert torch.equal(full, again), "%s differs from run to run" % tap
+        for k in sorted({0, n // 2, n - 1}):
+            one = eng.forward_tap(u8[k:k + 1].contiguous(), tap)
+            assert torch.equal(one[0], full[k]), "%s: frame %d of %d differs from the same frame run alone" % (tap, k, n)
+    eng.close()
