@@ -85,8 +85,8 @@ def parse():
                     help="un-profiled steps replay the forward from a hipGraph (scpose_hrnet_graph_*): 1 = every independent group of ops "
                          "on concurrent lanes (branches of a module, fuse rows, transition convolutions), 2 = only the fuse rows and "
                          "transition convolutions (short HBM-bound launches) side by side, the branches one after the other; 0: eager "
-                         "launches; default: 1 for batches <= 128 (W32 batch 64: -19 %%), 2 above (W48 batch 256: -0.3 ms; the "
-                         "MFMA-bound branch kernels each fill the chip and only contend when run side by side)")
+                         "launches; default: 1 (W32 batch 64: -19 %%; W48 batch 256: 27.8 vs 28.0 ms per step with 2 and 28.0 serial, "
+                         "same box -- until the persistent kernels took their tiles from queues, 2 was the faster one there)")
     ap.add_argument("--fused-decode", type=int, default=1,
                     help="1: key points from scpose_hrnet_forward_decode (decode inside the network's last kernel, no heat-map round trip); "
                          "0: scpose_hrnet_forward, then scpose_decode on the side stream")
@@ -178,7 +178,7 @@ def main():
     eng = ops.HrnetEngine(cfg, sd, dtype=args.dtype, device=dev)
     B = args.batch
     if args.graph < 0:
-        args.graph = 1 if B <= 128 else 2
+        args.graph = 1
     hh = image // 4
 
     # ---- synthetic inputs, resident in HBM before the timed region (shard = rank's slice) ----
