@@ -5,13 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, scpose
 from importlib import import_module
 ops = import_module("spacecraft-pose-estimation_amd.ops")
-from oracle import hrnet_ref as R
+syn = import_module("spacecraft-pose-estimation_amd.synthetic")   # product-side cfg / random checkpoint (no oracle/ in timing scripts)
 which = sys.argv[1] if len(sys.argv) > 1 else "w48"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 size = 384 if which == "w48" else 256
-cfg = R.w48_cfg() if which == "w48" else R.w32_cfg()
-eng = ops.HrnetEngine(cfg, R.make_state_dict(cfg, seed=0), dtype="bf16")
+cfg = syn.hrnet_cfg(48 if which == "w48" else 32, 11, 384 if which == "w48" else 256)
+eng = ops.HrnetEngine(cfg, syn.random_checkpoint(cfg, 0), dtype="bf16")
 x = torch.randint(0, 256, (n, size, size, 3), dtype=torch.uint8, device="cuda")
 for _ in range(reps):
     eng(x)
