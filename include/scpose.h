@@ -22,6 +22,14 @@
  *     thread-safe; distinct handles are independent.  The only process-wide state is the
  *     per-device memoisation above (idempotent, indexed by device id) and the thread-local
  *     error message.
+ *   - ONE STREAM PER HANDLE AT A TIME: besides its read-only weights a handle owns a few words
+ *     of mutable device state -- the dynamic tile queues of its persistent kernels (16 words
+ *     per layer, self-resetting at the end of each launch).  All launches that use one handle
+ *     -- eager forwards AND replays of graphs captured from it -- must therefore be ordered
+ *     with respect to each other (same stream, or event dependencies); two forwards of one
+ *     handle in flight at once would claim tiles from the same queue.  Every other buffer a
+ *     forward writes lies in the caller's workspace.  For concurrent forwards create one
+ *     handle per stream.
  *   - "blocked" activation layout used between layers: [N][C/8][H][W][8] 16-bit elements
  *     (bf16 or f16), C a multiple of 8.
  */

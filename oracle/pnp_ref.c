@@ -19,7 +19,8 @@
  * Notable OpenCV behaviours kept:
  *   - float64 object points are converted to float32 on entry to solvePnPRansac; image points
  *     arrive as float32; inside RANSAC everything is float32 in, float64 arithmetic;
- *   - minimal sample = 5 points for EPnP (P3P only when exactly 4 points are given);
+ *   - minimal sample = 5 points for EPnP; with exactly 4 usable points solvePnPRansac calls solvePnP(SOLVEPNP_P3P)
+ *     directly (p3p.cpp: Gao's P3P on the first three points, the fourth picks among up to four poses);
  *   - RNG is cv::RNG((uint64)-1) (MWC, coefficient 4164903690), uniform(0,count) = next % count;
  *   - undistortPoints: 5 fixed-point iterations; RANSAC error = squared pixel distance of the
  *     float32-rounded projection (with distortion), threshold 15^2, compared in float32;
@@ -660,6 +661,314 @@ static void solve_pnp_epnp(const camera* cam, const double* obj, const double* i
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* p3p.cpp + polynom_solver.cpp: the kernel solvePnPRansac switches to for exactly four points  */
+/* ------------------------------------------------------------------------------------------ */
+/* OpenCV 3.4 solvepnp.cpp, solvePnPRansac: `else if (npoints == 4) { model_points = 4; ransac_kernel_method = SOLVEPNP_P3P; }`
+ * followed by `if (model_points == npoints) return solvePnP(opoints, ipoints, K, dist, rvec, tvec, false, ransac_kernel_method)`:
+ * with four usable landmarks there is no RANSAC at all; solvePnP(SOLVEPNP_P3P) undistorts the (float32) image points,
+ * p3p::extract_points maps them back to pixels (x * fx + cx), p3p::solve finds up to four poses from the first three
+ * correspondences (X.S. Gao et al., "Complete solution classification for the perspective-three-point problem", PAMI 2003:
+ * solve_for_lengths -> quartic, then Horn's quaternion alignment) and keeps the one that reprojects the fourth point best. */
+static int solve_deg2(double a, double b, double c, double* x1, double* x2) {
+  double delta = b * b - 4 * a * c, inv_2a, sqrt_delta;
+  if (delta < 0) return 0;
+  inv_2a = 0.5 / a;
+  if (delta == 0) { *x1 = -b * inv_2a; *x2 = *x1; return 1; }
+  sqrt_delta = sqrt(delta);
+  *x1 = (-b + sqrt_delta) * inv_2a;
+  *x2 = (-b - sqrt_delta) * inv_2a;
+  return 2;
+}
+
+static int solve_deg3(double a, double b, double c, double d, double* x0, double* x1, double* x2) {
+  double inv_a, b_a, b_a2, c_a, d_a, Q, R, Q3, D, b_a_3, AD, BD;
+  if (a == 0) {
+    if (b == 0) {
+      if (c == 0) return 0;
+      *x0 = -d / c;
+      return 1;
+    }
+    *x2 = 0;
+    return solve_deg2(b, c, d, x0, x1);
+  }
+  inv_a = 1. / a;
+  b_a = inv_a * b; b_a2 = b_a * b_a;
+  c_a = inv_a * c;
+  d_a = inv_a * d;
+  Q = (3 * c_a - b_a2) / 9;
+  R = (9 * b_a * c_a - 27 * d_a - 2 * b_a * b_a2) / 54;
+  Q3 = Q * Q * Q;
+  D = Q3 + R * R;
+  b_a_3 = (1. / 3.) * b_a;
+  if (Q == 0) {
+    if (R == 0) { *x0 = *x1 = *x2 = -b_a_3; return 3; }
+    *x0 = pow(2 * R, 1 / 3.0) - b_a_3;
+    return 1;
+  }
+  if (D <= 0) {   /* three real roots */
+    double theta = acos(R / sqrt(-Q3));
+    double sqrt_Q = sqrt(-Q);
+    *x0 = 2 * sqrt_Q * cos(theta / 3.0) - b_a_3;
+    *x1 = 2 * sqrt_Q * cos((theta + 2 * 3.1415926535897932384626433832795) / 3.0) - b_a_3;
+    *x2 = 2 * sqrt_Q * cos((theta + 4 * 3.1415926535897932384626433832795) / 3.0) - b_a_3;
+    return 3;
+  }
+  AD = pow(fabs(R) + sqrt(D), 1.0 / 3.0) * (R > 0 ? 1 : (R < 0 ? -1 : 0));
+  BD = (AD == 0) ? 0 : -Q / AD;
+  *x0 = AD + BD - b_a_3;
+  return 1;
+}
+
+static int solve_deg4(double a, double b, double c, double d, double e, double* x0, double* x1, double* x2, double* x3) {
+  double inv_a, b2, bc, b3, r0, r1, r2, R2, R, inv_R, D2, E2, b_4, R_2;
+  int n, nb_real_roots = 0;
+  if (a == 0) { *x3 = 0; return solve_deg3(b, c, d, e, x0, x1, x2); }
+  inv_a = 1. / a;
+  b *= inv_a; c *= inv_a; d *= inv_a; e *= inv_a;
+  b2 = b * b; bc = b * c; b3 = b2 * b;
+  n = solve_deg3(1, -c, d * b - 4 * e, 4 * c * e - d * d - b2 * e, &r0, &r1, &r2);
+  if (n == 0) return 0;
+  R2 = 0.25 * b2 - c + r0;
+  if (R2 < 0) return 0;
+  R = sqrt(R2);
+  inv_R = 1. / R;
+  if (R < 10E-12) {
+    double temp = r0 * r0 - 4 * e;
+    if (temp < 0) D2 = E2 = -1;
+    else {
+      double sqrt_temp = sqrt(temp);
+      D2 = 0.75 * b2 - 2 * c + 2 * sqrt_temp;
+      E2 = D2 - 4 * sqrt_temp;
+    }
+  } else {
+    double u = 0.75 * b2 - 2 * c - R2, v = 0.25 * inv_R * (4 * bc - 8 * d - b3);
+    D2 = u + v;
+    E2 = u - v;
+  }
+  b_4 = 0.25 * b; R_2 = 0.5 * R;
+  if (D2 >= 0) {
+    double D = sqrt(D2), D_2 = 0.5 * D;
+    nb_real_roots = 2;
+    *x0 = R_2 + D_2 - b_4;
+    *x1 = *x0 - D;
+  }
+  if (E2 >= 0) {
+    double E = sqrt(E2), E_2 = 0.5 * E;
+    if (nb_real_roots == 0) {
+      *x0 = -R_2 + E_2 - b_4;
+      *x1 = *x0 - E;
+      nb_real_roots = 2;
+    } else {
+      *x2 = -R_2 + E_2 - b_4;
+      *x3 = *x2 - E;
+      nb_real_roots = 4;
+    }
+  }
+  return nb_real_roots;
+}
+
+/* p3p::jacobi_4x4: cyclic Jacobi on the symmetric 4 x 4 A (upper triangle used and destroyed); D eigenvalues, U eigenvectors in columns */
+static int jacobi_4x4(double* A, double* D, double* U) {
+  double B[4], Z[4];
+  int iter, i, j, k;
+  for (i = 0; i < 16; i++) U[i] = (i % 5 == 0) ? 1. : 0.;
+  B[0] = A[0]; B[1] = A[5]; B[2] = A[10]; B[3] = A[15];
+  memcpy(D, B, 4 * sizeof(double));
+  memset(Z, 0, 4 * sizeof(double));
+  for (iter = 0; iter < 50; iter++) {
+    double sum = fabs(A[1]) + fabs(A[2]) + fabs(A[3]) + fabs(A[6]) + fabs(A[7]) + fabs(A[11]);
+    double tresh;
+    if (sum == 0.0) return 1;
+    tresh = (iter < 3) ? 0.2 * sum / 16. : 0.0;
+    for (i = 0; i < 3; i++) {
+      double* pAij = A + 5 * i + 1;
+      for (j = i + 1; j < 4; j++) {
+        double Aij = *pAij;
+        double eps_machine = 100.0 * fabs(Aij);
+        if (iter > 3 && fabs(D[i]) + eps_machine == fabs(D[i]) && fabs(D[j]) + eps_machine == fabs(D[j]))
+          *pAij = 0.0;
+        else if (fabs(Aij) > tresh) {
+          double hh = D[j] - D[i], t, c, s, tau;
+          if (fabs(hh) + eps_machine == fabs(hh))
+            t = Aij / hh;
+          else {
+            double theta = 0.5 * hh / Aij;
+            t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+            if (theta < 0.0) t = -t;
+          }
+          hh = t * Aij;
+          Z[i] -= hh; Z[j] += hh;
+          D[i] -= hh; D[j] += hh;
+          *pAij = 0.0;
+          c = 1.0 / sqrt(1 + t * t);
+          s = t * c;
+          tau = s / (1.0 + c);
+          for (k = 0; k <= i - 1; k++) {
+            double g = A[k * 4 + i], h = A[k * 4 + j];
+            A[k * 4 + i] = g - s * (h + g * tau);
+            A[k * 4 + j] = h + s * (g - h * tau);
+          }
+          for (k = i + 1; k <= j - 1; k++) {
+            double g = A[i * 4 + k], h = A[k * 4 + j];
+            A[i * 4 + k] = g - s * (h + g * tau);
+            A[k * 4 + j] = h + s * (g - h * tau);
+          }
+          for (k = j + 1; k < 4; k++) {
+            double g = A[i * 4 + k], h = A[j * 4 + k];
+            A[i * 4 + k] = g - s * (h + g * tau);
+            A[j * 4 + k] = h + s * (g - h * tau);
+          }
+          for (k = 0; k < 4; k++) {
+            double g = U[k * 4 + i], h = U[k * 4 + j];
+            U[k * 4 + i] = g - s * (h + g * tau);
+            U[k * 4 + j] = h + s * (g - h * tau);
+          }
+        }
+        pAij++;
+      }
+    }
+    for (i = 0; i < 4; i++) B[i] += Z[i];
+    memcpy(D, B, 4 * sizeof(double));
+    memset(Z, 0, 4 * sizeof(double));
+  }
+  return 0;
+}
+
+/* p3p::align: rigid motion taking the three world points X onto the camera-frame points M_end (Horn, unit quaternion) */
+static void p3p_align(double M_end[3][3], const double* X /* 3 x 3, row = point */, double R[3][3], double T[3]) {
+  double C_start[3], C_end[3], s[9], Qs[16], evs[4], U[16], q[4], ev_max;
+  double q02, q12, q22, q32, q0_1, q0_2, q0_3, q1_2, q1_3, q2_3;
+  int i, j, i_ev = 0;
+  for (i = 0; i < 3; i++) C_end[i] = (M_end[0][i] + M_end[1][i] + M_end[2][i]) / 3;
+  for (i = 0; i < 3; i++) C_start[i] = (X[i] + X[3 + i] + X[6 + i]) / 3;
+  for (j = 0; j < 3; j++)
+    for (i = 0; i < 3; i++)
+      s[i * 3 + j] = (X[i] * M_end[0][j] + X[3 + i] * M_end[1][j] + X[6 + i] * M_end[2][j]) / 3 - C_end[j] * C_start[i];
+  Qs[0 * 4 + 0] = s[0 * 3 + 0] + s[1 * 3 + 1] + s[2 * 3 + 2];
+  Qs[1 * 4 + 1] = s[0 * 3 + 0] - s[1 * 3 + 1] - s[2 * 3 + 2];
+  Qs[2 * 4 + 2] = s[1 * 3 + 1] - s[2 * 3 + 2] - s[0 * 3 + 0];
+  Qs[3 * 4 + 3] = s[2 * 3 + 2] - s[0 * 3 + 0] - s[1 * 3 + 1];
+  Qs[1 * 4 + 0] = Qs[0 * 4 + 1] = s[1 * 3 + 2] - s[2 * 3 + 1];
+  Qs[2 * 4 + 0] = Qs[0 * 4 + 2] = s[2 * 3 + 0] - s[0 * 3 + 2];
+  Qs[3 * 4 + 0] = Qs[0 * 4 + 3] = s[0 * 3 + 1] - s[1 * 3 + 0];
+  Qs[2 * 4 + 1] = Qs[1 * 4 + 2] = s[1 * 3 + 0] + s[0 * 3 + 1];
+  Qs[3 * 4 + 1] = Qs[1 * 4 + 3] = s[2 * 3 + 0] + s[0 * 3 + 2];
+  Qs[3 * 4 + 2] = Qs[2 * 4 + 3] = s[2 * 3 + 1] + s[1 * 3 + 2];
+  jacobi_4x4(Qs, evs, U);
+  ev_max = evs[0];
+  for (i = 1; i < 4; i++)
+    if (evs[i] > ev_max) ev_max = evs[i_ev = i];
+  for (i = 0; i < 4; i++) q[i] = U[i * 4 + i_ev];
+  q02 = q[0] * q[0]; q12 = q[1] * q[1]; q22 = q[2] * q[2]; q32 = q[3] * q[3];
+  q0_1 = q[0] * q[1]; q0_2 = q[0] * q[2]; q0_3 = q[0] * q[3];
+  q1_2 = q[1] * q[2]; q1_3 = q[1] * q[3];
+  q2_3 = q[2] * q[3];
+  R[0][0] = q02 + q12 - q22 - q32; R[0][1] = 2. * (q1_2 - q0_3); R[0][2] = 2. * (q1_3 + q0_2);
+  R[1][0] = 2. * (q1_2 + q0_3); R[1][1] = q02 + q22 - q12 - q32; R[1][2] = 2. * (q2_3 - q0_1);
+  R[2][0] = 2. * (q1_3 - q0_2); R[2][1] = 2. * (q2_3 + q0_1); R[2][2] = q02 + q32 - q12 - q22;
+  for (i = 0; i < 3; i++) T[i] = C_end[i] - (R[i][0] * C_start[0] + R[i][1] * C_start[1] + R[i][2] * C_start[2]);
+}
+
+/* p3p::solve_for_lengths: |PA|, |PB|, |PC| from the pairwise distances |BC| |AC| |AB| and the cosines of the angles at P */
+static int p3p_solve_for_lengths(double lengths[4][3], const double distances[3], const double cosines[3]) {
+  double p = cosines[0] * 2, q = cosines[1] * 2, r = cosines[2] * 2;
+  double inv_d22 = 1. / (distances[2] * distances[2]);
+  double a = inv_d22 * (distances[0] * distances[0]);
+  double b = inv_d22 * (distances[1] * distances[1]);
+  double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r;
+  double pr = p * r, pqr = q * pr;
+  double ab, a_2, A, a_4, B, C, D, E, temp, b0, real_roots[4], r3, pr2, r3q, inv_b0;
+  int n, i, nb_solutions = 0;
+  if (p2 + q2 + r2 - pqr - 1 == 0) return 0;   /* reality condition (the four points should not be coplanar) */
+  ab = a * b; a_2 = 2 * a;
+  A = -2 * b + b2 + a2 + 1 + ab * (2 - r2) - a_2;
+  if (A == 0) return 0;
+  a_4 = 4 * a;
+  B = q * (-2 * (ab + a2 + 1 - b) + r2 * ab + a_4) + pr * (b - b2 + ab);
+  C = q2 + b2 * (r2 + p2 - 2) - b * (p2 + pqr) - ab * (r2 + pqr) + (a2 - a_2) * (2 + q2) + 2;
+  D = pr * (ab - b2 + b) + q * ((p2 - 2) * b + 2 * (ab - a2) + a_4 - 2);
+  E = 1 + 2 * (b - a - ab) + b2 - b * p2 + a2;
+  temp = (p2 * (a - 1 + b) + r2 * (a - 1 - b) + pqr - a * pqr);
+  b0 = b * temp * temp;
+  if (b0 == 0) return 0;
+  n = solve_deg4(A, B, C, D, E, &real_roots[0], &real_roots[1], &real_roots[2], &real_roots[3]);
+  if (n == 0) return 0;
+  r3 = r2 * r; pr2 = p * r2; r3q = r3 * q;
+  inv_b0 = 1. / b0;
+  for (i = 0; i < n; i++) {
+    double x = real_roots[i], x2, b1, y, v, Z;
+    if (x <= 0) continue;
+    x2 = x * x;
+    b1 = ((1 - a - b) * x2 + (q * a - q) * x + 1 - a + b) *
+         (((r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1)) * x +
+           (r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) + pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2))) * x2 +
+          (r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) + r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) +
+           pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b)) * x +
+          2 * r3q * (a_2 - b - a2 + ab - 1) + pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
+          p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1)));
+    if (b1 <= 0) continue;
+    y = inv_b0 * b1;
+    v = x2 + y * y - x * y * r;
+    if (v <= 0) continue;
+    Z = distances[2] / sqrt(v);
+    lengths[nb_solutions][0] = x * Z;
+    lengths[nb_solutions][1] = y * Z;
+    lengths[nb_solutions][2] = Z;
+    nb_solutions++;
+  }
+  return nb_solutions;
+}
+
+/* solvePnP(.., SOLVEPNP_P3P) on exactly four correspondences.  obj: 4 x 3 (float32-representable), img: 4 x 2 raw float32 image
+ * points.  Returns 1 and (rvec, tvec), or 0 when the first three points admit no pose. */
+static int solve_pnp_p3p(const camera* cam, const double* obj, const double* img, double rvec[3], double tvec[3]) {
+  const double inv_fx = 1. / cam->fx, inv_fy = 1. / cam->fy, cx_fx = cam->cx / cam->fx, cy_fy = cam->cy / cam->fy;
+  double mu[4], mv[4], m[3][3], distances[3], cosines[3], lengths[4][3], Rs[4][3][3], ts[4][3], min_reproj = 0, R9[9];
+  int i, j, n, ns = 0, nb = 0;
+  for (i = 0; i < 4; i++) {   /* undistortPoints writes CV_32FC2; p3p::extract_points maps back to pixels in double */
+    double x, y;
+    undistort_point(cam, img[2 * i], img[2 * i + 1], &x, &y);
+    mu[i] = (double)(float)x * cam->fx + cam->cx;
+    mv[i] = (double)(float)y * cam->fy + cam->cy;
+  }
+  for (i = 0; i < 3; i++) {   /* unit bearing vectors of the first three points */
+    double u = inv_fx * mu[i] - cx_fx, v = inv_fy * mv[i] - cy_fy;
+    double norm = sqrt(u * u + v * v + 1), mk = 1. / norm;
+    m[i][0] = u * mk; m[i][1] = v * mk; m[i][2] = mk;
+  }
+  distances[0] = sqrt((obj[3] - obj[6]) * (obj[3] - obj[6]) + (obj[4] - obj[7]) * (obj[4] - obj[7]) + (obj[5] - obj[8]) * (obj[5] - obj[8]));
+  distances[1] = sqrt((obj[0] - obj[6]) * (obj[0] - obj[6]) + (obj[1] - obj[7]) * (obj[1] - obj[7]) + (obj[2] - obj[8]) * (obj[2] - obj[8]));
+  distances[2] = sqrt((obj[0] - obj[3]) * (obj[0] - obj[3]) + (obj[1] - obj[4]) * (obj[1] - obj[4]) + (obj[2] - obj[5]) * (obj[2] - obj[5]));
+  cosines[0] = m[1][0] * m[2][0] + m[1][1] * m[2][1] + m[1][2] * m[2][2];
+  cosines[1] = m[0][0] * m[2][0] + m[0][1] * m[2][1] + m[0][2] * m[2][2];
+  cosines[2] = m[0][0] * m[1][0] + m[0][1] * m[1][1] + m[0][2] * m[1][2];
+  n = p3p_solve_for_lengths(lengths, distances, cosines);
+  for (i = 0; i < n; i++) {
+    double M_orig[3][3];
+    for (j = 0; j < 3; j++) { M_orig[j][0] = lengths[i][j] * m[j][0]; M_orig[j][1] = lengths[i][j] * m[j][1]; M_orig[j][2] = lengths[i][j] * m[j][2]; }
+    p3p_align(M_orig, obj, Rs[nb], ts[nb]);
+    nb++;
+  }
+  if (nb == 0) return 0;
+  for (i = 0; i < nb; i++) {   /* the fourth point picks the solution */
+    const double X3 = obj[9], Y3 = obj[10], Z3 = obj[11];
+    double X3p = Rs[i][0][0] * X3 + Rs[i][0][1] * Y3 + Rs[i][0][2] * Z3 + ts[i][0];
+    double Y3p = Rs[i][1][0] * X3 + Rs[i][1][1] * Y3 + Rs[i][1][2] * Z3 + ts[i][1];
+    double Z3p = Rs[i][2][0] * X3 + Rs[i][2][1] * Y3 + Rs[i][2][2] * Z3 + ts[i][2];
+    double mu3p = cam->cx + cam->fx * X3p / Z3p;
+    double mv3p = cam->cy + cam->fy * Y3p / Z3p;
+    double reproj = (mu3p - mu[3]) * (mu3p - mu[3]) + (mv3p - mv[3]) * (mv3p - mv[3]);
+    if (i == 0 || min_reproj > reproj) { ns = i; min_reproj = reproj; }
+  }
+  for (i = 0; i < 3; i++) {
+    for (j = 0; j < 3; j++) R9[3 * i + j] = Rs[ns][i][j];
+    tvec[i] = ts[ns][i];
+  }
+  rodrigues_mat2vec(R9, rvec);
+  return 1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* ptsetreg.cpp RANSAC + solvepnp.cpp solvePnPRansac                                           */
 /* ------------------------------------------------------------------------------------------ */
 static int ransac_update_num_iters(double p, double ep, int model_points, int max_iters) {
@@ -693,7 +1002,7 @@ static int find_inliers(const camera* cam, const double* obj, const double* img,
   return nz;
 }
 
-/* Returns number of inliers (>0) on success, -2 when RANSAC finds no model, -1 when n < 4. */
+/* Returns number of inliers (>0) on success, -2 when RANSAC (or P3P, n = 4) finds no model, -1 when n < 4. */
 static int solve_pnp_ransac(const camera* cam, const double* obj64, const float* img32, int n, int max_iters,
                             double reproj_err, double confidence, double rvec[3], double tvec[3],
                             int* iters_run) {
@@ -707,7 +1016,10 @@ static int solve_pnp_ransac(const camera* cam, const double* obj64, const float*
   if (n < 4 || n > MAXPTS) return -1;
   for (i = 0; i < 3 * n; i++) obj[i] = (double)(float)obj64[i];   /* convertTo(CV_32F) */
   for (i = 0; i < 2 * n; i++) img[i] = (double)img32[i];
-  if (n == 4) return -3;  /* P3P kernel: not on this path (J=11/24 always gives >= 5 points) */
+  if (n == 4) {   /* model_points = npoints = 4: solvePnP(SOLVEPNP_P3P) directly, no RANSAC (see solve_pnp_p3p) */
+    if (!solve_pnp_p3p(cam, obj, img, rvec, tvec)) { memset(rvec, 0, 24); memset(tvec, 0, 24); return -2; }
+    return n;
+  }
   if (n == model_points) {
     solve_pnp_epnp(cam, obj, img, n, 1, rvec, tvec);
     return n;
@@ -812,6 +1124,13 @@ void pnp_ref_batch(const float* kp_xyc, const double* landmarks, const double* K
 }
 
 /* exposed pieces for unit tests of the restatement */
+int pnp_ref_p3p(const double* K, const double* dist, const double* obj, const double* img, double* rvec, double* tvec) {
+  camera cam;
+  int i;
+  cam.fx = K[0]; cam.fy = K[4]; cam.cx = K[2]; cam.cy = K[5];
+  for (i = 0; i < 5; i++) cam.k[i] = dist ? dist[i] : 0.0;
+  return solve_pnp_p3p(&cam, obj, img, rvec, tvec);
+}
 void pnp_ref_epnp(const double* K, const double* dist, const double* obj, const double* img, int n, double* rvec, double* tvec) {
   camera cam;
   int i;

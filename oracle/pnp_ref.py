@@ -75,6 +75,17 @@ def epnp(obj, img, K=CAMERA_K, dist=CAMERA_DIST):
     return rv, tv
 
 
+def p3p(obj4, img4, K=CAMERA_K, dist=CAMERA_DIST):
+    """solvePnP(SOLVEPNP_P3P) on exactly four correspondences (pnp_ref.c: solve_pnp_p3p); returns (ok, rvec, tvec)."""
+    obj = np.ascontiguousarray(obj4, dtype=np.float64); img = np.ascontiguousarray(img4, dtype=np.float64)
+    assert obj.shape == (4, 3) and img.shape == (4, 2)
+    rv = np.zeros(3); tv = np.zeros(3)
+    lib().pnp_ref_p3p.restype = c_int
+    ok = lib().pnp_ref_p3p(_p(np.ascontiguousarray(K, dtype=np.float64)), _p(np.ascontiguousarray(dist, dtype=np.float64)),
+                           _p(obj), _p(img), _p(rv), _p(tv))
+    return bool(ok), rv, tv
+
+
 def rodrigues(x):
     x = np.ascontiguousarray(x, dtype=np.float64)
     out = np.zeros(3 if x.size == 9 else 9)

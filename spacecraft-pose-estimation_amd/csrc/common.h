@@ -204,7 +204,7 @@ void stem_fused_pack(const float* w1, const float* b1, const float* w2, const fl
                      std::vector<uint16_t>* pw2, std::vector<float>* pb1, std::vector<float>* pb2);
 int32_t stem_fused_launch(const void* in, int in_fmt, const void* w1, const void* w2, const float* b1, const float* b2,
                           const float* mean_std, int N, int H, int W, int dtype, void* out,
-                          uint32_t* sched /*2 zero-initialised device words: dynamic tile queue*/, hipStream_t stream);
+                          uint32_t* sched /*2 zero-initialised device words: dynamic tile queue (conv_device.h: tile_claim)*/, hipStream_t stream);
 
 // fused layer1 Bottleneck (bottleneck.hip): conv1 1x1 Cin->64, conv2 3x3 64->64, conv3 1x1 64->256 + residual in one launch;
 // Cin = 256: identity residual; Cin = 64: the first Bottleneck, its `downsample` projection (wds, bds) folded into conv3
@@ -213,7 +213,7 @@ void bottleneck_pack(const float* w1, const float* w2, const float* w3, const fl
                      const float* bds, int cin, int dtype,
                      std::vector<uint16_t>* pw1, std::vector<uint16_t>* pw2, std::vector<uint16_t>* pw3, std::vector<float>* pb);
 int32_t bottleneck_launch(const void* in, const void* w1, const void* w2, const void* w3, const float* bias, int N, int H, int W,
-                          int cin, int dtype, void* out, uint32_t* sched /*2 zero-initialised device words: dynamic tile queue*/,
+                          int cin, int dtype, void* out, uint32_t* sched /*11 zero-initialised device words: per-XCD tile queues [0..7], finished workgroups [8], device-wide queue of the first Bottleneck [9..10]*/,
                           hipStream_t stream);
 
 // ---- elementwise ---------------------------------------------------------------------------

@@ -9,8 +9,8 @@ namespace scpose {
 
 int32_t conv_m32_dispatch_bf16(int mr, int wm, int nr, int occ, const ConvLaunch& L, size_t lds, hipStream_t st);
 int32_t conv_m32_dispatch_f16(int mr, int wm, int nr, int occ, const ConvLaunch& L, size_t lds, hipStream_t st);
-int32_t conv_m32p_dispatch_bf16(int stride, int mr, int nr, const ConvLaunch& L, size_t lds, hipStream_t st);
-int32_t conv_m32p_dispatch_f16(int stride, int mr, int nr, const ConvLaunch& L, size_t lds, hipStream_t st);
+int32_t conv_m32p_dispatch_bf16(int stride, int mr, int nr, int c16, const ConvLaunch& L, size_t lds, hipStream_t st);
+int32_t conv_m32p_dispatch_f16(int stride, int mr, int nr, int c16, const ConvLaunch& L, size_t lds, hipStream_t st);
 
 // kernel variants built (keep in step with m32_dispatch / m32p_dispatch): occ = resident workgroups
 // per CU of the single-role kernel (1, 2), or 3 = the producer/consumer kernel (512 threads, one per CU)
@@ -241,8 +241,12 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
     // L.groups doubles as "K-chunks of weights held in producer registers" for the producer/consumer kernel
     static const char* wr_env = dev_env("SCPOSE_M32_WREG");
     L.groups = (pc.n_mblk == 1 && ck.nchunks == 6 && ck.cp == 2 && pc.stride == 1 && pc.mrep == 3 && b_nr == 3 && !(wr_env && atoi(wr_env) == 0)) ? 6 : 1;
-    if (pc.dtype == SCPOSE_DT_BF16) return conv_m32p_dispatch_bf16(pc.stride, pc.mrep, b_nr, L, lds, stream);
-    return conv_m32p_dispatch_f16(pc.stride, pc.mrep, b_nr, L, lds, stream);
+    // 16x16x32 consumers (conv_m32p_kernel.h, C16; round 4): the MFMA-bound stride-1 layers with 96-row Cout blocks, three 32-pixel
+    // columns per consumer wave and an even number of 2-plane chunks (stages are processed in pairs): 96->96, 192->192, 384->384
+    static const char* c16_env = dev_env("SCPOSE_M16");
+    const int c16 = (pc.stride == 1 && pc.mrep == 3 && b_nr == 3 && ck.cp == 2 && ck.nchunks % 2 == 0 && !(c16_env && atoi(c16_env) == 0)) ? 1 : 0;
+    if (pc.dtype == SCPOSE_DT_BF16) return conv_m32p_dispatch_bf16(pc.stride, pc.mrep, b_nr, c16, L, lds, stream);
+    return conv_m32p_dispatch_f16(pc.stride, pc.mrep, b_nr, c16, L, lds, stream);
   }
   if (pc.dtype == SCPOSE_DT_BF16) return conv_m32_dispatch_bf16(pc.mrep, pc.wm, b_nr, b_occ, L, lds, stream);
   return conv_m32_dispatch_f16(pc.mrep, pc.wm, b_nr, b_occ, L, lds, stream);

@@ -25,7 +25,28 @@ namespace scpose {
 // WREG > 0: the layer has ONE Cout block of WREG K-chunks and the producers keep all of its packed weights in
 // their (otherwise idle) registers -- 7 x 16 B per thread and chunk -- and refill the LDS chunk buffers with
 // ds_write_b128 instead of LDS-DMA: 7 of the ~16 memory instructions a producer wave issues per stage disappear.
-template <int DT, int KS, int STRIDE, int MR, int NR, int WREG = 0>
+//
+// C16 = 1 (round 4): the CONSUMERS run v_mfma_f32_16x16x32 instead of 32x32x16 -- same tile, same LDS images, same producers.
+// Why: these layers run at the clock the chip grants under load, and on random data it grants the 16x16x32 stream more
+// (tools_dev/micro/shape_bench.hip: this consumer loop beside 7 LDS-DMA per producer wave and stage, 3 015 vs 3 043 cycles per
+// stage but 1.90 vs 1.71 GHz: +12 % FLOP/s; MI355X micro-architecture guide, "DVFS give-back" item 7).
+//   * K = 32 of one MFMA is FOUR groups of 8 channels, and every 16-lane group q of a wave reads its own fragment address, so
+//     the four groups may be any (plane, tap) pairs.  The packed weight image is already [group = 2 tap + plane][row][16 B], so
+//     a k-step takes two taps of both planes: q & 1 = plane, q >> 1 = which tap of the pair.  Nothing about the producers, the
+//     LDS layout or the host-side packing changes.
+//   * 18 groups per stage are 4.5 k-steps: stages are processed in PAIRS (the host routes layers with an even number of
+//     2-plane chunks here).  Over a pair the lanes with q >> 1 = 0 walk taps 0 3 6 2 8 | 0 3 6 5, the others 1 4 7 5 | 2 1 4 7 8:
+//     k-step 4 straddles the stage barrier.  Its lower half-wave's fragments (tap 8 of the even stage) are requested before
+//     that barrier and kept in registers across it; behind it the upper half-wave's (tap 2 of the odd stage) are read into
+//     the same registers with EXEC = lanes 32-63.
+//   * a wave owns MT/16 x 2 NR accumulators of 16 x 16 (6 x 6 x 4 = 144 registers, as before); the A fragments of a k-step are
+//     double-buffered (all six stay live through its six columns), the B fragments sit in a ring of 2 NR + 1 registers; the
+//     twelve reads of the next k-step are issued BETWEEN this k-step's MFMAs, at most one per two MFMAs (an in-order wave that
+//     issues seven reads back to back leaves its matrix pipe idle: 3 360 vs 3 015 cycles per stage in shape_bench), and
+//     waited for with counted lgkmcnt (LDS returns in order).
+//   * fp32 summation order differs from the 32x32x16 form (taps pair up differently inside an MFMA); it is fixed for a layer
+//     shape, so the invariance properties (batch position, batch size, eager = captured) hold as before.
+template <int DT, int KS, int STRIDE, int MR, int NR, int WREG = 0, int C16 = 0>
 __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename DtOf<DT>::type T;
@@ -308,6 +329,240 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
     if (it_begin < it_end && !SCP_DBG(p, 2)) store_results(it_end - 1, qb_prev, 0, ROPL);   // drain the last tile
     if (SCP_DBG(p, 8) && SCP_DBG_BUF(p) && lane == 0)
       for (int k = 0; k < 6; ++k) SCP_DBG_BUF(p)[((size_t)blockIdx.x * 8 + wave_all) * 6 + k] = tph[k];
+  } else if constexpr (C16 != 0) {
+    // =====================================================================================
+    // consumers, 16x16x32 form (see the header comment): LDS reads, MFMAs, epilogue into the retire buffer
+    // =====================================================================================
+    static_assert(KS == 3 && MT % 16 == 0, "16x16x32 consumers: 3x3 layers");
+    constexpr int MB = MT / 16;          // 16-row blocks of the Cout block
+    constexpr int NB = 2 * NR;           // 16-pixel columns of the wave's 32 * NR pixel slots
+    constexpr int RING = NB + 1;
+    constexpr int TAPB = 2 * MT * 16;    // bytes of one tap (both planes) in the packed weight image
+    static_assert(MB == 6 && NB == 6, "16x16x32 consumers: the k-step schedule below is written for 6 x 6 accumulators");
+    typedef f32x4 acc_t;
+    // Lane (q = lane >> 4, l15 = lane & 15): plane q & 1 of the stage's two; class q >> 1 picks the tap of a k-step's pair.
+    // Pairs are chosen so that the two classes' fragment addresses differ by a constant: one pixel (taps kx, kx + 1 of a row) or
+    // one row (taps (ky, 2), (ky + 1, 2)), so a B address is  pixoffq[n] + class shift + (uniform: buffer + tap)  -- one v_add3
+    // with the uniform part in an SGPR -- and an A address is a per-stage base + an immediate:
+    //   k-step    0      1      2      3      4 (straddle)        5      6      7      8
+    //   taps    0 | 1  3 | 4  6 | 7  2 | 5  8 even | 2 odd       0 | 1  3 | 4  6 | 7  5 | 8
+    int pixoffq[NB];   // byte offset of this lane's pixel (column n) in its plane of a staged chunk
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      int ps, py, px;
+      pixel_of((wave * NB + n) * 16 + (lane & 15), ps, py, px);
+      pixoffq[n] = (ps >= 0 ? (ps * HP + (py * STRIDE) * p.halo_w + px * STRIDE) * 16 : 0) + ((lane >> 4) & 1) * p.plane_stride;
+    }
+    const uint32_t hw16 = (uint32_t)p.halo_w * 16u;
+    const uint32_t sh_px = (uint32_t)(lane >> 5) * 16u, sh_row = (uint32_t)(lane >> 5) * hw16;   // class shifts of the B address
+    acc_t acc[MB][NB];
+    frag_t a0[MB], a1[MB], bR[RING];
+    const bool wave_idle = wave * NB * 16 >= P;   // wave-uniform
+    int wc = 0, xb = 0;
+    __syncthreads();   // matches the producers' prologue barrier
+
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
+    auto now = [&]() -> unsigned long long { return SCP_DBG(p, 8) ? __builtin_amdgcn_s_memtime() : 0ull; };
+    auto add3 = [](uint32_t a, uint32_t b, uint32_t c_uniform) -> uint32_t {   // opaque to the compiler: 54 hoisted addresses otherwise
+      uint32_t d;
+      asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
+      return d;
+    };
+#define M16_WAIT(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+#define M16_BREG(S, N) bR[((N) - (S) + 4 * RING) % RING]
+#define M16_TAP0(S) ((S) == 0 ? 0 : (S) == 1 ? 3 : (S) == 2 ? 6 : (S) == 3 ? 2 : (S) == 4 ? 8 : (S) == 5 ? 0 : (S) == 6 ? 3 : (S) == 7 ? 6 : 5)
+#define M16_ROWPAIR(S) ((S) == 3 || (S) == 8)   // the classes' taps are one ROW apart (else one pixel)
+#define M16_RDA(S, M, NA) lds_read16<M16_TAP0(S) * TAPB + (M) * 256>(NA[M], M16_ROWPAIR(S) ? wa3 : wa1);
+#define M16_RDB(S, N) lds_read16<0>(M16_BREG(S, N), add3((uint32_t)pixoffq[N], M16_ROWPAIR(S) ? sh_row : sh_px, \
+                                                         xl + (uint32_t)(M16_TAP0(S) / 3) * hw16 + (uint32_t)(M16_TAP0(S) % 3) * 16u));
+    // Issue order of a k-step's prefetch: A'0 A'1 B'0 | A'2 A'3 B'1 | A'4 B'2 | A'5 B'3 | B'4 | B'5.  Column 0 of the next k-step
+    // needs A'0..5 and B'0 = all but the three youngest requests -> lgkmcnt(3); column 3 needs B'3 with B'4 B'5 and the eight
+    // requests of the new k-step's columns 0-2 behind it -> lgkmcnt(10); columns 4, 5: lgkmcnt(11).  A k-step whose twelve
+    // fragments were requested in one burst (FIRST: A0..5 B0..5) counts 5 7 9 10 11 11; one that prefetches nothing 3 - - 2 1 0.
+#define M16_WAITOF(FIRST, N, MORE) ((FIRST) ? ((N) == 0 ? 5 : (N) == 1 ? 7 : (N) == 2 ? 9 : (N) == 3 ? 10 : 11) \
+                                            : (MORE) ? ((N) == 0 ? 3 : (N) == 3 ? 10 : (N) >= 4 ? 11 : -1)       \
+                                                     : ((N) == 0 ? 3 : (N) >= 3 ? 5 - (N) : -1))
+#define M16_COL(S, N, CA, NA, MORE, FIRST)                                                                               \
+    {                                                                                                                    \
+      if constexpr (M16_WAITOF(FIRST, N, MORE) >= 0) { M16_WAIT(M16_WAITOF(FIRST, N, MORE) < 0 ? 0 : M16_WAITOF(FIRST, N, MORE)) } \
+      if constexpr ((N) == 0) { _Pragma("unroll") for (int m = 0; m < MB; ++m) lds_landed(CA[m]); }                      \
+      lds_landed(M16_BREG(S, N));                                                                                        \
+      mfma16_acc<T>(acc[0][N], CA[0], M16_BREG(S, N)); mfma16_acc<T>(acc[1][N], CA[1], M16_BREG(S, N));                  \
+      if constexpr (MORE) { if constexpr ((N) == 0) { M16_RDA((S) + 1, 0, NA) } else if constexpr ((N) == 1) { M16_RDA((S) + 1, 2, NA) } \
+                            else if constexpr ((N) == 2) { M16_RDA((S) + 1, 4, NA) } else if constexpr ((N) == 3) { M16_RDA((S) + 1, 5, NA) } } \
+      mfma16_acc<T>(acc[2][N], CA[2], M16_BREG(S, N)); mfma16_acc<T>(acc[3][N], CA[3], M16_BREG(S, N));                  \
+      if constexpr (MORE) { if constexpr ((N) == 0) { M16_RDA((S) + 1, 1, NA) } else if constexpr ((N) == 1) { M16_RDA((S) + 1, 3, NA) } } \
+      mfma16_acc<T>(acc[4][N], CA[4], M16_BREG(S, N));                                                                   \
+      if constexpr (MORE) { M16_RDB((S) + 1, N) }                                                                        \
+      mfma16_acc<T>(acc[5][N], CA[5], M16_BREG(S, N));                                                                   \
+    }
+#define M16_KSTEP(S, CA, NA, MORE, FIRST) M16_COL(S, 0, CA, NA, MORE, FIRST) M16_COL(S, 1, CA, NA, MORE, FIRST) M16_COL(S, 2, CA, NA, MORE, FIRST) \
+                                          M16_COL(S, 3, CA, NA, MORE, FIRST) M16_COL(S, 4, CA, NA, MORE, FIRST) M16_COL(S, 5, CA, NA, MORE, FIRST)
+    // per-stage A bases, formed behind an opaque copy of the lane id so that they are not kept live across stages
+#define M16_STAGE_BASES(WL)                                                                              \
+      uint32_t lane_s = (uint32_t)lane;                                                                  \
+      asm volatile("" : "+v"(lane_s));                                                                   \
+      const uint32_t wa0 = (WL) + ((((lane_s >> 4) & 1) * MT + (lane_s & 15)) * 16);                     \
+      const uint32_t wa1 = wa0 + (lane_s >> 5) * TAPB, wa3 = wa0 + (lane_s >> 5) * (3 * TAPB);
+    for (int it = it_begin; it < it_end; ++it) {
+      const int mb = it - fdiv(it, p.fd_nmblk) * p.n_mblk;
+      for (int c = 0; c < p.nchunks; c += 2) {
+        const bool compute = !(SCP_DBG(p, 1) || wave_idle);
+        // ---------------- even stage: taps 0|1 3|4 6|7 2|5 of chunk c, and the lower half of the straddling k-step (tap 8) ----------------
+        {
+          const unsigned long long t0 = now();
+          const uint32_t xl = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(xl0 + xb * p.lds_x));
+          M16_STAGE_BASES((uint32_t)(size_t)(wl0 + (w_resident ? c : (wc & 1)) * p.lds_w))
+          (void)wa0;
+          if (compute) {   // the first fragments fly while the accumulators are initialised
+            M16_RDA(0, 0, a0) M16_RDA(0, 1, a0) M16_RDA(0, 2, a0) M16_RDA(0, 3, a0) M16_RDA(0, 4, a0) M16_RDA(0, 5, a0)
+            M16_RDB(0, 0) M16_RDB(0, 1) M16_RDB(0, 2) M16_RDB(0, 3) M16_RDB(0, 4) M16_RDB(0, 5)
+          }
+          if (c == 0) {   // accumulators start at the bias of their rows: row(j) = 16 m + 4 q + j
+            const float* bq = bias_l + mb * MT + 4 * (lane_s >> 4);
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+              const float4 b4 = *reinterpret_cast<const float4*>(bq + m * 16);
+#pragma unroll
+              for (int n = 0; n < NB; ++n) { acc[m][n][0] = b4.x; acc[m][n][1] = b4.y; acc[m][n][2] = b4.z; acc[m][n][3] = b4.w; }
+            }
+            // VALU write -> MFMA SrcC needs wait states the hazard recogniser cannot see around inline-asm MFMAs (conv_device.h)
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+              for (int n = 0; n < NB; ++n) mfma_input_fence<false>(acc[m][n]);
+          }
+          if (compute) {
+            M16_KSTEP(0, a0, a1, true, true) M16_KSTEP(1, a1, a0, true, false) M16_KSTEP(2, a0, a1, true, false)
+            M16_KSTEP(3, a1, a0, true, false)   // prefetches k-step 4 from THIS stage's buffers: tap 8 for class 0 (class 1's slots are refilled below)
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+              for (int n = 0; n < NB; ++n) mfma_result_fence<false>(acc[m][n]);
+          }
+          const unsigned long long t1 = now();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the straddling fragments have landed before the producers may refill these buffers
+          if (compute) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m) lds_landed(a0[m]);
+#pragma unroll
+            for (int n = 0; n < NB; ++n) lds_landed(M16_BREG(4, n));
+          }
+          const unsigned long long t2 = now();
+          __builtin_amdgcn_s_barrier();
+          if SCP_DBG(p, 8) { const unsigned long long t3 = now(); tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; }
+          xb ^= 1; ++wc;
+        }
+        // ---------------- odd stage: upper half of the straddling k-step (tap 2), then taps 0|1 3|4 6|7 5|8 of chunk c + 1 ----------------
+        {
+          const unsigned long long t0 = now();
+          const bool last = c + 2 >= p.nchunks;
+          const uint32_t xl = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(xl0 + xb * p.lds_x));
+          M16_STAGE_BASES((uint32_t)(size_t)(wl0 + (w_resident ? c + 1 : (wc & 1)) * p.lds_w))
+          if (compute) {
+            {   // lanes 32-63 (class 1): their group of k-step 4 is tap 2 of this stage; lanes 0-31 keep what they hold
+              uint32_t xa[NB];
+#pragma unroll
+              for (int n = 0; n < NB; ++n) xa[n] = add3((uint32_t)pixoffq[n], 0u, xl + 32u);
+              unsigned long long keep;
+              asm volatile(
+                  "s_mov_b64 %[keep], exec\n\t"
+                  "s_mov_b32 exec_lo, 0\n\t"
+                  "ds_read_b128 %[a0], %[wm] offset:%[o0]\n\t"
+                  "ds_read_b128 %[a1], %[wm] offset:%[o1]\n\t"
+                  "ds_read_b128 %[a2], %[wm] offset:%[o2]\n\t"
+                  "ds_read_b128 %[a3], %[wm] offset:%[o3]\n\t"
+                  "ds_read_b128 %[a4], %[wm] offset:%[o4]\n\t"
+                  "ds_read_b128 %[a5], %[wm] offset:%[o5]\n\t"
+                  "ds_read_b128 %[b0], %[x0]\n\t"
+                  "ds_read_b128 %[b1], %[x1]\n\t"
+                  "ds_read_b128 %[b2], %[x2]\n\t"
+                  "ds_read_b128 %[b3], %[x3]\n\t"
+                  "ds_read_b128 %[b4], %[x4]\n\t"
+                  "ds_read_b128 %[b5], %[x5]\n\t"
+                  "s_mov_b64 exec, %[keep]"
+                  : [keep] "=&s"(keep), [a0] "+v"(a0[0]), [a1] "+v"(a0[1]), [a2] "+v"(a0[2]), [a3] "+v"(a0[3]), [a4] "+v"(a0[4]), [a5] "+v"(a0[5]),
+                    [b0] "+v"(M16_BREG(4, 0)), [b1] "+v"(M16_BREG(4, 1)), [b2] "+v"(M16_BREG(4, 2)), [b3] "+v"(M16_BREG(4, 3)),
+                    [b4] "+v"(M16_BREG(4, 4)), [b5] "+v"(M16_BREG(4, 5))
+                  : [wm] "v"(wa0), [x0] "v"(xa[0]), [x1] "v"(xa[1]), [x2] "v"(xa[2]), [x3] "v"(xa[3]), [x4] "v"(xa[4]), [x5] "v"(xa[5]),
+                    [o0] "n"(2 * TAPB), [o1] "n"(2 * TAPB + 256), [o2] "n"(2 * TAPB + 512), [o3] "n"(2 * TAPB + 768), [o4] "n"(2 * TAPB + 1024),
+                    [o5] "n"(2 * TAPB + 1280)
+                  : "memory");
+            }
+            M16_KSTEP(4, a0, a1, true, true) M16_KSTEP(5, a1, a0, true, false) M16_KSTEP(6, a0, a1, true, false)
+            M16_KSTEP(7, a1, a0, true, false) M16_KSTEP(8, a0, a1, false, false)
+            // last MFMA's result visible to the VALU -- only the tile's last stage is followed by VALU reads of the accumulators
+            if (last) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+              for (int n = 0; n < NB; ++n) mfma_result_fence<false>(acc[m][n]);
+          }
+          const unsigned long long t1 = now();
+          if (last && !wave_idle) {
+            // retire: RO <- ReLU(acc + residual), in place.  A lane holds rows 16 m + 4 q .. + 3 of its pixel: channels 4 (q & 1) .. + 3
+            // of output plane 2 m + (q >> 1), i.e. one 8-byte half-slot per accumulator -- no lane exchange, no separate bias add.
+            const uint32_t relu_floor = p.relu ? 0u : 0x80008000u;
+            // (the slot address is formed HERE, behind an opaque copy of the lane id: hoisted out of the tile loop it would be
+            // live across the k-steps, which have no register to spare)
+            uint32_t lane_e = (uint32_t)lane;
+            asm volatile("" : "+v"(lane_e));
+            char* const slot0 = ro + ((((lane_e >> 5) & 1) * PXCAP) + wave * NB * 16 + (lane_e & 15)) * 16 + 8 * ((lane_e >> 4) & 1);
+            auto slot = [&](int m, int n) -> char* { return slot0 + ((2 * m) * PXCAP + n * 16) * 16; };
+            if (!p.res) {
+#pragma unroll
+              for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                  uint2 o;
+                  o.x = relu2_16(pack2<T>(acc[m][n][0], acc[m][n][1]), relu_floor);
+                  o.y = relu2_16(pack2<T>(acc[m][n][2], acc[m][n][3]), relu_floor);
+                  *reinterpret_cast<uint2*>(slot(m, n)) = o;     // padding pixels write their own slots too: the producers never store those
+                }
+            } else {
+              // residual half-slots are read one row block ahead of the one being finalised (the in-place writes would otherwise
+              // order every read behind the previous write)
+              uint2 rr[2][NB];
+#pragma unroll
+              for (int n = 0; n < NB; ++n) rr[0][n] = *reinterpret_cast<const uint2*>(slot(0, n));
+#pragma unroll
+              for (int m = 0; m < MB; ++m) {
+                if (m + 1 < MB) {
+#pragma unroll
+                  for (int n = 0; n < NB; ++n) rr[(m + 1) & 1][n] = *reinterpret_cast<const uint2*>(slot(m + 1, n));
+                }
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                  const uint2 x = rr[m & 1][n];
+                  const float v0 = acc[m][n][0] + from_bits<T>(x.x & 0xffff), v1 = acc[m][n][1] + from_bits<T>(x.x >> 16);
+                  const float v2 = acc[m][n][2] + from_bits<T>(x.y & 0xffff), v3 = acc[m][n][3] + from_bits<T>(x.y >> 16);
+                  uint2 o;
+                  o.x = relu2_16(pack2<T>(v0, v1), relu_floor); o.y = relu2_16(pack2<T>(v2, v3), relu_floor);
+                  *reinterpret_cast<uint2*>(slot(m, n)) = o;
+                }
+              }
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const unsigned long long t2 = now();
+          __builtin_amdgcn_s_barrier();
+          if SCP_DBG(p, 8) { const unsigned long long t3 = now(); tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; }
+          xb ^= 1; ++wc;
+        }
+      }
+    }
+#undef M16_STAGE_BASES
+#undef M16_KSTEP
+#undef M16_COL
+#undef M16_WAITOF
+#undef M16_RDB
+#undef M16_RDA
+#undef M16_ROWPAIR
+#undef M16_TAP0
+#undef M16_BREG
+#undef M16_WAIT
+    if (SCP_DBG(p, 8) && SCP_DBG_BUF(p) && lane == 0)
+      for (int k = 0; k < 6; ++k) SCP_DBG_BUF(p)[((size_t)blockIdx.x * 8 + wave_all) * 6 + k] = tph[k];
   } else {
     // =====================================================================================
     // consumers: LDS reads, MFMAs, epilogue into the retire buffer
@@ -507,9 +762,9 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
   }
 }
 
-template <int DT, int STRIDE, int MR, int NR, int WREG = 0>
+template <int DT, int STRIDE, int MR, int NR, int WREG = 0, int C16 = 0>
 int32_t m32p_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
-  auto kern = conv_m32p_kernel<DT, 3, STRIDE, MR, NR, WREG>;
+  auto kern = conv_m32p_kernel<DT, 3, STRIDE, MR, NR, WREG, C16>;
   static LdsOptIn big_lds;   // per device (common.h)
   { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(kern), 160 * 1024, &big_lds); if (rc != SCPOSE_OK) return rc; }
   hipLaunchKernelGGL(kern, dim3(L.grid), dim3(512), lds, st, L);
@@ -518,7 +773,12 @@ int32_t m32p_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
 }
 
 template <int DT>
-int32_t m32p_dispatch(int stride, int mr, int nr, const ConvLaunch& L, size_t lds, hipStream_t st) {
+int32_t m32p_dispatch(int stride, int mr, int nr, int c16, const ConvLaunch& L, size_t lds, hipStream_t st) {
+  if (c16) {   // 16x16x32 consumers (conv_launch_m32 routes only stride 1, 96-row blocks, 3 columns, an even number of 2-plane chunks here)
+    if (stride == 1 && mr == 3 && nr == 3) return L.groups == 6 ? m32p_launch_one<DT, 1, 3, 3, 6, 1>(L, lds, st) : m32p_launch_one<DT, 1, 3, 3, 0, 1>(L, lds, st);
+    set_error("conv m32p: 16x16x32 consumer variant stride=%d mr=%d nr=%d not built", stride, mr, nr);
+    return SCPOSE_E_INVALID;
+  }
   if (stride == 2) {
     if (mr == 3 && nr == 1) return m32p_launch_one<DT, 2, 3, 1>(L, lds, st);
     if (mr == 3 && nr == 2) return m32p_launch_one<DT, 2, 3, 2>(L, lds, st);

@@ -332,7 +332,9 @@ __global__ __launch_bounds__(768, 3) void conv_s2r12_kernel(const S2r12Launch p)
 bool conv_s2r_config(int cin, int cout, int stride, int* planes, int* nblk, int* g) {
   if (stride == 1 && !(cin == 64 && cout == 64)) return false;   // stride 1: layer1's 3x3 (Bottleneck conv2, no residual)
   if (cin == 96) {                              // conv_s2r12_kernel: one block per wave, 6 or 12 blocks per workgroup pass
-    if (stride != 2 || cout % 96 != 0) return false;
+    // a pass of the kernel covers 16 * g output channels: 96 (g = 6) or whole multiples of 192 (g = 12).  Any other width
+    // (288, 480, ...) would leave its last 96 channels unwritten -- those layers stay on the producer/consumer kernel.
+    if (stride != 2 || !(cout == 96 || cout % 192 == 0)) return false;
     *planes = 12; *nblk = 1; *g = cout == 96 ? 6 : 12;
     return true;
   }
@@ -410,6 +412,7 @@ static int32_t conv_s2r12_launch(const PackedConv& pc, int g, const void* in, in
   L.tiles_x = (L.Wo + k12T - 1) / k12T; L.tiles_y = (L.Ho + k12T - 1) / k12T;
   L.tiles_total = N * L.tiles_x * L.tiles_y;
   L.npass = pc.cout / (16 * g);
+  SCP_REQUIRE(L.npass * g * 16 == pc.cout, "conv s2r12: %d output channels are not a whole number of %d-channel passes", pc.cout, 16 * g);
   int per_pass = conv_device_cus() / L.npass;             // every pass gets its own share of the workgroups
   if (per_pass < 1) per_pass = 1;
   if (per_pass > L.tiles_total) per_pass = L.tiles_total;

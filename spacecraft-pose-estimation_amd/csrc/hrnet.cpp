@@ -124,13 +124,13 @@ struct scpose_hrnet {
   // ops[conv_op] launches head_fused with the fuse op's terms -- unless the forward stops at the fuse op's output
   // (scpose_hrnet_forward_tap) or the shape is not supported
   struct HeadFused { bool ok = false; int fuse_op = -1, conv_op = -1; void* d_w = nullptr; float* d_b = nullptr;
-                     float* d_part_v = nullptr; int32_t* d_part_i = nullptr; int part_cap = 0; bool active = false; } headf;
+                     bool active = false; } headf;
   std::vector<scpose::TensorDesc> tensors;
   std::vector<scpose::Op> ops;
   std::vector<std::pair<std::string, int>> taps;   // named intermediate tensors (scpose_hrnet_forward_tap): name -> tensor id
   // cached arena plans: [0] serial forward (a tensor is released right after its last reader), [1] captured forward
   // (releases deferred to the end of the epoch, so that ops running side by side never share memory)
-  struct Plan { int n = -1, h = -1, w = -1; size_t bytes = 0; std::vector<size_t> off; } plan[2];
+  struct Plan { int n = -1, h = -1, w = -1; size_t bytes = 0, part_off = 0; std::vector<size_t> off; } plan[2];
   // per-op HIP events of the last profiled forward (ops.size()+1, created by scpose_hrnet_create)
   std::vector<hipEvent_t> events;
   bool events_valid = false;
@@ -600,6 +600,12 @@ size_t hrnet_plan(scpose_hrnet* net, int n, int h, int w, int mode = 0) {
     for (int k = 0; k < op.nterms; ++k) done(op.term[k]);
     // an output nobody reads (cannot happen in a well-formed net) is simply never reused
   }
+  // Behind the arena: the fused tail's partial maxima (head_fused.hip: part_v, then part_i).  They live in the CALLER's
+  // workspace, like every other buffer a launch writes, so a captured graph -- which owns its workspace -- never holds a
+  // pointer into memory a later forward of another batch size could free (they used to be engine-owned and
+  // re-allocated on demand).
+  P.part_off = top;
+  if (net->headf.ok) top += 2 * head_fused_part_bytes(n);
   P.n = n; P.h = h; P.w = w; P.bytes = top;
   return top;
 }
@@ -630,14 +636,6 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
   net->headf.active = fused_tail;
   SCP_REQUIRE(heatmaps || (dec && fused_tail) || stop_tensor >= 0,
               "hrnet_forward: this network's tail is not fused for this shape -- key points need a heat-map buffer");
-  if (dec && fused_tail && net->headf.part_cap < n) {   // partial maxima of the strips (grown on demand, outside any capture: graph_create runs an eager forward first)
-    if (net->headf.d_part_v) (void)hipFree(net->headf.d_part_v);
-    if (net->headf.d_part_i) (void)hipFree(net->headf.d_part_i);
-    net->headf.d_part_v = nullptr; net->headf.d_part_i = nullptr; net->headf.part_cap = 0;
-    SCP_CHECK_HIP(hipMalloc(&net->headf.d_part_v, head_fused_part_bytes(n)));
-    SCP_CHECK_HIP(hipMalloc(&net->headf.d_part_i, head_fused_part_bytes(n)));
-    net->headf.part_cap = n;
-  }
   SCP_REQUIRE(h % 32 == 0 && w % 32 == 0 && h > 0 && w > 0, "hrnet_forward: H=%d W=%d must be multiples of 32", h, w);
   const size_t need = hrnet_plan(net, n, h, w, mode);
   if (ws_bytes < need || !ws) {
@@ -647,6 +645,8 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
   char* base = static_cast<char*>(ws);
   const std::vector<size_t>& off = net->plan[mode].off;
   auto ptr = [&](int t) -> void* { return t >= 0 ? base + off[t] : nullptr; };
+  float* const part_v = reinterpret_cast<float*>(base + net->plan[mode].part_off);
+  int32_t* const part_i = reinterpret_cast<int32_t*>(base + net->plan[mode].part_off + head_fused_part_bytes(n));
   SCP_REQUIRE(!profile || net->events.size() == net->ops.size() + 1, "hrnet_forward: profiling events missing");
   net->events_valid = false;
   size_t opi = 0;
@@ -693,8 +693,8 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
       const void* terms[4];
       for (int k = 0; k < fo.nterms; ++k) terms[k] = ptr(fo.term[k]);
       rc = head_fused_launch(terms, fo.shift, fo.nterms, n, ty.C, h >> ty.ds, w >> ty.ds, net->desc.num_joints, net->desc.dtype,
-                             net->headf.d_w, net->headf.d_b, heatmaps, dec ? net->headf.d_part_v : nullptr,
-                             dec ? net->headf.d_part_i : nullptr, dec ? dec->center : nullptr, dec ? dec->scale : nullptr,
+                             net->headf.d_w, net->headf.d_b, heatmaps, dec ? part_v : nullptr,
+                             dec ? part_i : nullptr, dec ? dec->center : nullptr, dec ? dec->scale : nullptr,
                              dec ? dec->post_process : 0, dec ? dec->preds : nullptr, st);
     } else if (op.kind == OP_STEM) {
       rc = stem_launch(in, in_fmt, net->d_stem_w, net->d_stem_b, net->d_mean_std, n, h, w,
@@ -849,8 +849,6 @@ void hrnet_free(scpose_hrnet* net) {
   if (net->d_sched) (void)hipFree(net->d_sched);
   if (net->headf.d_w) (void)hipFree(net->headf.d_w);
   if (net->headf.d_b) (void)hipFree(net->headf.d_b);
-  if (net->headf.d_part_v) (void)hipFree(net->headf.d_part_v);
-  if (net->headf.d_part_i) (void)hipFree(net->headf.d_part_i);
   for (auto& e : net->events) if (e) (void)hipEventDestroy(e);
   net->events.clear();
 }

@@ -682,6 +682,255 @@ __device__ void solve_epnp(EpnpCtx& e, const PtSet& ps, double* ut, double rvec[
 }
 #undef UT
 
+// ------------------------------------------------------------------------------------------------------------------
+// Exactly four usable landmarks: cv2.solvePnPRansac switches its kernel (OpenCV 3.4 solvepnp.cpp: `npoints == 4` ->
+// model_points = 4, SOLVEPNP_P3P, and model_points == npoints -> solvePnP directly, no RANSAC), i.e. p3p.cpp: Gao's P3P
+// on the first three correspondences -- a quartic in x = |PA| / |PC| (polynom_solver.cpp) -- gives up to four poses, each
+// completed by Horn's quaternion alignment (p3p::align, jacobi_4x4); the fourth point picks the one it reprojects best.
+// Here the quartic is solved once per wave and its (up to four) real roots go to lanes 0-3, which build, align and score
+// their pose side by side; an ordered scan over those lanes replays the sequential "first minimum wins" choice.
+// Reference call site: pose_estimation/export_predicted_poses_real.py:199-201.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ int solve_deg2(double a, double b, double c, double& x1, double& x2) {
+  const double delta = b * b - 4 * a * c;
+  if (delta < 0) return 0;
+  const double inv_2a = 0.5 / a;
+  if (delta == 0) { x1 = -b * inv_2a; x2 = x1; return 1; }
+  const double sq = sqrt(delta);
+  x1 = (-b + sq) * inv_2a; x2 = (-b - sq) * inv_2a;
+  return 2;
+}
+__device__ int solve_deg3(double a, double b, double c, double d, double& x0, double& x1, double& x2) {
+  if (a == 0) {
+    if (b == 0) {
+      if (c == 0) return 0;
+      x0 = -d / c;
+      return 1;
+    }
+    x2 = 0;
+    return solve_deg2(b, c, d, x0, x1);
+  }
+  const double inv_a = 1. / a, b_a = inv_a * b, b_a2 = b_a * b_a, c_a = inv_a * c, d_a = inv_a * d;
+  const double Q = (3 * c_a - b_a2) / 9, R = (9 * b_a * c_a - 27 * d_a - 2 * b_a * b_a2) / 54;
+  const double Q3 = Q * Q * Q, D = Q3 + R * R, b_a_3 = (1. / 3.) * b_a;
+  if (Q == 0) {
+    if (R == 0) { x0 = x1 = x2 = -b_a_3; return 3; }
+    x0 = pow(2 * R, 1 / 3.0) - b_a_3;
+    return 1;
+  }
+  if (D <= 0) {
+    const double theta = acos(R / sqrt(-Q3)), sqrt_Q = sqrt(-Q);
+    x0 = 2 * sqrt_Q * cos(theta / 3.0) - b_a_3;
+    x1 = 2 * sqrt_Q * cos((theta + 2 * 3.1415926535897932384626433832795) / 3.0) - b_a_3;
+    x2 = 2 * sqrt_Q * cos((theta + 4 * 3.1415926535897932384626433832795) / 3.0) - b_a_3;
+    return 3;
+  }
+  const double AD = pow(fabs(R) + sqrt(D), 1.0 / 3.0) * (R > 0 ? 1 : (R < 0 ? -1 : 0));
+  const double BD = (AD == 0) ? 0 : -Q / AD;
+  x0 = AD + BD - b_a_3;
+  return 1;
+}
+__device__ int solve_deg4(double a, double b, double c, double d, double e, double x[4]) {
+  if (a == 0) { x[3] = 0; return solve_deg3(b, c, d, e, x[0], x[1], x[2]); }
+  const double inv_a = 1. / a;
+  b *= inv_a; c *= inv_a; d *= inv_a; e *= inv_a;
+  const double b2 = b * b, bc = b * c, b3 = b2 * b;
+  double r0, r1, r2;
+  if (solve_deg3(1, -c, d * b - 4 * e, 4 * c * e - d * d - b2 * e, r0, r1, r2) == 0) return 0;
+  const double R2 = 0.25 * b2 - c + r0;
+  if (R2 < 0) return 0;
+  const double R = sqrt(R2), inv_R = 1. / R;
+  double D2, E2;
+  if (R < 10E-12) {
+    const double temp = r0 * r0 - 4 * e;
+    if (temp < 0) D2 = E2 = -1;
+    else {
+      const double st = sqrt(temp);
+      D2 = 0.75 * b2 - 2 * c + 2 * st;
+      E2 = D2 - 4 * st;
+    }
+  } else {
+    const double u = 0.75 * b2 - 2 * c - R2, v = 0.25 * inv_R * (4 * bc - 8 * d - b3);
+    D2 = u + v; E2 = u - v;
+  }
+  const double b_4 = 0.25 * b, R_2 = 0.5 * R;
+  int nb = 0;
+  if (D2 >= 0) {
+    const double D = sqrt(D2);
+    nb = 2;
+    x[0] = R_2 + 0.5 * D - b_4;
+    x[1] = x[0] - D;
+  }
+  if (E2 >= 0) {
+    const double E = sqrt(E2);
+    if (nb == 0) { x[0] = -R_2 + 0.5 * E - b_4; x[1] = x[0] - E; nb = 2; }
+    else { x[2] = -R_2 + 0.5 * E - b_4; x[3] = x[2] - E; nb = 4; }
+  }
+  return nb;
+}
+
+// p3p::jacobi_4x4 (cyclic Jacobi, symmetric 4 x 4, upper triangle used and destroyed)
+__device__ void jacobi_4x4(double* A, double* D, double* U) {
+  double B[4], Z[4];
+  for (int i = 0; i < 16; i++) U[i] = (i % 5 == 0) ? 1. : 0.;
+  B[0] = A[0]; B[1] = A[5]; B[2] = A[10]; B[3] = A[15];
+  for (int i = 0; i < 4; i++) { D[i] = B[i]; Z[i] = 0; }
+  for (int iter = 0; iter < 50; iter++) {
+    const double sum = fabs(A[1]) + fabs(A[2]) + fabs(A[3]) + fabs(A[6]) + fabs(A[7]) + fabs(A[11]);
+    if (sum == 0.0) return;
+    const double tresh = (iter < 3) ? 0.2 * sum / 16. : 0.0;
+    for (int i = 0; i < 3; i++)
+      for (int j = i + 1; j < 4; j++) {
+        double& Aij_ref = A[4 * i + j];
+        const double Aij = Aij_ref, eps_machine = 100.0 * fabs(Aij);
+        if (iter > 3 && fabs(D[i]) + eps_machine == fabs(D[i]) && fabs(D[j]) + eps_machine == fabs(D[j])) {
+          Aij_ref = 0.0;
+        } else if (fabs(Aij) > tresh) {
+          double hh = D[j] - D[i], t;
+          if (fabs(hh) + eps_machine == fabs(hh)) t = Aij / hh;
+          else {
+            const double theta = 0.5 * hh / Aij;
+            t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+            if (theta < 0.0) t = -t;
+          }
+          hh = t * Aij;
+          Z[i] -= hh; Z[j] += hh; D[i] -= hh; D[j] += hh;
+          Aij_ref = 0.0;
+          const double c = 1.0 / sqrt(1 + t * t), sn = t * c, tau = sn / (1.0 + c);
+          auto rot = [&](double& g_ref, double& h_ref) {
+            const double g = g_ref, h = h_ref;
+            g_ref = g - sn * (h + g * tau);
+            h_ref = h + sn * (g - h * tau);
+          };
+          for (int k = 0; k <= i - 1; k++) rot(A[k * 4 + i], A[k * 4 + j]);
+          for (int k = i + 1; k <= j - 1; k++) rot(A[i * 4 + k], A[k * 4 + j]);
+          for (int k = j + 1; k < 4; k++) rot(A[i * 4 + k], A[j * 4 + k]);
+          for (int k = 0; k < 4; k++) rot(U[k * 4 + i], U[k * 4 + j]);
+        }
+      }
+    for (int i = 0; i < 4; i++) { B[i] += Z[i]; D[i] = B[i]; Z[i] = 0; }
+  }
+}
+
+// p3p::align: the rigid motion that takes the three world points X (rows) onto the camera-frame points M
+__device__ void p3p_align(const double M[3][3], const double* X, double R[9], double T[3]) {
+  double Cs[3], Ce[3], sm[9], Qs[16], evs[4], U[16];
+  for (int i = 0; i < 3; i++) { Ce[i] = (M[0][i] + M[1][i] + M[2][i]) / 3; Cs[i] = (X[i] + X[3 + i] + X[6 + i]) / 3; }
+  for (int j = 0; j < 3; j++)
+    for (int i = 0; i < 3; i++) sm[i * 3 + j] = (X[i] * M[0][j] + X[3 + i] * M[1][j] + X[6 + i] * M[2][j]) / 3 - Ce[j] * Cs[i];
+  Qs[0] = sm[0] + sm[4] + sm[8];
+  Qs[5] = sm[0] - sm[4] - sm[8];
+  Qs[10] = sm[4] - sm[8] - sm[0];
+  Qs[15] = sm[8] - sm[0] - sm[4];
+  Qs[4] = Qs[1] = sm[5] - sm[7];
+  Qs[8] = Qs[2] = sm[6] - sm[2];
+  Qs[12] = Qs[3] = sm[1] - sm[3];
+  Qs[9] = Qs[6] = sm[3] + sm[1];
+  Qs[13] = Qs[7] = sm[6] + sm[2];
+  Qs[14] = Qs[11] = sm[7] + sm[5];
+  jacobi_4x4(Qs, evs, U);
+  int i_ev = 0;
+  double ev_max = evs[0];
+  for (int i = 1; i < 4; i++)
+    if (evs[i] > ev_max) { ev_max = evs[i]; i_ev = i; }
+  double q[4];
+  for (int i = 0; i < 4; i++) q[i] = U[i * 4 + i_ev];
+  const double q02 = q[0] * q[0], q12 = q[1] * q[1], q22 = q[2] * q[2], q32 = q[3] * q[3];
+  const double q0_1 = q[0] * q[1], q0_2 = q[0] * q[2], q0_3 = q[0] * q[3], q1_2 = q[1] * q[2], q1_3 = q[1] * q[3], q2_3 = q[2] * q[3];
+  R[0] = q02 + q12 - q22 - q32; R[1] = 2. * (q1_2 - q0_3); R[2] = 2. * (q1_3 + q0_2);
+  R[3] = 2. * (q1_2 + q0_3); R[4] = q02 + q22 - q12 - q32; R[5] = 2. * (q2_3 - q0_1);
+  R[6] = 2. * (q1_3 - q0_2); R[7] = 2. * (q2_3 + q0_1); R[8] = q02 + q32 - q12 - q22;
+  for (int i = 0; i < 3; i++) T[i] = Ce[i] - (R[3 * i] * Cs[0] + R[3 * i + 1] * Cs[1] + R[3 * i + 2] * Cs[2]);
+}
+
+// obj: 4 x 3 (float32-rounded landmarks), upx: 4 x 2 undistorted image points, float32-rounded, mapped back to pixels
+// (p3p::extract_points).  Returns true and (rvec, tvec) wave-uniformly, or false when the first three points admit no pose.
+__device__ bool solve_p3p(const Cam& cam, const double* obj, const double* upx, int lane, double rvec[3], double tvec[3]) {
+  const double inv_fx = 1. / cam.fx, inv_fy = 1. / cam.fy, cx_fx = cam.cx / cam.fx, cy_fy = cam.cy / cam.fy;
+  double m[3][3];
+  for (int i = 0; i < 3; i++) {
+    const double u = inv_fx * upx[2 * i] - cx_fx, v = inv_fy * upx[2 * i + 1] - cy_fy;
+    const double mk = 1. / sqrt(u * u + v * v + 1);
+    m[i][0] = u * mk; m[i][1] = v * mk; m[i][2] = mk;
+  }
+  auto dist3 = [&](int i, int j) {
+    const double dx = obj[3 * i] - obj[3 * j], dy = obj[3 * i + 1] - obj[3 * j + 1], dz = obj[3 * i + 2] - obj[3 * j + 2];
+    return sqrt(dx * dx + dy * dy + dz * dz);
+  };
+  const double d0 = dist3(1, 2), d1 = dist3(0, 2), d2 = dist3(0, 1);
+  const double c0 = m[1][0] * m[2][0] + m[1][1] * m[2][1] + m[1][2] * m[2][2];
+  const double c1 = m[0][0] * m[2][0] + m[0][1] * m[2][1] + m[0][2] * m[2][2];
+  const double c2 = m[0][0] * m[1][0] + m[0][1] * m[1][1] + m[0][2] * m[1][2];
+  // p3p::solve_for_lengths, wave-uniform part: the quartic
+  const double p = c0 * 2, q = c1 * 2, r = c2 * 2;
+  const double inv_d22 = 1. / (d2 * d2), a = inv_d22 * (d0 * d0), b = inv_d22 * (d1 * d1);
+  const double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r, pr = p * r, pqr = q * pr;
+  if (p2 + q2 + r2 - pqr - 1 == 0) return false;
+  const double ab = a * b, a_2 = 2 * a;
+  const double A = -2 * b + b2 + a2 + 1 + ab * (2 - r2) - a_2;
+  if (A == 0) return false;
+  const double a_4 = 4 * a;
+  const double B = q * (-2 * (ab + a2 + 1 - b) + r2 * ab + a_4) + pr * (b - b2 + ab);
+  const double C = q2 + b2 * (r2 + p2 - 2) - b * (p2 + pqr) - ab * (r2 + pqr) + (a2 - a_2) * (2 + q2) + 2;
+  const double D = pr * (ab - b2 + b) + q * ((p2 - 2) * b + 2 * (ab - a2) + a_4 - 2);
+  const double E = 1 + 2 * (b - a - ab) + b2 - b * p2 + a2;
+  const double temp = (p2 * (a - 1 + b) + r2 * (a - 1 - b) + pqr - a * pqr);
+  const double b0 = b * temp * temp;
+  if (b0 == 0) return false;
+  double roots[4] = {0, 0, 0, 0};
+  const int nroots = solve_deg4(A, B, C, D, E, roots);
+  if (nroots == 0) return false;
+  // lane i < nroots: root i -> lengths -> alignment -> reprojection of the fourth point
+  const double r3 = r2 * r, pr2 = p * r2, r3q = r3 * q, inv_b0 = 1. / b0;
+  const int li = lane & 3;
+  const double x = li == 0 ? roots[0] : li == 1 ? roots[1] : li == 2 ? roots[2] : roots[3];
+  bool valid = lane < nroots && x > 0;
+  double Rl[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Tl[3] = {0, 0, 0}, reproj = 0;
+  if (valid) {
+    const double x2 = x * x;
+    const double b1 =
+        ((1 - a - b) * x2 + (q * a - q) * x + 1 - a + b) *
+        (((r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1)) * x +
+          (r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) + pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2))) * x2 +
+         (r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) + r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) +
+          pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b)) * x +
+         2 * r3q * (a_2 - b - a2 + ab - 1) + pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
+         p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1)));
+    valid = b1 > 0;
+    if (valid) {
+      const double y = inv_b0 * b1, v = x2 + y * y - x * y * r;
+      valid = v > 0;
+      if (valid) {
+        const double Z = d2 / sqrt(v), len[3] = {x * Z, y * Z, Z};
+        double M[3][3];
+        for (int j = 0; j < 3; j++) { M[j][0] = len[j] * m[j][0]; M[j][1] = len[j] * m[j][1]; M[j][2] = len[j] * m[j][2]; }
+        p3p_align(M, obj, Rl, Tl);
+        const double X3 = obj[9], Y3 = obj[10], Z3 = obj[11];
+        const double X3p = Rl[0] * X3 + Rl[1] * Y3 + Rl[2] * Z3 + Tl[0];
+        const double Y3p = Rl[3] * X3 + Rl[4] * Y3 + Rl[5] * Z3 + Tl[1];
+        const double Z3p = Rl[6] * X3 + Rl[7] * Y3 + Rl[8] * Z3 + Tl[2];
+        const double du = cam.cx + cam.fx * X3p / Z3p - upx[6], dv = cam.cy + cam.fy * Y3p / Z3p - upx[7];
+        reproj = du * du + dv * dv;
+      }
+    }
+  }
+  // the sequential choice of p3p::solve: first solution, then any later one with a strictly smaller reprojection error
+  const unsigned long long vm = __ballot(valid) & 0xfULL;
+  if (vm == 0ULL) return false;
+  int ns = -1;
+  double min_reproj = 0;
+  for (int i = 0; i < 4; i++) {
+    if (!((vm >> i) & 1ULL)) continue;
+    const double ri = __shfl(reproj, i, 64);
+    if (ns < 0 || min_reproj > ri) { ns = i; min_reproj = ri; }
+  }
+  double Rb[9];
+  for (int k = 0; k < 9; k++) Rb[k] = __shfl(Rl[k], ns, 64);
+  for (int k = 0; k < 3; k++) tvec[k] = __shfl(Tl[k], ns, 64);
+  rodrigues_mat2vec(Rb, rvec);
+  return true;
+}
+
 __device__ int ransac_update_num_iters(double p, double ep, int model_points, int max_iters) {
   p = p > 0. ? p : 0.; p = p < 1. ? p : 1.;
   ep = ep > 0. ? ep : 0.; ep = ep < 1. ? ep : 1.;
@@ -751,7 +1000,8 @@ __global__ __launch_bounds__(256) void pnp_kernel(const PnpArgs a) {
   if (n < 4) {
     status = -1;
   } else if (n == 4) {
-    status = -3;   // OpenCV switches to its P3P kernel for exactly 4 points: not on this path
+    // OpenCV switches to its P3P kernel for exactly four points and skips RANSAC (solve_p3p above); no pose -> -2 like a failed RANSAC
+    status = solve_p3p(cam, s_obj, s_u32, lane, rvec, tvec) ? 4 : -2;
   } else if (n == model_points) {
     PtSet ps{(1ULL << n) - 1ULL, 0u, n, false};
     e.us = s_u32;

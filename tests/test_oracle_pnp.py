@@ -74,3 +74,36 @@ def test_confidence_threshold_loop():
     o = P.solve_batch(kp)
     assert list(o["status"][:3]) == [-1, 5, 11]
     assert abs(0.95 * 0.8 ** 100 - 1.935e-10) < 1e-12
+
+
+def test_p3p_recovers_exact_pose_from_four_points():
+    """Exactly four usable landmarks: solvePnPRansac -> solvePnP(SOLVEPNP_P3P) (pnp_ref.c: solve_pnp_p3p).  Noise-free
+    projections of four non-coplanar landmarks recover the generating pose: up to four poses fit the first three points, the
+    fourth picks the right one.  (float32 rounding of the undistorted points limits the agreement to ~1e-6.)"""
+    rng = np.random.default_rng(44)
+    sets = [[0, 1, 2, 4], [8, 9, 10, 3], [0, 5, 6, 10], [4, 1, 7, 9]]
+    for k in range(40):
+        R = P.random_rotation(rng)
+        t = np.array([rng.uniform(-1, 1), rng.uniform(-0.6, 0.6), rng.uniform(3, 10)])
+        obj = P.LANDMARKS[sets[k % 4]]
+        img = P.project_numpy(R, t, obj).astype(np.float32).astype(np.float64)
+        ok, rv, tv = P.p3p(obj.astype(np.float32).astype(np.float64), img)
+        assert ok
+        assert P.rot_angle(P.rodrigues(rv), R) < 2e-5
+        assert np.linalg.norm(tv - t) / np.linalg.norm(t) < 2e-5
+
+
+def test_four_confident_landmarks_go_through_p3p():
+    """export_predicted_poses_real.py:186-201 with only four scores above the final threshold: status 4 and the P3P pose."""
+    rng = np.random.default_rng(45)
+    kp, Rs, ts = P.synth_keypoints(8, rng, 0.0, 0.0)
+    keep = [0, 2, 5, 9]
+    kp[:, :, 2] = 1e-11
+    kp[:, keep, 2] = 0.99
+    o = P.solve_batch(kp)
+    assert (o["status"] == 4).all()
+    assert P.rot_angle(o["R"], Rs).max() < 2e-5
+    assert (np.linalg.norm(o["t"] - ts, axis=1) / np.linalg.norm(ts, axis=1)).max() < 2e-5
+    # the pose equals the direct P3P call on those four correspondences
+    ok, rv, tv = P.p3p(P.LANDMARKS[keep].astype(np.float32).astype(np.float64), kp[0, keep, :2].astype(np.float64))
+    assert ok and np.abs(rv - o["rvec"][0]).max() < 1e-12 and np.abs(tv - o["t"][0]).max() < 1e-12
