@@ -143,7 +143,7 @@ struct PackedConv {
   size_t w1_bytes = 0;
   int cout_pad1 = 0;
   // tiling chosen by conv_launch_m32 for the last (N, Ho, Wo) seen (the search is a function of those and the layer only)
-  struct TileMemo { int n = -1, ho = 0, wo = 0, th = 0, tw = 0, nseg = 0, nr = 0, ps = 0, occ = 0, cp = 0, cus = 0; };
+  struct TileMemo { int n = -1, ho = 0, wo = 0, th = 0, tw = 0, nseg = 0, nr = 0, ps = 0, occ = 0, cp = 0, cus = 0, nb16 = 0; };
   mutable TileMemo m32_memo[2];   // [0] whole chip, [1] a share of it (concurrent lanes)
   // register-weight stride-2 kernel (conv_s2r.hip): weights [k-step][cout block][k-group][row][8], bias in MFMA row order
   void* d_ws2 = nullptr;

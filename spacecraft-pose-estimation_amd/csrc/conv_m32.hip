@@ -13,12 +13,24 @@ int32_t conv_m32p_dispatch_bf16(int stride, int mr, int nr, int c16, const ConvL
 int32_t conv_m32p_dispatch_f16(int stride, int mr, int nr, int c16, const ConvLaunch& L, size_t lds, hipStream_t st);
 
 // kernel variants built (keep in step with m32_dispatch / m32p_dispatch): occ = resident workgroups
-// per CU of the single-role kernel (1, 2), or 3 = the producer/consumer kernel (512 threads, one per CU)
-struct M32Variant { int mr, wm, nr, occ; };
+// per CU of the single-role kernel (1, 2), or 3 = the producer/consumer kernel (512 threads, one per CU);
+// nb16 > 0: the producer/consumer kernel with 16x16x32 consumers and nb16 columns of 16 pixels per consumer wave
+// (conv_m32p_kernel.h, C16) -- the ONLY family of the layers conv_m16_eligible() names, whatever the batch, so that a
+// frame's sums are formed in one order; nr then only sizes the tile (nb16 * 16 = nr * 32 pixels)
+struct M32Variant { int mr, wm, nr, occ, nb16; };
 static const M32Variant kVariants[] = {
-  {3, 1, 3, 1}, {3, 1, 2, 2}, {3, 1, 1, 3}, {3, 1, 2, 3}, {3, 1, 3, 3},
-  {2, 1, 2, 1}, {2, 1, 4, 1}, {2, 1, 3, 2}, {2, 1, 1, 3}, {2, 1, 2, 3}, {2, 1, 3, 3},
+  {3, 1, 3, 1, 0}, {3, 1, 2, 2, 0}, {3, 1, 1, 3, 0}, {3, 1, 2, 3, 0}, {3, 1, 3, 3, 0},
+  {2, 1, 2, 1, 0}, {2, 1, 4, 1, 0}, {2, 1, 3, 2, 0}, {2, 1, 1, 3, 0}, {2, 1, 2, 3, 0}, {2, 1, 3, 3, 0},
+  {3, 1, 1, 3, 2}, {3, 1, 2, 3, 4}, {3, 1, 3, 3, 5}, {3, 1, 3, 3, 6},
 };
+
+// 16x16x32 consumers: stride-1 3x3 layers with 96-row Cout blocks whose input is a whole number of 32-channel pairs of plane
+// pairs (the consumers process 2-plane groups in pairs) and has at least the three 2-plane chunks the producer/consumer
+// schedule needs: 96 -> 96, 192 -> 192, 384 -> 384 of HRNet-W48.  SCPOSE_M16=0 (development) keeps them on 32x32x16.
+static bool conv_m16_eligible(const PackedConv& pc) {
+  static const char* e = dev_env("SCPOSE_M16");
+  return pc.ks == 3 && pc.stride == 1 && pc.mrep == 3 && pc.wm == 1 && pc.cp == 2 && (pc.cin / 16) % 2 == 0 && pc.cin / 16 >= 3 && !(e && atoi(e) == 0);
+}
 
 bool conv_m32_choose(int cin, int cout, int ks, int stride, int* mr, int* wm, int* cp) {
   static const char* e = dev_env("SCPOSE_M32");
@@ -84,16 +96,17 @@ size_t pack_conv_weights_m32(const float* w, int cout, int cin, int ks, int mt, 
 // weights stay resident (all chunks in LDS) when the layer has one Cout block and they fit
 struct M32pChunking { int cp, nchunks, ksteps_full; };
 static M32pChunking m32p_chunking(const PackedConv& pc, int cp) { return {cp, (pc.cin / 8) / cp, (cp / 2) * pc.ks * pc.ks}; }
-static int m32p_wbufs(const PackedConv& pc, const M32pChunking& ck, int plane_stride, int nr) {
+// (pxcap = pixel slots of a tile group = rows of the retire buffer: 4 waves x nr x 32, or 4 x nb16 x 16)
+static int m32p_wbufs(const PackedConv& pc, const M32pChunking& ck, int plane_stride, int pxcap) {
   const size_t lds_w = (size_t)ck.ksteps_full * 2 * pc.mt * 16;
   const size_t lds_bias = (((size_t)pc.n_mblk * pc.mt * 4) + 511) & ~(size_t)511;
-  const size_t rest = lds_bias + 2 * (size_t)ck.cp * plane_stride + (size_t)(pc.mt / 8) * (4 * nr * 32) * 16;
+  const size_t rest = lds_bias + 2 * (size_t)ck.cp * plane_stride + (size_t)(pc.mt / 8) * pxcap * 16;
   return (pc.n_mblk == 1 && ck.nchunks > 2 && rest + ck.nchunks * lds_w <= 160 * 1024) ? ck.nchunks : 2;
 }
-static size_t m32p_lds_bytes(const PackedConv& pc, const M32pChunking& ck, int plane_stride, int nr) {
+static size_t m32p_lds_bytes(const PackedConv& pc, const M32pChunking& ck, int plane_stride, int pxcap) {
   const size_t lds_w = (size_t)ck.ksteps_full * 2 * pc.mt * 16;
   const size_t lds_bias = (((size_t)pc.n_mblk * pc.mt * 4) + 511) & ~(size_t)511;
-  return lds_bias + m32p_wbufs(pc, ck, plane_stride, nr) * lds_w + 2 * (size_t)ck.cp * plane_stride + (size_t)(pc.mt / 8) * (4 * nr * 32) * 16;
+  return lds_bias + m32p_wbufs(pc, ck, plane_stride, pxcap) * lds_w + 2 * (size_t)ck.cp * plane_stride + (size_t)(pc.mt / 8) * pxcap * 16;
 }
 
 static size_t m32_lds_bytes(const PackedConv& pc, int plane_stride) {
@@ -112,9 +125,10 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   // (one computes while the other is stalled in its memory instructions), then pixels per weight chunk
   double best = -1e30, best_p = 1e30;
   bool found = false, found_p = false;
-  int b_th = 0, b_tw = 0, b_nseg = 0, b_nr = 0, b_ps = 0, b_occ = 1, b_cp = pc.cp;
+  int b_th = 0, b_tw = 0, b_nseg = 0, b_nr = 0, b_ps = 0, b_occ = 1, b_cp = pc.cp, b_nb16 = 0;
   long b_items = 0;
-  int p_th = 0, p_tw = 0, p_nseg = 0, p_nr = 0, p_ps = 0, p_cp = pc.cp;   // best producer/consumer candidate (cost model)
+  int p_th = 0, p_tw = 0, p_nseg = 0, p_nr = 0, p_ps = 0, p_cp = pc.cp, p_nb16 = 0;   // best producer/consumer candidate (cost model)
+  const bool m16 = conv_m16_eligible(pc);
   static const char* cus_env = dev_env("SCPOSE_M32_CUS");   // development: size small layers for a share of the chip (concurrent lanes)
   const int cus_all = conv_device_cus();
   // a share of the chip only for layers that cannot fill it anyway (<= 64 k output pixels: chains of DMA round trips, whose
@@ -125,14 +139,17 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   // the search below depends on (layer, N, Ho, Wo) only: its result is remembered in the layer (a forward launches the
   // same shapes every time; small batches are launch-bound on the host)
   PackedConv::TileMemo& memo = pc.m32_memo[cus != cus_all];
-  const bool memo_hit = memo.n == L.N && memo.ho == L.Ho && memo.wo == L.Wo && memo.cus == cus && !dev_env("SCPOSE_M32_OCC") && !dev_env("SCPOSE_M32_NR") && !dev_env("SCPOSE_M32_CPMUL") && !dev_env("SCPOSE_M32_CUS");
-  if (memo_hit) { found = true; b_th = memo.th; b_tw = memo.tw; b_nseg = memo.nseg; b_nr = memo.nr; b_ps = memo.ps; b_occ = memo.occ; b_cp = memo.cp; }
+  const bool memo_hit = memo.n == L.N && memo.ho == L.Ho && memo.wo == L.Wo && memo.cus == cus && !dev_env("SCPOSE_M32_OCC") && !dev_env("SCPOSE_M32_NR") && !dev_env("SCPOSE_M32_CPMUL") && !dev_env("SCPOSE_M32_CUS") && !dev_env("SCPOSE_M16_NB");
+  if (memo_hit) { found = true; b_th = memo.th; b_tw = memo.tw; b_nseg = memo.nseg; b_nr = memo.nr; b_ps = memo.ps; b_occ = memo.occ; b_cp = memo.cp; b_nb16 = memo.nb16; }
   for (const M32Variant& v : kVariants) {
     if (memo_hit) break;
     static const char* nr_env = dev_env("SCPOSE_M32_NR");   // development: restrict the search to one column count
     if (v.mr != pc.mrep || v.wm != pc.wm || (occ_only && v.occ != occ_only) || (nr_env && v.nr != atoi(nr_env))) continue;
+    if (m16 != (v.nb16 > 0)) continue;   // the layer's kernel family does not depend on the batch (see kVariants)
+    static const char* nb_env = dev_env("SCPOSE_M16_NB");   // development: restrict the search to one column count of the 16x16x32 consumers
+    if (nb_env && v.nb16 > 0 && v.nb16 != atoi(nb_env)) continue;
     const int nr = v.nr;
-    const int cap = wn * nr * 32;
+    const int cap = v.nb16 > 0 ? wn * v.nb16 * 16 : wn * nr * 32;
     if (v.occ == 3 && (pc.nchunks < 3 || (pc.cin / 8) % pc.cp != 0)) continue;   // retire-buffer schedule needs >= 3 equal chunks
     if (pc.stride == 2 && v.occ != 3) continue;
     const int halo_cap = v.occ == 2 ? 512 : 1024;
@@ -163,17 +180,17 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
               const int cp = pc.cp * mul;
               if ((mul > 1 && pc.cp != 2) || (pc.cin / 8) % cp != 0) continue;
               const M32pChunking ck = m32p_chunking(pc, cp);
-              if (ck.nchunks < 3 || m32p_lds_bytes(pc, ck, ps, nr) > lds_cap) continue;
+              if (ck.nchunks < 3 || m32p_lds_bytes(pc, ck, ps, cap) > lds_cap) continue;
               any = true;
               const double per_cu = (double)((items + cus - 1) / cus);
-              const double mfma = (double)v.mr * nr * (cp / 2) * pc.ks * pc.ks * 32.0 * 1.35;
-              const bool res_w = m32p_wbufs(pc, ck, ps, nr) > 2;
+              const double mfma = (double)v.mr * (cap / 128.0) * (cp / 2) * pc.ks * pc.ks * 32.0 * 1.35;
+              const bool res_w = m32p_wbufs(pc, ck, ps, cap) > 2;
               const double bytes = (res_w ? 0.0 : (double)ck.ksteps_full * 2 * pc.mt * 16) + (double)cp * ps +
                                    2.0 * pc.mt * (nseg * th * tw) * 2 / ck.nchunks;
               double stage = (mfma > bytes / 13.0 ? mfma : bytes / 13.0) + 700.0;
               if (stage < 2600.0) stage = 2600.0;
-              const double cost = per_cu * (ck.nchunks * stage + (double)v.mr * nr * 16 * 25.0);
-              if (cost < best_p) { found_p = true; best_p = cost; p_th = th; p_tw = tw; p_nseg = nseg; p_nr = nr; p_ps = ps; p_cp = cp; }
+              const double cost = per_cu * (ck.nchunks * stage + (double)v.mr * (cap / 128.0) * 16 * 25.0);
+              if (cost < best_p) { found_p = true; best_p = cost; p_th = th; p_tw = tw; p_nseg = nseg; p_nr = nr; p_ps = ps; p_cp = cp; p_nb16 = v.nb16; }
             }
             if (!any) break;
             continue;
@@ -189,9 +206,10 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   // layer is a chain of DMA round trips and the small-tile producer/consumer candidates are 1.7-2x faster
   // (W32 batch 64: 128->128 @16x16 30.8 -> 14.9 us, 256->256 @8x8 40.1 -> 23.0 us before deeper chunks)
   if (!memo_hit && found_p && (!found || pc.mrep == 3 || pc.stride == 2 || pc.cout == 48 || b_items <= (long)cus * b_occ)) {
-    found = true; b_th = p_th; b_tw = p_tw; b_nseg = p_nseg; b_nr = p_nr; b_ps = p_ps; b_occ = 3; b_cp = p_cp;
+    found = true; b_th = p_th; b_tw = p_tw; b_nseg = p_nseg; b_nr = p_nr; b_ps = p_ps; b_occ = 3; b_cp = p_cp; b_nb16 = p_nb16;
   }
   SCP_REQUIRE(found, "conv m32: no tiling for %dx%d output", L.Ho, L.Wo);
+  memo.nb16 = b_nb16;
   memo.n = L.N; memo.ho = L.Ho; memo.wo = L.Wo; memo.th = b_th; memo.tw = b_tw; memo.nseg = b_nseg; memo.nr = b_nr; memo.ps = b_ps; memo.occ = b_occ; memo.cp = b_cp; memo.cus = cus;
   L.th = b_th; L.tw = b_tw; L.nt = b_nseg;
   L.tiles_x = (L.Wo + L.tw - 1) / L.tw;
@@ -204,10 +222,11 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   L.lds_w = ck.ksteps_full * 2 * pc.mt * 16;
   L.lds_x = ck.cp * L.plane_stride;
   L.lds_bias = ((pc.n_mblk * pc.mt * 4) + 511) & ~511;
-  L.nbuf_w = b_occ == 3 ? m32p_wbufs(pc, ck, L.plane_stride, b_nr) : (pc.nchunks == 1 && pc.n_mblk == 1) ? 1 : 2;
+  const int pxcap = b_nb16 > 0 ? wn * b_nb16 * 16 : wn * b_nr * 32;
+  L.nbuf_w = b_occ == 3 ? m32p_wbufs(pc, ck, L.plane_stride, pxcap) : (pc.nchunks == 1 && pc.n_mblk == 1) ? 1 : 2;
   L.nbuf_x = 2;
   L.groups = 1;
-  const size_t lds = b_occ == 3 ? m32p_lds_bytes(pc, ck, L.plane_stride, b_nr) : m32_lds_bytes(pc, L.plane_stride);
+  const size_t lds = b_occ == 3 ? m32p_lds_bytes(pc, ck, L.plane_stride, pxcap) : m32_lds_bytes(pc, L.plane_stride);
   L.zero16 = conv_zero_page();
   SCP_REQUIRE(L.zero16, "conv: cannot allocate the zero page");
   L.tiles_total = L.N * L.tiles_x * L.tiles_y;
@@ -226,8 +245,8 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   L.dbg_buf = nullptr;
   if (L.dbg & 8) L.dbg_buf = conv_dbg_buffer(stream);
   if (L.dbg & 32)
-    fprintf(stderr, "m32 %d->%d %dx%d: mr=%d nr=%d occ=%d cp=%d tile %dx%d nseg=%d halo %dx%d lds=%zu items=%d\n", pc.cin, pc.cout, L.Ho, L.Wo,
-            pc.mrep, b_nr, b_occ, L.cp, L.th, L.tw, L.nt, L.halo_h, L.halo_w, lds, L.items_total);
+    fprintf(stderr, "m32 %d->%d %dx%d N=%d: mr=%d nr=%d nb16=%d occ=%d cp=%d tile %dx%d nseg=%d halo %dx%d lds=%zu items=%d\n", pc.cin, pc.cout, L.Ho, L.Wo, L.N,
+            pc.mrep, b_nr, b_nb16, b_occ, L.cp, L.th, L.tw, L.nt, L.halo_h, L.halo_w, lds, L.items_total);
   L.fd_npix = make_fastdiv(L.th * L.tw); L.fd_tw = make_fastdiv(L.tw);
   L.fd_hp = make_fastdiv(L.halo_h * L.halo_w); L.fd_halo_w = make_fastdiv(L.halo_w);
   L.fd_tiles_img = make_fastdiv(L.tiles_x * L.tiles_y); L.fd_tiles_x = make_fastdiv(L.tiles_x);
@@ -240,13 +259,10 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   if (b_occ == 3) {
     // L.groups doubles as "K-chunks of weights held in producer registers" for the producer/consumer kernel
     static const char* wr_env = dev_env("SCPOSE_M32_WREG");
-    L.groups = (pc.n_mblk == 1 && ck.nchunks == 6 && ck.cp == 2 && pc.stride == 1 && pc.mrep == 3 && b_nr == 3 && !(wr_env && atoi(wr_env) == 0)) ? 6 : 1;
-    // 16x16x32 consumers (conv_m32p_kernel.h, C16; round 4): the MFMA-bound stride-1 layers with 96-row Cout blocks, three 32-pixel
-    // columns per consumer wave and an even number of 2-plane chunks (stages are processed in pairs): 96->96, 192->192, 384->384
-    static const char* c16_env = dev_env("SCPOSE_M16");
-    const int c16 = (pc.stride == 1 && pc.mrep == 3 && b_nr == 3 && ck.cp == 2 && ck.nchunks % 2 == 0 && !(c16_env && atoi(c16_env) == 0)) ? 1 : 0;
-    if (pc.dtype == SCPOSE_DT_BF16) return conv_m32p_dispatch_bf16(pc.stride, pc.mrep, b_nr, c16, L, lds, stream);
-    return conv_m32p_dispatch_f16(pc.stride, pc.mrep, b_nr, c16, L, lds, stream);
+    L.groups = (pc.n_mblk == 1 && ck.nchunks == 6 && ck.cp == 2 && pc.stride == 1 && pc.mrep == 3 && (b_nb16 > 0 ? b_nb16 == 6 : b_nr == 3) && !(wr_env && atoi(wr_env) == 0)) ? 6 : 1;
+    // b_nb16 > 0: 16x16x32 consumers (conv_m32p_kernel.h, C16; round 4) -- see conv_m16_eligible
+    if (pc.dtype == SCPOSE_DT_BF16) return conv_m32p_dispatch_bf16(pc.stride, pc.mrep, b_nr, b_nb16, L, lds, stream);
+    return conv_m32p_dispatch_f16(pc.stride, pc.mrep, b_nr, b_nb16, L, lds, stream);
   }
   if (pc.dtype == SCPOSE_DT_BF16) return conv_m32_dispatch_bf16(pc.mrep, pc.wm, b_nr, b_occ, L, lds, stream);
   return conv_m32_dispatch_f16(pc.mrep, pc.wm, b_nr, b_occ, L, lds, stream);

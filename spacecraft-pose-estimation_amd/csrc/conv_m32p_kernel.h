@@ -22,6 +22,31 @@
 
 namespace scpose {
 
+// ---- 16x16x32 consumers (C16 > 0): compile-time schedule ----------------------------------------------------------------
+// k-step S of a pair of plane pairs: class 0 reads tap m16_tap0(S), class 1 the tap one pixel (or, m16_rowpair, one row) further
+constexpr int m16_tap0(int S) { return S == 0 ? 0 : S == 1 ? 3 : S == 2 ? 6 : S == 3 ? 2 : S == 4 ? 8 : S == 5 ? 0 : S == 6 ? 3 : S == 7 ? 6 : 5; }
+constexpr bool m16_rowpair(int S) { return S == 3 || S == 8; }
+// B fragments live in a ring of NB + 1 registers: column N of k-step S sits in slot (N - S) mod RING, so the request for column N
+// of k-step S + 1 goes to the slot column N - 1 released one column earlier (never to a register an MFMA in flight still reads)
+constexpr int m16_ring(int N, int S, int RING) { return ((N - S) % RING + 4 * RING) % RING; }
+// behind column n a prefetching k-step requests m16_na(NB, n) of the next k-step's six A fragments, then its B fragment of column n
+constexpr int m16_na(int NB, int n) { return NB == 2 ? 3 : (n < 2 ? 2 : n < 4 ? 1 : 0); }   // NB 6: 2 2 1 1 0 0, 5: 2 2 1 1 0, 4: 2 2 1 1, 2: 3 3
+constexpr int m16_afirst(int NB, int n) { int a = 0; for (int k = 0; k < n; ++k) a += m16_na(NB, k); return a; }
+constexpr int m16_issued(int NB, int n) { return m16_afirst(NB, n) + n; }   // requests of a prefetching k-step in front of its column n
+constexpr int m16_ja(int NB) { return NB == 2 ? 1 : 3; }                    // the column that requests the last A fragment
+// LDS returns in order: lgkmcnt value to wait for in front of column n (-1: what it needs is older than something already waited for).
+// first: the k-step's fragments were requested in one burst, A0..5 B0..NB-1; more: the k-step itself prefetches.
+constexpr int m16_wait(int NB, int n, bool first, bool more) {
+  if (first) return (NB - 1 - n) + (more ? m16_issued(NB, n) : 0);
+  if (n == 0) return NB - m16_ja(NB);
+  if (n < m16_ja(NB)) return -1;
+  return (NB - 1 - n) + (more ? m16_issued(NB, n) : 0);
+}
+static_assert(m16_wait(6, 0, true, true) == 5 && m16_wait(6, 1, true, true) == 7 && m16_wait(6, 3, true, true) == 10 && m16_wait(6, 5, true, true) == 11, "");
+static_assert(m16_wait(6, 0, false, true) == 3 && m16_wait(6, 2, false, true) == -1 && m16_wait(6, 3, false, true) == 10 && m16_wait(6, 4, false, true) == 11, "");
+static_assert(m16_wait(6, 0, false, false) == 3 && m16_wait(6, 3, false, false) == 2 && m16_wait(6, 5, false, false) == 0, "");
+static_assert(m16_wait(2, 0, false, true) == 1 && m16_wait(2, 1, false, true) == 4 && m16_wait(5, 4, false, true) == 10 && m16_wait(4, 3, false, true) == 8, "");
+
 // WREG > 0: the layer has ONE Cout block of WREG K-chunks and the producers keep all of its packed weights in
 // their (otherwise idle) registers -- 7 x 16 B per thread and chunk -- and refill the LDS chunk buffers with
 // ds_write_b128 instead of LDS-DMA: 7 of the ~16 memory instructions a producer wave issues per stage disappear.
@@ -54,7 +79,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
   constexpr int MT = 32 * MR;
   constexpr int KK = KS * KS;
   constexpr int MAXP = 4;
-  constexpr int PXCAP = 4 * NR * 32;           // pixel slots of a tile group
+  constexpr int PXCAP = C16 ? 64 * C16 : 4 * NR * 32;   // pixel slots of a tile group (16x16x32 consumers: four waves x C16 columns of 16)
   constexpr int ROPL = MT / 8;                 // planes of a Cout block
   constexpr int NQ = (PXCAP + 255) / 256;      // retire-buffer pixels per producer thread and plane
 
@@ -333,20 +358,24 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
     // =====================================================================================
     // consumers, 16x16x32 form (see the header comment): LDS reads, MFMAs, epilogue into the retire buffer
     // =====================================================================================
-    static_assert(KS == 3 && MT % 16 == 0, "16x16x32 consumers: 3x3 layers");
+    static_assert(KS == 3 && MT == 96, "16x16x32 consumers: 3x3 layers, 96-row Cout blocks");
     constexpr int MB = MT / 16;          // 16-row blocks of the Cout block
-    constexpr int NB = 2 * NR;           // 16-pixel columns of the wave's 32 * NR pixel slots
+    constexpr int NB = C16;              // 16-pixel columns of a consumer wave (PXCAP = 64 NB pixel slots per tile group)
     constexpr int RING = NB + 1;
     constexpr int TAPB = 2 * MT * 16;    // bytes of one tap (both planes) in the packed weight image
-    static_assert(MB == 6 && NB == 6, "16x16x32 consumers: the k-step schedule below is written for 6 x 6 accumulators");
+    static_assert(NB == 2 || NB == 4 || NB == 5 || NB == 6, "16x16x32 consumers: column counts with a prefetch schedule");
     typedef f32x4 acc_t;
-    // Lane (q = lane >> 4, l15 = lane & 15): plane q & 1 of the stage's two; class q >> 1 picks the tap of a k-step's pair.
+    // Lane (q = lane >> 4, l15 = lane & 15): plane q & 1 of a plane pair; class q >> 1 picks the tap of a k-step's pair.
     // Pairs are chosen so that the two classes' fragment addresses differ by a constant: one pixel (taps kx, kx + 1 of a row) or
     // one row (taps (ky, 2), (ky + 1, 2)), so a B address is  pixoffq[n] + class shift + (uniform: buffer + tap)  -- one v_add3
-    // with the uniform part in an SGPR -- and an A address is a per-stage base + an immediate:
+    // with the uniform part in an SGPR -- and an A address is a per-half base + an immediate.  Over a PAIR of plane pairs
+    // (32 channels: nine k-steps; m16_tap0 / m16_rowpair):
     //   k-step    0      1      2      3      4 (straddle)        5      6      7      8
     //   taps    0 | 1  3 | 4  6 | 7  2 | 5  8 even | 2 odd       0 | 1  3 | 4  6 | 7  5 | 8
-    int pixoffq[NB];   // byte offset of this lane's pixel (column n) in its plane of a staged chunk
+    // With 2-plane stages (p.cp == 2) the even and the odd plane pair are two STAGES and k-step 4 straddles their barrier; with
+    // deeper stages (small batches) both halves read the same stage's buffers.  Either way a pixel's
+    // fp32 sums are formed by the same MFMAs in the same order, whatever the tile, the column count or the stage depth.
+    int pixoffq[NB];   // byte offset of this lane's pixel (column n) in its plane of a staged plane pair
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
       int ps, py, px;
@@ -358,114 +387,151 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
     acc_t acc[MB][NB];
     frag_t a0[MB], a1[MB], bR[RING];
     const bool wave_idle = wave * NB * 16 >= P;   // wave-uniform
+    const int npp = p.cp >> 1;                    // plane pairs per stage: 1 (the halves of a pair are two stages), 2 or 4
     int wc = 0, xb = 0;
     __syncthreads();   // matches the producers' prologue barrier
 
     unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
     auto now = [&]() -> unsigned long long { return SCP_DBG(p, 8) ? __builtin_amdgcn_s_memtime() : 0ull; };
-    auto add3 = [](uint32_t a, uint32_t b, uint32_t c_uniform) -> uint32_t {   // opaque to the compiler: 54 hoisted addresses otherwise
+    auto add3 = [](uint32_t a, uint32_t b, uint32_t c_uniform) -> uint32_t {   // opaque to the compiler: dozens of hoisted addresses otherwise
       uint32_t d;
       asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
       return d;
     };
-#define M16_WAIT(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-#define M16_BREG(S, N) bR[((N) - (S) + 4 * RING) % RING]
-#define M16_TAP0(S) ((S) == 0 ? 0 : (S) == 1 ? 3 : (S) == 2 ? 6 : (S) == 3 ? 2 : (S) == 4 ? 8 : (S) == 5 ? 0 : (S) == 6 ? 3 : (S) == 7 ? 6 : 5)
-#define M16_ROWPAIR(S) ((S) == 3 || (S) == 8)   // the classes' taps are one ROW apart (else one pixel)
-#define M16_RDA(S, M, NA) lds_read16<M16_TAP0(S) * TAPB + (M) * 256>(NA[M], M16_ROWPAIR(S) ? wa3 : wa1);
-#define M16_RDB(S, N) lds_read16<0>(M16_BREG(S, N), add3((uint32_t)pixoffq[N], M16_ROWPAIR(S) ? sh_row : sh_px, \
-                                                         xl + (uint32_t)(M16_TAP0(S) / 3) * hw16 + (uint32_t)(M16_TAP0(S) % 3) * 16u));
-    // Issue order of a k-step's prefetch: A'0 A'1 B'0 | A'2 A'3 B'1 | A'4 B'2 | A'5 B'3 | B'4 | B'5.  Column 0 of the next k-step
-    // needs A'0..5 and B'0 = all but the three youngest requests -> lgkmcnt(3); column 3 needs B'3 with B'4 B'5 and the eight
-    // requests of the new k-step's columns 0-2 behind it -> lgkmcnt(10); columns 4, 5: lgkmcnt(11).  A k-step whose twelve
-    // fragments were requested in one burst (FIRST: A0..5 B0..5) counts 5 7 9 10 11 11; one that prefetches nothing 3 - - 2 1 0.
-#define M16_WAITOF(FIRST, N, MORE) ((FIRST) ? ((N) == 0 ? 5 : (N) == 1 ? 7 : (N) == 2 ? 9 : (N) == 3 ? 10 : 11) \
-                                            : (MORE) ? ((N) == 0 ? 3 : (N) == 3 ? 10 : (N) >= 4 ? 11 : -1)       \
-                                                     : ((N) == 0 ? 3 : (N) >= 3 ? 5 - (N) : -1))
-#define M16_COL(S, N, CA, NA, MORE, FIRST)                                                                               \
-    {                                                                                                                    \
-      if constexpr (M16_WAITOF(FIRST, N, MORE) >= 0) { M16_WAIT(M16_WAITOF(FIRST, N, MORE) < 0 ? 0 : M16_WAITOF(FIRST, N, MORE)) } \
-      if constexpr ((N) == 0) { _Pragma("unroll") for (int m = 0; m < MB; ++m) lds_landed(CA[m]); }                      \
-      lds_landed(M16_BREG(S, N));                                                                                        \
-      mfma16_acc<T>(acc[0][N], CA[0], M16_BREG(S, N)); mfma16_acc<T>(acc[1][N], CA[1], M16_BREG(S, N));                  \
-      if constexpr (MORE) { if constexpr ((N) == 0) { M16_RDA((S) + 1, 0, NA) } else if constexpr ((N) == 1) { M16_RDA((S) + 1, 2, NA) } \
-                            else if constexpr ((N) == 2) { M16_RDA((S) + 1, 4, NA) } else if constexpr ((N) == 3) { M16_RDA((S) + 1, 5, NA) } } \
-      mfma16_acc<T>(acc[2][N], CA[2], M16_BREG(S, N)); mfma16_acc<T>(acc[3][N], CA[3], M16_BREG(S, N));                  \
-      if constexpr (MORE) { if constexpr ((N) == 0) { M16_RDA((S) + 1, 1, NA) } else if constexpr ((N) == 1) { M16_RDA((S) + 1, 3, NA) } } \
-      mfma16_acc<T>(acc[4][N], CA[4], M16_BREG(S, N));                                                                   \
-      if constexpr (MORE) { M16_RDB((S) + 1, N) }                                                                        \
-      mfma16_acc<T>(acc[5][N], CA[5], M16_BREG(S, N));                                                                   \
-    }
-#define M16_KSTEP(S, CA, NA, MORE, FIRST) M16_COL(S, 0, CA, NA, MORE, FIRST) M16_COL(S, 1, CA, NA, MORE, FIRST) M16_COL(S, 2, CA, NA, MORE, FIRST) \
-                                          M16_COL(S, 3, CA, NA, MORE, FIRST) M16_COL(S, 4, CA, NA, MORE, FIRST) M16_COL(S, 5, CA, NA, MORE, FIRST)
-    // per-stage A bases, formed behind an opaque copy of the lane id so that they are not kept live across stages
-#define M16_STAGE_BASES(WL)                                                                              \
+    // request fragment M of k-step S (bases of the half that k-step reads) / the B fragment of column N of k-step S
+    auto rd_a = [&](auto s_, auto m_, frag_t* dst, uint32_t wa1, uint32_t wa3) {
+      constexpr int S = decltype(s_)::value, M = decltype(m_)::value;
+      lds_read16<m16_tap0(S) * TAPB + M * 256>(dst[M], m16_rowpair(S) ? wa3 : wa1);
+    };
+    auto rd_b = [&](auto s_, auto n_, uint32_t xl) {
+      constexpr int S = decltype(s_)::value, N = decltype(n_)::value;
+      lds_read16<0>(bR[m16_ring(N, S, RING)], add3((uint32_t)pixoffq[N], m16_rowpair(S) ? sh_row : sh_px,
+                                                    xl + (uint32_t)(m16_tap0(S) / 3) * hw16 + (uint32_t)(m16_tap0(S) % 3) * 16u));
+    };
+    // One column of a k-step: wait (counted) for its B fragment, six MFMAs, and between them this column's share of the next
+    // k-step's requests (m16_na of its A fragments, its B fragment of this column); wa1n / wa3n / xln: bases of k-step S + 1.
+    auto kcol = [&](auto s_, auto n_, auto more_, auto first_, frag_t* CA, frag_t* NA, uint32_t wa1n, uint32_t wa3n, uint32_t xln) {
+      constexpr int S = decltype(s_)::value, N = decltype(n_)::value;
+      constexpr bool MORE = decltype(more_)::value, FIRST = decltype(first_)::value;
+      constexpr int W = m16_wait(NB, N, FIRST, MORE);
+      if constexpr (W >= 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(W < 0 ? 0 : W) : "memory");
+      if constexpr (N == 0) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) lds_landed(CA[m]);
+      }
+      frag_t& b = bR[m16_ring(N, S, RING)];
+      lds_landed(b);
+      constexpr int NA_ = MORE ? m16_na(NB, N) : 0, AF = m16_afirst(NB, N);
+      using SN = std::integral_constant<int, S + 1>;
+      mfma16_acc<T>(acc[0][N], CA[0], b);
+      if constexpr (NA_ == 3) rd_a(SN{}, std::integral_constant<int, AF < 6 ? AF : 0>{}, NA, wa1n, wa3n);
+      mfma16_acc<T>(acc[1][N], CA[1], b);
+      if constexpr (NA_ == 1 || NA_ == 2) rd_a(SN{}, std::integral_constant<int, AF < 6 ? AF : 0>{}, NA, wa1n, wa3n);
+      mfma16_acc<T>(acc[2][N], CA[2], b);
+      if constexpr (NA_ == 3) rd_a(SN{}, std::integral_constant<int, AF + 1 < 6 ? AF + 1 : 0>{}, NA, wa1n, wa3n);
+      mfma16_acc<T>(acc[3][N], CA[3], b);
+      if constexpr (NA_ >= 2) rd_a(SN{}, std::integral_constant<int, AF + NA_ - 1 < 6 ? AF + NA_ - 1 : 0>{}, NA, wa1n, wa3n);
+      mfma16_acc<T>(acc[4][N], CA[4], b);
+      if constexpr (MORE) rd_b(SN{}, n_, xln);
+      mfma16_acc<T>(acc[5][N], CA[5], b);
+    };
+    auto kstep = [&](auto s_, auto more_, auto first_, frag_t* CA, frag_t* NA, uint32_t wa1n, uint32_t wa3n, uint32_t xln) {
+      kcol(s_, std::integral_constant<int, 0>{}, more_, first_, CA, NA, wa1n, wa3n, xln);
+      kcol(s_, std::integral_constant<int, 1>{}, more_, first_, CA, NA, wa1n, wa3n, xln);
+      if constexpr (NB > 2) kcol(s_, std::integral_constant<int, 2>{}, more_, first_, CA, NA, wa1n, wa3n, xln);
+      if constexpr (NB > 3) kcol(s_, std::integral_constant<int, 3>{}, more_, first_, CA, NA, wa1n, wa3n, xln);
+      if constexpr (NB > 4) kcol(s_, std::integral_constant<int, 4>{}, more_, first_, CA, NA, wa1n, wa3n, xln);
+      if constexpr (NB > 5) kcol(s_, std::integral_constant<int, 5>{}, more_, first_, CA, NA, wa1n, wa3n, xln);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+    using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>; using I8 = std::integral_constant<int, 8>;
+    using Yes = std::true_type; using No = std::false_type;
+    // per-half A bases, formed behind an opaque copy of the lane id so that they are not kept live across halves
+#define M16_BASES(WL)                                                                                    \
       uint32_t lane_s = (uint32_t)lane;                                                                  \
       asm volatile("" : "+v"(lane_s));                                                                   \
       const uint32_t wa0 = (WL) + ((((lane_s >> 4) & 1) * MT + (lane_s & 15)) * 16);                     \
       const uint32_t wa1 = wa0 + (lane_s >> 5) * TAPB, wa3 = wa0 + (lane_s >> 5) * (3 * TAPB);
+    if (wave_idle) {
+      // a consumer wave whose pixel slots all lie past the work item's pixels (two 12 x 12 images fill 288 of 384 slots) has
+      // nothing to compute: it only keeps the barriers.  (Its own loop: a conditional around the k-steps would keep every
+      // fragment register live across the epilogue.)
+      for (int it = it_begin; it < it_end; ++it)
+        for (int c = 0; c < p.nchunks; ++c) __builtin_amdgcn_s_barrier();
+    } else
     for (int it = it_begin; it < it_end; ++it) {
       const int mb = it - fdiv(it, p.fd_nmblk) * p.n_mblk;
-      for (int c = 0; c < p.nchunks; c += 2) {
-        const bool compute = !(SCP_DBG(p, 1) || wave_idle);
-        // ---------------- even stage: taps 0|1 3|4 6|7 2|5 of chunk c, and the lower half of the straddling k-step (tap 8) ----------------
-        {
-          const unsigned long long t0 = now();
-          const uint32_t xl = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(xl0 + xb * p.lds_x));
-          M16_STAGE_BASES((uint32_t)(size_t)(wl0 + (w_resident ? c : (wc & 1)) * p.lds_w))
-          (void)wa0;
-          if (compute) {   // the first fragments fly while the accumulators are initialised
-            M16_RDA(0, 0, a0) M16_RDA(0, 1, a0) M16_RDA(0, 2, a0) M16_RDA(0, 3, a0) M16_RDA(0, 4, a0) M16_RDA(0, 5, a0)
-            M16_RDB(0, 0) M16_RDB(0, 1) M16_RDB(0, 2) M16_RDB(0, 3) M16_RDB(0, 4) M16_RDB(0, 5)
-          }
-          if (c == 0) {   // accumulators start at the bias of their rows: row(j) = 16 m + 4 q + j
-            const float* bq = bias_l + mb * MT + 4 * (lane_s >> 4);
-#pragma unroll
-            for (int m = 0; m < MB; ++m) {
-              const float4 b4 = *reinterpret_cast<const float4*>(bq + m * 16);
-#pragma unroll
-              for (int n = 0; n < NB; ++n) { acc[m][n][0] = b4.x; acc[m][n][1] = b4.y; acc[m][n][2] = b4.z; acc[m][n][3] = b4.w; }
+      for (int c = 0; c < p.nchunks; c += (npp == 1 ? 2 : 1)) {
+        const bool last = c + (npp == 1 ? 2 : 1) >= p.nchunks;
+        unsigned long long t0 = now(), t_mid = 0;
+        for (int u = 0; 2 * u < npp || u == 0; ++u) {   // pairs of plane pairs of this stage (one, split over two stages, when npp == 1)
+          // ---------------- even plane pair: taps 0|1 3|4 6|7 2|5, and the lower half of the straddling k-step (tap 8) ----------------
+          {
+            const uint32_t xl = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(xl0 + xb * p.lds_x) + (uint32_t)(4 * u) * (uint32_t)p.plane_stride);
+            M16_BASES((uint32_t)(size_t)(wl0 + (w_resident ? c : (wc & 1)) * p.lds_w) + (uint32_t)(2 * u) * (9 * TAPB))
+            (void)wa0;
+            {   // the first fragments fly while the accumulators are initialised
+              rd_a(I0{}, I0{}, a0, wa1, wa3); rd_a(I0{}, I1{}, a0, wa1, wa3); rd_a(I0{}, I2{}, a0, wa1, wa3);
+              rd_a(I0{}, I3{}, a0, wa1, wa3); rd_a(I0{}, I4{}, a0, wa1, wa3); rd_a(I0{}, I5{}, a0, wa1, wa3);
+              rd_b(I0{}, I0{}, xl); rd_b(I0{}, I1{}, xl);
+              if constexpr (NB > 2) rd_b(I0{}, I2{}, xl);
+              if constexpr (NB > 3) rd_b(I0{}, I3{}, xl);
+              if constexpr (NB > 4) rd_b(I0{}, I4{}, xl);
+              if constexpr (NB > 5) rd_b(I0{}, I5{}, xl);
             }
-            // VALU write -> MFMA SrcC needs wait states the hazard recogniser cannot see around inline-asm MFMAs (conv_device.h)
+            if (c == 0 && u == 0) {   // accumulators start at the bias of their rows: row(j) = 16 m + 4 q + j
+              const float* bq = bias_l + mb * MT + 4 * (lane_s >> 4);
 #pragma unroll
-            for (int m = 0; m < MB; ++m)
+              for (int m = 0; m < MB; ++m) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bq + m * 16);
 #pragma unroll
-              for (int n = 0; n < NB; ++n) mfma_input_fence<false>(acc[m][n]);
+                for (int n = 0; n < NB; ++n) { acc[m][n][0] = b4.x; acc[m][n][1] = b4.y; acc[m][n][2] = b4.z; acc[m][n][3] = b4.w; }
+              }
+              // VALU write -> MFMA SrcC needs wait states the hazard recogniser cannot see around inline-asm MFMAs (conv_device.h)
+#pragma unroll
+              for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) mfma_input_fence<false>(acc[m][n]);
+            }
+            if (!SCP_DBG(p, 1)) {   // (development build: bit 1 skips the MFMA loops -- wrong results, timing ablation; folds away in the product)
+              kstep(I0{}, Yes{}, Yes{}, a0, a1, wa1, wa3, xl); kstep(I1{}, Yes{}, No{}, a1, a0, wa1, wa3, xl);
+              kstep(I2{}, Yes{}, No{}, a0, a1, wa1, wa3, xl);
+              kstep(I3{}, Yes{}, No{}, a1, a0, wa1, wa3, xl);   // requests k-step 4 from THIS half's buffers: tap 8 for class 0 (class 1's lanes are refilled below)
+#pragma unroll
+              for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) mfma_result_fence<false>(acc[m][n]);
+            }
           }
-          if (compute) {
-            M16_KSTEP(0, a0, a1, true, true) M16_KSTEP(1, a1, a0, true, false) M16_KSTEP(2, a0, a1, true, false)
-            M16_KSTEP(3, a1, a0, true, false)   // prefetches k-step 4 from THIS stage's buffers: tap 8 for class 0 (class 1's slots are refilled below)
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-              for (int n = 0; n < NB; ++n) mfma_result_fence<false>(acc[m][n]);
+          if (npp == 1) {   // the halves are two stages: the straddling fragments land before the producers may refill these buffers
+            const unsigned long long t1 = now();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long t2 = now();
+            __builtin_amdgcn_s_barrier();
+            if SCP_DBG(p, 8) { const unsigned long long t3 = now(); tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; t0 = t3; }
+            xb ^= 1; ++wc;
           }
-          const unsigned long long t1 = now();
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the straddling fragments have landed before the producers may refill these buffers
-          if (compute) {
+          {
 #pragma unroll
             for (int m = 0; m < MB; ++m) lds_landed(a0[m]);
 #pragma unroll
-            for (int n = 0; n < NB; ++n) lds_landed(M16_BREG(4, n));
+            for (int n = 0; n < NB; ++n) lds_landed(bR[m16_ring(n, 4, RING)]);
           }
-          const unsigned long long t2 = now();
-          __builtin_amdgcn_s_barrier();
-          if SCP_DBG(p, 8) { const unsigned long long t3 = now(); tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; }
-          xb ^= 1; ++wc;
-        }
-        // ---------------- odd stage: upper half of the straddling k-step (tap 2), then taps 0|1 3|4 6|7 5|8 of chunk c + 1 ----------------
-        {
-          const unsigned long long t0 = now();
-          const bool last = c + 2 >= p.nchunks;
-          const uint32_t xl = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(xl0 + xb * p.lds_x));
-          M16_STAGE_BASES((uint32_t)(size_t)(wl0 + (w_resident ? c + 1 : (wc & 1)) * p.lds_w))
-          if (compute) {
-            {   // lanes 32-63 (class 1): their group of k-step 4 is tap 2 of this stage; lanes 0-31 keep what they hold
+          // ---------------- odd plane pair: upper half of the straddling k-step (tap 2), then taps 0|1 3|4 6|7 5|8 ----------------
+          {
+            const uint32_t xl = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(xl0 + xb * p.lds_x) +
+                                                              (npp == 1 ? 0u : (uint32_t)(4 * u + 2) * (uint32_t)p.plane_stride));
+            M16_BASES((uint32_t)(size_t)(wl0 + (w_resident ? c + (npp == 1 ? 1 : 0) : (wc & 1)) * p.lds_w) + (npp == 1 ? 0u : (uint32_t)(2 * u + 1) * (9 * TAPB)))
+            {
+              // lanes 32-63 (class 1): their group of k-step 4 is tap 2 of this plane pair; lanes 0-31 keep what they hold.  ONE asm
+              // statement, so that nothing the compiler schedules runs under the narrowed EXEC.
               uint32_t xa[NB];
 #pragma unroll
               for (int n = 0; n < NB; ++n) xa[n] = add3((uint32_t)pixoffq[n], 0u, xl + 32u);
               unsigned long long keep;
-              asm volatile(
+              if constexpr (NB == 6) {
+                asm volatile(
                   "s_mov_b64 %[keep], exec\n\t"
                   "s_mov_b32 exec_lo, 0\n\t"
                   "ds_read_b128 %[a0], %[wm] offset:%[o0]\n\t"
@@ -482,85 +548,141 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
                   "ds_read_b128 %[b5], %[x5]\n\t"
                   "s_mov_b64 exec, %[keep]"
                   : [keep] "=&s"(keep), [a0] "+v"(a0[0]), [a1] "+v"(a0[1]), [a2] "+v"(a0[2]), [a3] "+v"(a0[3]), [a4] "+v"(a0[4]), [a5] "+v"(a0[5]),
-                    [b0] "+v"(M16_BREG(4, 0)), [b1] "+v"(M16_BREG(4, 1)), [b2] "+v"(M16_BREG(4, 2)), [b3] "+v"(M16_BREG(4, 3)),
-                    [b4] "+v"(M16_BREG(4, 4)), [b5] "+v"(M16_BREG(4, 5))
+                    [b0] "+v"(bR[m16_ring(0, 4, RING)]), [b1] "+v"(bR[m16_ring(1, 4, RING)]), [b2] "+v"(bR[m16_ring(2, 4, RING)]), [b3] "+v"(bR[m16_ring(3, 4, RING)]), [b4] "+v"(bR[m16_ring(4, 4, RING)]), [b5] "+v"(bR[m16_ring(5, 4, RING)])
                   : [wm] "v"(wa0), [x0] "v"(xa[0]), [x1] "v"(xa[1]), [x2] "v"(xa[2]), [x3] "v"(xa[3]), [x4] "v"(xa[4]), [x5] "v"(xa[5]),
-                    [o0] "n"(2 * TAPB), [o1] "n"(2 * TAPB + 256), [o2] "n"(2 * TAPB + 512), [o3] "n"(2 * TAPB + 768), [o4] "n"(2 * TAPB + 1024),
-                    [o5] "n"(2 * TAPB + 1280)
+                    [o0] "n"(2 * TAPB + 0), [o1] "n"(2 * TAPB + 256), [o2] "n"(2 * TAPB + 512), [o3] "n"(2 * TAPB + 768), [o4] "n"(2 * TAPB + 1024), [o5] "n"(2 * TAPB + 1280)
                   : "memory");
-            }
-            M16_KSTEP(4, a0, a1, true, true) M16_KSTEP(5, a1, a0, true, false) M16_KSTEP(6, a0, a1, true, false)
-            M16_KSTEP(7, a1, a0, true, false) M16_KSTEP(8, a0, a1, false, false)
-            // last MFMA's result visible to the VALU -- only the tile's last stage is followed by VALU reads of the accumulators
-            if (last) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-              for (int n = 0; n < NB; ++n) mfma_result_fence<false>(acc[m][n]);
-          }
-          const unsigned long long t1 = now();
-          if (last && !wave_idle) {
-            // retire: RO <- ReLU(acc + residual), in place.  A lane holds rows 16 m + 4 q .. + 3 of its pixel: channels 4 (q & 1) .. + 3
-            // of output plane 2 m + (q >> 1), i.e. one 8-byte half-slot per accumulator -- no lane exchange, no separate bias add.
-            const uint32_t relu_floor = p.relu ? 0u : 0x80008000u;
-            // (the slot address is formed HERE, behind an opaque copy of the lane id: hoisted out of the tile loop it would be
-            // live across the k-steps, which have no register to spare)
-            uint32_t lane_e = (uint32_t)lane;
-            asm volatile("" : "+v"(lane_e));
-            char* const slot0 = ro + ((((lane_e >> 5) & 1) * PXCAP) + wave * NB * 16 + (lane_e & 15)) * 16 + 8 * ((lane_e >> 4) & 1);
-            auto slot = [&](int m, int n) -> char* { return slot0 + ((2 * m) * PXCAP + n * 16) * 16; };
-            if (!p.res) {
+              } else if constexpr (NB == 5) {
+                asm volatile(
+                  "s_mov_b64 %[keep], exec\n\t"
+                  "s_mov_b32 exec_lo, 0\n\t"
+                  "ds_read_b128 %[a0], %[wm] offset:%[o0]\n\t"
+                  "ds_read_b128 %[a1], %[wm] offset:%[o1]\n\t"
+                  "ds_read_b128 %[a2], %[wm] offset:%[o2]\n\t"
+                  "ds_read_b128 %[a3], %[wm] offset:%[o3]\n\t"
+                  "ds_read_b128 %[a4], %[wm] offset:%[o4]\n\t"
+                  "ds_read_b128 %[a5], %[wm] offset:%[o5]\n\t"
+                  "ds_read_b128 %[b0], %[x0]\n\t"
+                  "ds_read_b128 %[b1], %[x1]\n\t"
+                  "ds_read_b128 %[b2], %[x2]\n\t"
+                  "ds_read_b128 %[b3], %[x3]\n\t"
+                  "ds_read_b128 %[b4], %[x4]\n\t"
+                  "s_mov_b64 exec, %[keep]"
+                  : [keep] "=&s"(keep), [a0] "+v"(a0[0]), [a1] "+v"(a0[1]), [a2] "+v"(a0[2]), [a3] "+v"(a0[3]), [a4] "+v"(a0[4]), [a5] "+v"(a0[5]),
+                    [b0] "+v"(bR[m16_ring(0, 4, RING)]), [b1] "+v"(bR[m16_ring(1, 4, RING)]), [b2] "+v"(bR[m16_ring(2, 4, RING)]), [b3] "+v"(bR[m16_ring(3, 4, RING)]), [b4] "+v"(bR[m16_ring(4, 4, RING)])
+                  : [wm] "v"(wa0), [x0] "v"(xa[0]), [x1] "v"(xa[1]), [x2] "v"(xa[2]), [x3] "v"(xa[3]), [x4] "v"(xa[4]),
+                    [o0] "n"(2 * TAPB + 0), [o1] "n"(2 * TAPB + 256), [o2] "n"(2 * TAPB + 512), [o3] "n"(2 * TAPB + 768), [o4] "n"(2 * TAPB + 1024), [o5] "n"(2 * TAPB + 1280)
+                  : "memory");
+              } else if constexpr (NB == 4) {
+                asm volatile(
+                  "s_mov_b64 %[keep], exec\n\t"
+                  "s_mov_b32 exec_lo, 0\n\t"
+                  "ds_read_b128 %[a0], %[wm] offset:%[o0]\n\t"
+                  "ds_read_b128 %[a1], %[wm] offset:%[o1]\n\t"
+                  "ds_read_b128 %[a2], %[wm] offset:%[o2]\n\t"
+                  "ds_read_b128 %[a3], %[wm] offset:%[o3]\n\t"
+                  "ds_read_b128 %[a4], %[wm] offset:%[o4]\n\t"
+                  "ds_read_b128 %[a5], %[wm] offset:%[o5]\n\t"
+                  "ds_read_b128 %[b0], %[x0]\n\t"
+                  "ds_read_b128 %[b1], %[x1]\n\t"
+                  "ds_read_b128 %[b2], %[x2]\n\t"
+                  "ds_read_b128 %[b3], %[x3]\n\t"
+                  "s_mov_b64 exec, %[keep]"
+                  : [keep] "=&s"(keep), [a0] "+v"(a0[0]), [a1] "+v"(a0[1]), [a2] "+v"(a0[2]), [a3] "+v"(a0[3]), [a4] "+v"(a0[4]), [a5] "+v"(a0[5]),
+                    [b0] "+v"(bR[m16_ring(0, 4, RING)]), [b1] "+v"(bR[m16_ring(1, 4, RING)]), [b2] "+v"(bR[m16_ring(2, 4, RING)]), [b3] "+v"(bR[m16_ring(3, 4, RING)])
+                  : [wm] "v"(wa0), [x0] "v"(xa[0]), [x1] "v"(xa[1]), [x2] "v"(xa[2]), [x3] "v"(xa[3]),
+                    [o0] "n"(2 * TAPB + 0), [o1] "n"(2 * TAPB + 256), [o2] "n"(2 * TAPB + 512), [o3] "n"(2 * TAPB + 768), [o4] "n"(2 * TAPB + 1024), [o5] "n"(2 * TAPB + 1280)
+                  : "memory");
+              } else if constexpr (NB == 2) {
+                asm volatile(
+                  "s_mov_b64 %[keep], exec\n\t"
+                  "s_mov_b32 exec_lo, 0\n\t"
+                  "ds_read_b128 %[a0], %[wm] offset:%[o0]\n\t"
+                  "ds_read_b128 %[a1], %[wm] offset:%[o1]\n\t"
+                  "ds_read_b128 %[a2], %[wm] offset:%[o2]\n\t"
+                  "ds_read_b128 %[a3], %[wm] offset:%[o3]\n\t"
+                  "ds_read_b128 %[a4], %[wm] offset:%[o4]\n\t"
+                  "ds_read_b128 %[a5], %[wm] offset:%[o5]\n\t"
+                  "ds_read_b128 %[b0], %[x0]\n\t"
+                  "ds_read_b128 %[b1], %[x1]\n\t"
+                  "s_mov_b64 exec, %[keep]"
+                  : [keep] "=&s"(keep), [a0] "+v"(a0[0]), [a1] "+v"(a0[1]), [a2] "+v"(a0[2]), [a3] "+v"(a0[3]), [a4] "+v"(a0[4]), [a5] "+v"(a0[5]),
+                    [b0] "+v"(bR[m16_ring(0, 4, RING)]), [b1] "+v"(bR[m16_ring(1, 4, RING)])
+                  : [wm] "v"(wa0), [x0] "v"(xa[0]), [x1] "v"(xa[1]),
+                    [o0] "n"(2 * TAPB + 0), [o1] "n"(2 * TAPB + 256), [o2] "n"(2 * TAPB + 512), [o3] "n"(2 * TAPB + 768), [o4] "n"(2 * TAPB + 1024), [o5] "n"(2 * TAPB + 1280)
+                  : "memory");
+              }
+              if (!SCP_DBG(p, 1)) {
+                kstep(I4{}, Yes{}, Yes{}, a0, a1, wa1, wa3, xl); kstep(I5{}, Yes{}, No{}, a1, a0, wa1, wa3, xl);
+                kstep(I6{}, Yes{}, No{}, a0, a1, wa1, wa3, xl); kstep(I7{}, Yes{}, No{}, a1, a0, wa1, wa3, xl);
+                kstep(I8{}, No{}, No{}, a0, a1, wa1, wa3, xl);
+              }
 #pragma unroll
               for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int n = 0; n < NB; ++n) {
-                  uint2 o;
-                  o.x = relu2_16(pack2<T>(acc[m][n][0], acc[m][n][1]), relu_floor);
-                  o.y = relu2_16(pack2<T>(acc[m][n][2], acc[m][n][3]), relu_floor);
-                  *reinterpret_cast<uint2*>(slot(m, n)) = o;     // padding pixels write their own slots too: the producers never store those
-                }
-            } else {
-              // residual half-slots are read one row block ahead of the one being finalised (the in-place writes would otherwise
-              // order every read behind the previous write)
-              uint2 rr[2][NB];
+                for (int n = 0; n < NB; ++n) mfma_result_fence<false>(acc[m][n]);
+            }
+          }
+        }
+        t_mid = now();
+        if (last) {
+          // last MFMA's result visible to the VALU -- only the tile's last stage is followed by VALU reads of the accumulators
+          asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
-              for (int n = 0; n < NB; ++n) rr[0][n] = *reinterpret_cast<const uint2*>(slot(0, n));
+          for (int m = 0; m < MB; ++m)
 #pragma unroll
-              for (int m = 0; m < MB; ++m) {
-                if (m + 1 < MB) {
+            for (int n = 0; n < NB; ++n) mfma_result_fence<false>(acc[m][n]);
+          // retire: RO <- ReLU(acc + residual), in place.  A lane holds rows 16 m + 4 q .. + 3 of its pixel: channels 4 (q & 1) .. + 3
+          // of output plane 2 m + (q >> 1), i.e. one 8-byte half-slot per accumulator -- no lane exchange, no separate bias add.
+          const uint32_t relu_floor = p.relu ? 0u : 0x80008000u;
+          // (the slot address is formed HERE, behind an opaque copy of the lane id: hoisted out of the tile loop it would be
+          // live across the k-steps, which have no register to spare)
+          uint32_t lane_e = (uint32_t)lane;
+          asm volatile("" : "+v"(lane_e));
+          char* const slot0 = ro + ((((lane_e >> 5) & 1) * PXCAP) + wave * NB * 16 + (lane_e & 15)) * 16 + 8 * ((lane_e >> 4) & 1);
+          auto slot = [&](int m, int n) -> char* { return slot0 + ((2 * m) * PXCAP + n * 16) * 16; };
+          if (!p.res) {
 #pragma unroll
-                  for (int n = 0; n < NB; ++n) rr[(m + 1) & 1][n] = *reinterpret_cast<const uint2*>(slot(m + 1, n));
-                }
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int n = 0; n < NB; ++n) {
-                  const uint2 x = rr[m & 1][n];
-                  const float v0 = acc[m][n][0] + from_bits<T>(x.x & 0xffff), v1 = acc[m][n][1] + from_bits<T>(x.x >> 16);
-                  const float v2 = acc[m][n][2] + from_bits<T>(x.y & 0xffff), v3 = acc[m][n][3] + from_bits<T>(x.y >> 16);
-                  uint2 o;
-                  o.x = relu2_16(pack2<T>(v0, v1), relu_floor); o.y = relu2_16(pack2<T>(v2, v3), relu_floor);
-                  *reinterpret_cast<uint2*>(slot(m, n)) = o;
-                }
+              for (int n = 0; n < NB; ++n) {
+                uint2 o;
+                o.x = relu2_16(pack2<T>(acc[m][n][0], acc[m][n][1]), relu_floor);
+                o.y = relu2_16(pack2<T>(acc[m][n][2], acc[m][n][3]), relu_floor);
+                *reinterpret_cast<uint2*>(slot(m, n)) = o;     // padding pixels write their own slots too: the producers never store those
+              }
+          } else {
+            // residual half-slots are read one row block ahead of the one being finalised (the in-place writes would otherwise
+            // order every read behind the previous write)
+            uint2 rr[2][NB];
+#pragma unroll
+            for (int n = 0; n < NB; ++n) rr[0][n] = *reinterpret_cast<const uint2*>(slot(0, n));
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+              if (m + 1 < MB) {
+#pragma unroll
+                for (int n = 0; n < NB; ++n) rr[(m + 1) & 1][n] = *reinterpret_cast<const uint2*>(slot(m + 1, n));
+              }
+#pragma unroll
+              for (int n = 0; n < NB; ++n) {
+                const uint2 x = rr[m & 1][n];
+                const float v0 = acc[m][n][0] + from_bits<T>(x.x & 0xffff), v1 = acc[m][n][1] + from_bits<T>(x.x >> 16);
+                const float v2 = acc[m][n][2] + from_bits<T>(x.y & 0xffff), v3 = acc[m][n][3] + from_bits<T>(x.y >> 16);
+                uint2 o;
+                o.x = relu2_16(pack2<T>(v0, v1), relu_floor); o.y = relu2_16(pack2<T>(v2, v3), relu_floor);
+                *reinterpret_cast<uint2*>(slot(m, n)) = o;
               }
             }
           }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          const unsigned long long t2 = now();
-          __builtin_amdgcn_s_barrier();
-          if SCP_DBG(p, 8) { const unsigned long long t3 = now(); tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; }
-          xb ^= 1; ++wc;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long t2 = now();
+        __builtin_amdgcn_s_barrier();
+        if SCP_DBG(p, 8) { const unsigned long long t3 = now(); tph[0] += t_mid - t0; tph[1] += t2 - t_mid; tph[2] += t3 - t2; }
+        xb ^= 1; ++wc;
       }
     }
-#undef M16_STAGE_BASES
-#undef M16_KSTEP
-#undef M16_COL
-#undef M16_WAITOF
-#undef M16_RDB
-#undef M16_RDA
-#undef M16_ROWPAIR
-#undef M16_TAP0
-#undef M16_BREG
-#undef M16_WAIT
+#undef M16_BASES
     if (SCP_DBG(p, 8) && SCP_DBG_BUF(p) && lane == 0)
       for (int k = 0; k < 6; ++k) SCP_DBG_BUF(p)[((size_t)blockIdx.x * 8 + wave_all) * 6 + k] = tph[k];
   } else {
@@ -774,9 +896,14 @@ int32_t m32p_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
 
 template <int DT>
 int32_t m32p_dispatch(int stride, int mr, int nr, int c16, const ConvLaunch& L, size_t lds, hipStream_t st) {
-  if (c16) {   // 16x16x32 consumers (conv_launch_m32 routes only stride 1, 96-row blocks, 3 columns, an even number of 2-plane chunks here)
-    if (stride == 1 && mr == 3 && nr == 3) return L.groups == 6 ? m32p_launch_one<DT, 1, 3, 3, 6, 1>(L, lds, st) : m32p_launch_one<DT, 1, 3, 3, 0, 1>(L, lds, st);
-    set_error("conv m32p: 16x16x32 consumer variant stride=%d mr=%d nr=%d not built", stride, mr, nr);
+  if (c16) {   // 16x16x32 consumers, c16 = 16-pixel columns per consumer wave (conv_launch_m32 routes only stride 1 and 96-row blocks here)
+    if (stride == 1 && mr == 3) {
+      if (c16 == 6) return L.groups == 6 ? m32p_launch_one<DT, 1, 3, 3, 6, 6>(L, lds, st) : m32p_launch_one<DT, 1, 3, 3, 0, 6>(L, lds, st);
+      if (c16 == 5) return m32p_launch_one<DT, 1, 3, 3, 0, 5>(L, lds, st);
+      if (c16 == 4) return m32p_launch_one<DT, 1, 3, 2, 0, 4>(L, lds, st);
+      if (c16 == 2) return m32p_launch_one<DT, 1, 3, 1, 0, 2>(L, lds, st);
+    }
+    set_error("conv m32p: 16x16x32 consumer variant stride=%d mr=%d columns=%d not built", stride, mr, c16);
     return SCPOSE_E_INVALID;
   }
   if (stride == 2) {
