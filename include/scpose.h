@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SCPOSE_ABI_VERSION 5
+#define SCPOSE_ABI_VERSION 6
 
 enum {
   SCPOSE_OK = 0,
@@ -190,6 +190,12 @@ int32_t scpose_hrnet_forward_tap(scpose_hrnet_t h, const void* in, int32_t in_fm
 int32_t scpose_hrnet_forward_profiled(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n,
                                       int32_t height, int32_t width, float* heatmaps,
                                       void* workspace, size_t workspace_bytes, void* stream);
+/* (ABI 6) the same hook for scpose_hrnet_forward_decode: the launch list of the key-point path (fused tail with the decode
+ * inside, no heat-map written when `heatmaps` is NULL) -- what bench.py's timed steps replay -- with per-launch events */
+int32_t scpose_hrnet_forward_decode_profiled(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n, int32_t height,
+                                             int32_t width, const float* center, const float* scale, int32_t post_process,
+                                             float* preds_xyc, float* heatmaps, void* workspace, size_t workspace_bytes,
+                                             void* stream);
 int32_t scpose_hrnet_profile_read(scpose_hrnet_t h, int32_t height, int32_t width, int32_t cap,
                                   float* ms, double* flops_per_frame, double* bytes_per_frame,
                                   int32_t* sig, int32_t* count);

@@ -21,7 +21,7 @@ if os.environ.get("SCPOSE_DEV") == "1":
 
 DT_BF16, DT_F16 = 0, 1
 IN_F32_NCHW, IN_U8_NHWC = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class HrnetDesc(ctypes.Structure):
@@ -71,6 +71,8 @@ SYMBOLS = {
                                            POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), c_void_p, c_size_t, c_void_p]),
     "scpose_hrnet_forward_profiled": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                                 c_void_p, c_size_t, c_void_p]),
+    "scpose_hrnet_forward_decode_profiled": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
+                                                       c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "scpose_hrnet_profile_read": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                             c_void_p, POINTER(c_int32)]),
     "scpose_decode": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,

@@ -10,12 +10,19 @@
 // every tile (672 of the 1 150 KB of LDS reads per tile are A fragments; LDS is active 49 % of the time too).
 // Here a wave belongs to ONE layer for the kernel's whole life:
 //   waves 0-3 (one per SIMD)  conv1 of tile i      x tile (LDS)  -> intermediate tile i (LDS, ReLU, 16-bit)
-//   waves 4-7 (one per SIMD)  conv2 of tile i - 1   intermediate tile i - 1 (LDS) + residual (global) -> output (global)
+//   waves 4-7 (one per SIMD)  conv2 of tile i - 1   intermediate tile i - 1 (LDS) + residual (the tile's own input) -> output (global)
 // * its layer's packed weights never leave its registers (C = 48: 14 k-steps x 3 row blocks x 4 VGPRs = 168), so the MFMA
 //   A operands cost no LDS read at all and LDS holds nothing but the double-buffered input tile (2 x 38.4 KB) and the
 //   double-buffered intermediate tile (2 x 32 KB);
 // * while one layer's wave is in its epilogue the other layer's wave on the same SIMD is issuing MFMAs; one workgroup
 //   barrier per tile.
+// * residual (round 4): the block's residual IS the centre of its input tile, which is in LDS -- but conv2 of tile i - 1 runs
+//   while that buffer is being refilled with tile i + 1.  So at the END of step i - 1, when the buffer is still whole (conv1 has
+//   been reading it all step; the LDS-DMA of that step went to the other buffer) and the conv2 waves' accumulator and fragment
+//   registers are free, every conv2 lane fetches the residual vectors of ITS output pixels of tile i - 1: the first pass's
+//   (MREP vectors) stay in registers across the barrier, the second pass's go through a lane-private LDS slot (rl0), because
+//   2 x MREP vectors next to the first pass's accumulators and fragments are 12 registers more than the 168 of weights leave.
+//   Round 3 re-read them from global memory (through L2): 226 MB of the launch's 422 MB of fabric fetches at batch 256.
 // Same MFMA (v_mfma_f32_16x16x32), same K order, same accumulator initialisation (bias) and the same rounding points as
 // conv_block_kernel.h: results are bit-identical to it.
 #pragma once
@@ -23,7 +30,8 @@
 
 namespace scpose {
 
-constexpr size_t block2_lds_bytes(int mrep) { return 1024 + 2 * 2 * mrep * (size_t)(block_xs() + block_ms()); }
+// + the residual hand-over area: MREP 16-byte vectors per conv2 lane (see "residual" in the kernel)
+constexpr size_t block2_lds_bytes(int mrep) { return 1024 + 2 * 2 * mrep * (size_t)(block_xs() + block_ms()) + (size_t)mrep * 256 * 16; }
 
 template <int DT, int MREP>
 __global__ __launch_bounds__(512, 2) void conv_block2_kernel(const BlockLaunch p) {
@@ -34,6 +42,7 @@ __global__ __launch_bounds__(512, 2) void conv_block2_kernel(const BlockLaunch p
   constexpr int XS = block_xs(), MS = block_ms();
   char* const xl0 = smem + 1024;                       // [2][PLANES][20 x 20][16 B]
   char* const ml0 = xl0 + 2 * PLANES * XS;             // [2][PLANES][18 x 18 (+ pad)][16 B]
+  char* const rl0 = ml0 + 2 * PLANES * MS;             // [MREP][256 conv2 lanes][16 B]: residual vectors of the second pass (below)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, r = lane & 15, half = lane >> 5, psel = q & 1, hi = q >> 1;
@@ -103,13 +112,13 @@ __global__ __launch_bounds__(512, 2) void conv_block2_kernel(const BlockLaunch p
 
   // k-loop: NCOL columns, the layer's A fragments from registers, B fragments two k-steps ahead (a k-step is 3-6 MFMAs = 48-96
   // cycles on this wave's pipe: less than an LDS read takes when the other seven waves read too)
-  auto kloop = [&](auto ncol_c, auto role_c, const char* tile, const int* pixoff, f32x4 (*acc)[3], auto&& side) {
+  auto kloop = [&](auto ncol_c, auto role_c, const char* tile, const int* pixoff, f32x4 (*acc)[3], auto&& side, int psel_k) {
     constexpr int NCOL = decltype(ncol_c)::value;
     constexpr int ROLE = decltype(role_c)::value;
     constexpr int PS = ROLE ? MS : XS, ROWW = ROLE ? 18 : 20;
     const char* base[NCOL];
 #pragma unroll
-    for (int n = 0; n < NCOL; ++n) base[n] = tile + psel * PS + pixoff[n];
+    for (int n = 0; n < NCOL; ++n) base[n] = tile + psel_k * PS + pixoff[n];
     int hi_ = hi;
     asm volatile("" : "+v"(hi_));   // the per-k-step selects below stay in the loop (one VALU each) instead of being hoisted
                                     // out of the tile loop into registers the weights need
@@ -151,9 +160,11 @@ __global__ __launch_bounds__(512, 2) void conv_block2_kernel(const BlockLaunch p
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
     return t;
   };
-  // step i: conv1 of tile t_begin + i (i < ntiles) beside conv2 of tile t_begin + i - 1 (i >= 1); one barrier per step
-  for (int i = 0; i <= ntiles; ++i) {
-    if (role == 0) {
+  // step i: conv1 of tile t_begin + i (i < ntiles) beside conv2 of tile t_begin + i - 1 (i >= 1); one barrier per step.
+  // (Two loops, one per role, with the same number of barriers: values one role carries from step to step -- the conv2 waves'
+  // residual registers -- are then not live in the other role's code, which has no register to spare either.)
+  if (role == 0) {
+    for (int i = 0; i <= ntiles; ++i) {
       if (i < ntiles) {
         const int t = t_begin + i;
         int img, oy0, ox0;
@@ -198,8 +209,8 @@ __global__ __launch_bounds__(512, 2) void conv_block2_kernel(const BlockLaunch p
           }
           const unsigned long long s1 = now();
           auto none = [](auto) {};
-          if (ncol == 2) kloop(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, xl, pixoff, acc, none);
-          else kloop(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, xl, pixoff, acc, none);
+          if (ncol == 2) kloop(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, xl, pixoff, acc, none, psel);
+          else kloop(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, xl, pixoff, acc, none, psel);
           const unsigned long long s2 = now();
           tph[1] += s2 - s1;
 #pragma unroll
@@ -222,7 +233,16 @@ __global__ __launch_bounds__(512, 2) void conv_block2_kernel(const BlockLaunch p
           tph[2] += now() - s2;
         }
       }
-    } else {
+      const unsigned long long s9 = now();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // intermediate tile i complete and input tile i + 1 landed | intermediate tile i - 1 and input tile i free
+      tph[5] += now() - s9;
+    }
+  } else {
+    u32x4 res0[MREP];   // residual vectors of the coming step's first pass
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) res0[m] = u32x4{0u, 0u, 0u, 0u};
+    for (int i = 0; i <= ntiles; ++i) {
       const unsigned long long s0 = now();
       // the next input tile (its buffer held tile i - 1: conv1 finished reading it a barrier ago) is requested from inside the k-loops
       // below, one LDS-DMA instruction per k-step: an LDS-DMA instruction blocks its wave while the path is busy (~140 cycles each
@@ -251,17 +271,24 @@ __global__ __launch_bounds__(512, 2) void conv_block2_kernel(const BlockLaunch p
         const char* ml = ml0 + ((i - 1) & 1) * (PLANES * MS);
         // 16 columns = the tile's 16 rows: wave rw owns rows rw + 4 j, two at a time (the lower half-wave ends up with the
         // first row's pixel, the upper half-wave with the second row's)
-#pragma unroll 1
-        for (int pass = 0; pass < 2; ++pass) {
+        // (the two passes are two instances of one body: in a rolled loop the first pass's residual registers would be live through
+        // the second pass too)
+        auto conv2_pass = [&](auto pass_c) {
+          constexpr int pass = decltype(pass_c)::value;
           const int row0 = rw + 8 * pass, row1 = row0 + 4;
-          int rr = r;
-          asm volatile("" : "+v"(rr));                            // (see issue_x)
-          const int oy = oy0 + (half ? row1 : row0), ox = ox0 + rr;
+          int rt2 = tid;
+          asm volatile("" : "+v"(rt2));                           // (see issue_x: per-pass lane geometry is formed here, from an opaque
+                                                                  // copy of the thread id, or the unrolled passes' constants get hoisted)
+          const int rr = rt2 & 15, half_ = (rt2 >> 5) & 1, psel_ = (rt2 >> 4) & 1;
+          const int oy = oy0 + (half_ ? row1 : row0), ox = ox0 + rr;
           const bool store_ok = oy < p.H && ox < p.W;
-          const uint32_t gvoff = store_ok ? (uint32_t)((img * PLANES + psel) * HW + oy * p.W + ox) * 16u : BUF_OOB;
+          const uint32_t gvoff = store_ok ? (uint32_t)((img * PLANES + psel_) * HW + oy * p.W + ox) * 16u : BUF_OOB;
           u32x4 resv[MREP];                                       // residual: this lane's output pixel of x, planes 2 m + psel
 #pragma unroll
-          for (int m = 0; m < MREP; ++m) resv[m] = load16_buf(rs_in, gvoff, (uint32_t)(2 * m * HW) * 16u);
+          for (int m = 0; m < MREP; ++m) {
+            if constexpr (pass == 0) resv[m] = res0[m];             // fetched at the end of the previous step, kept in registers
+            else resv[m] = *reinterpret_cast<const u32x4*>(rl0 + m * 4096 + (rt2 & 255) * 16);
+          }
           int pixoff[2] = {(row0 * 18 + rr) * 16, (row1 * 18 + rr) * 16};
           f32x4 acc[MREP][3];
 #pragma unroll
@@ -280,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void conv_block2_kernel(const BlockLaunch p
             constexpr int S = decltype(sc)::value;
             if constexpr (S < PLANES) { if (dma_on) x_dma(xv, pass, S, (i + 1) & 1); }
           };
-          kloop(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, ml, pixoff, acc, side);
+          kloop(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, ml, pixoff, acc, side, psel_);
           const unsigned long long s2 = now();
           tph[1] += s2 - s1;
 #pragma unroll
@@ -307,14 +334,29 @@ __global__ __launch_bounds__(512, 2) void conv_block2_kernel(const BlockLaunch p
             store16_buf(rs_out, gvoff, (uint32_t)(2 * m * HW) * 16u, ov);
           }
           tph[2] += now() - s2;
-        }
+        };
+        conv2_pass(std::integral_constant<int, 0>{});
+        conv2_pass(std::integral_constant<int, 1>{});
+      }
+      // residual of tile i for the next step (see the header comment): its input buffer is whole until the barrier below
+      if (i < ntiles) {
+        int tt = tid;
+        asm volatile("" : "+v"(tt));                               // lane geometry recomputed here (see issue_x): nothing of it lives across the passes
+        const int l_ = tt & 63, rr = l_ & 15, ps_ = (l_ >> 4) & 1, hf_ = l_ >> 5, rw_ = (tt >> 6) & 3;
+        const char* xc = xl0 + (i & 1) * (PLANES * XS) + ps_ * XS + ((2 + rw_ + 4 * hf_) * 20 + 2 + rr) * 16;   // centre pixel (rw | rw + 4, rr), plane psel
+        char* rl = rl0 + (tt & 255) * 16;
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) res0[m] = *reinterpret_cast<const u32x4*>(xc + 2 * m * XS);                // first pass: rows rw | rw + 4
+#pragma unroll
+        for (int m = 0; m < MREP; ++m)                                                                           // second pass: 8 rows further down
+          *reinterpret_cast<u32x4*>(rl + m * 4096) = *reinterpret_cast<const u32x4*>(xc + 2 * m * XS + 8 * 20 * 16);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next input tile has landed (this wave's pieces)
+      const unsigned long long s9 = now();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // intermediate tile i complete and input tile i + 1 landed | intermediate tile i - 1 and input tile i free
+      tph[5] += now() - s9;
     }
-    const unsigned long long s9 = now();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // intermediate tile i complete and input tile i + 1 landed | intermediate tile i - 1 and input tile i free
-    tph[5] += now() - s9;
   }
   if (SCP_DBG_BUF(p) && lane == 0)
     for (int k = 0; k < 6; ++k) SCP_DBG_BUF(p)[((size_t)blockIdx.x * 8 + wave) * 6 + k] = tph[k];

@@ -1115,6 +1115,17 @@ extern "C" int32_t scpose_hrnet_forward_profiled(scpose_hrnet_t h, const void* i
                        static_cast<hipStream_t>(stream), true);
 }
 
+extern "C" int32_t scpose_hrnet_forward_decode_profiled(scpose_hrnet_t h, const void* in, int32_t in_fmt, int32_t n, int32_t height,
+                                                        int32_t width, const float* center, const float* scale, int32_t post_process,
+                                                        float* preds_xyc, float* heatmaps, void* workspace, size_t workspace_bytes,
+                                                        void* stream) {
+  SCP_REQUIRE(h && in && center && scale && preds_xyc, "hrnet_forward_decode_profiled: null argument");
+  SCP_REQUIRE(h->desc.head == SCPOSE_HEAD_FINAL_LAYER || heatmaps, "hrnet_forward_decode_profiled: the hrnet_cms heads need a heat-map buffer");
+  const scpose::HeadDecode dec{center, scale, post_process, preds_xyc};
+  return hrnet_forward(h, in, in_fmt, n, height, width, heatmaps, workspace, workspace_bytes,
+                       static_cast<hipStream_t>(stream), true, -1, 0, nullptr, &dec);
+}
+
 extern "C" int32_t scpose_hrnet_profile_read(scpose_hrnet_t h, int32_t height, int32_t width,
                                              int32_t cap, float* ms, double* flops_per_frame,
                                              double* bytes_per_frame, int32_t* sig, int32_t* count) {

@@ -344,10 +344,11 @@ class HrnetEngine:
         nat.check(nat.lib().scpose_hrnet_tail_fused(self._h, n, h, w, ctypes.byref(k)), "hrnet_tail_fused")
         return bool(k.value)
 
-    def forward_decode(self, x, center, scale, post_process=True, heatmaps=False):
+    def forward_decode(self, x, center, scale, post_process=True, heatmaps=False, profile=False):
         """Key points straight from the forward (scpose_hrnet_forward_decode): (N, J, 3) [x_img, y_img, maxval], bit-identical
         to decode(forward(x), center, scale, post_process).  For pose_hrnet with a 1x1 final layer no heat-map is written
-        unless heatmaps=True (then (preds, heatmaps) is returned); other heads always go through a heat-map buffer."""
+        unless heatmaps=True (then (preds, heatmaps) is returned); other heads always go through a heat-map buffer.
+        profile=True records a HIP event around every launch (read with profile_read())."""
         _need_cuda(x, center, scale)
         x = x.contiguous()
         if x.dtype == torch.uint8:
@@ -368,9 +369,10 @@ class HrnetEngine:
             hm = torch.empty((n, self.num_joints, oh, ow), dtype=torch.float32, device=x.device)
         cc = center.contiguous().float(); ss = scale.contiguous().float()
         preds = torch.empty((n, self.num_joints, 3), dtype=torch.float32, device=x.device)
-        nat.check(nat.lib().scpose_hrnet_forward_decode(self._h, _ptr(x), fmt, n, h, w, _ptr(cc), _ptr(ss), int(bool(post_process)),
-                                                        _ptr(preds), _ptr(hm) if hm is not None else None, _ptr(self._ws),
-                                                        self._ws.numel(), _stream()), "hrnet_forward_decode")
+        fn = nat.lib().scpose_hrnet_forward_decode_profiled if profile else nat.lib().scpose_hrnet_forward_decode
+        nat.check(fn(self._h, _ptr(x), fmt, n, h, w, _ptr(cc), _ptr(ss), int(bool(post_process)),
+                     _ptr(preds), _ptr(hm) if hm is not None else None, _ptr(self._ws),
+                     self._ws.numel(), _stream()), "hrnet_forward_decode")
         self._last_hw = (h, w)
         return (preds, hm) if heatmaps else preds
 

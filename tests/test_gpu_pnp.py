@@ -72,13 +72,11 @@ def test_pnp_exactly_four_points_take_the_p3p_branch(gpu_ops):
     """export_predicted_poses_real.py:199-201 with four usable landmarks: cv2.solvePnPRansac switches to solvePnP(SOLVEPNP_P3P)
     (OpenCV 3.4 solvepnp.cpp; p3p.cpp, polynom_solver.cpp) -- Gao's P3P on the first three points, the fourth picks among up to
     four poses.  The kernel spreads the quartic's roots over lanes 0-3 (csrc/pnp.hip: solve_p3p); the oracle runs them one after
-    the other.  Noise-free and noisy key points, several landmark subsets (so that point order and geometry vary).
-    P3P on a 0.7 m target at 3-10 m is ill-conditioned in a tail of the cases (x = |PA|/|PC| ~ 1: near-multiple roots of the
-    quartic, for cv2 as for this restatement), where the last bits of acos / cos / pow -- libm in the oracle, the device library
-    in the kernel -- are amplified: the north-star bounds are asserted on the frames whose quartic is well separated (the
-    oracle's pose reprojects its own first three points to < 1e-2 px, which P3P does exactly in exact arithmetic: 64 % of
-    these frames) and the
-    selected solution (status, sign of the pose) on all of them."""
+    the other.  Noise-free and noisy key points, four landmark subsets (point order and geometry vary).
+    P3P on a 0.7 m target at 3-10 m is ill-conditioned in a third of the cases (x = |PA| / |PC| ~ 1: near-multiple roots of the
+    quartic -- for cv2 as for this restatement: the returned pose then misses its own first three points by > 1e-2 px), so the
+    known-answer check against the generating pose is made on the well-conditioned frames only; kernel = oracle is asserted
+    on ALL frames (measured: 4e-8 rad, bit-identical translations, the ill-conditioned ones included)."""
     rng = np.random.default_rng(46)
     subsets = [[0, 2, 5, 9], [1, 3, 4, 10], [8, 6, 0, 7], [2, 9, 4, 3]]
     n = 256
@@ -88,25 +86,19 @@ def test_pnp_exactly_four_points_take_the_p3p_branch(gpu_ops):
     for i in range(n):
         kp[i, subsets[i % 4], 2] = 0.99
     ref = P.solve_batch(kp)
-    rot, tv, st, rv = _gpu(gpu_ops, kp)
-    assert np.array_equal(st, ref["status"]) and set(st.tolist()) <= {4, -2}
-    ok = st == 4
-    assert ok.mean() > 0.9
+    gpu = _gpu(gpu_ops, kp)
+    assert set(ref["status"].tolist()) <= {4, -2} and (ref["status"] == 4).mean() > 0.9
+    a, t = _check(gpu, ref)                                # identical status, rotation <= 1e-4 rad, translation <= 1e-4 on every frame
+    ok = ref["status"] == 4
     well = np.zeros(n, dtype=bool)
     for i in np.nonzero(ok)[0]:
         sub = sorted(subsets[i % 4])                       # the filter keeps landmark order
         uv = P.project(ref["R"][i], ref["t"][i], P.LANDMARKS[sub].astype(np.float32).astype(np.float64))
         well[i] = np.abs(uv[:3] - kp[i, sub[:3], :2]).max() < 1e-2
-    assert well.sum() >= 0.5 * ok.sum(), "too few well-conditioned P3P frames to say anything: %d of %d" % (well.sum(), ok.sum())
-    ang = P.rot_angle(rot[ok], ref["R"][ok])
-    terr = np.linalg.norm(tv[ok] - ref["t"][ok], axis=1) / np.linalg.norm(ref["t"][ok], axis=1)
-    print("P3P: %d frames with a pose, %d well-conditioned; max rot diff %.2e rad / t %.2e there, %.2e / %.2e overall (median %.1e, %.1f %% within 1e-4)" % (
-        ok.sum(), well.sum(), ang[well[ok]].max(), terr[well[ok]].max(), ang.max(), terr.max(), np.median(ang), 100.0 * (ang <= ROT_TOL).mean()))
-    assert ang[well[ok]].max() <= ROT_TOL and terr[well[ok]].max() <= T_TOL
-    assert np.median(ang) <= 1e-8                          # same arithmetic: typically identical to the last bits
-    assert (ang <= ROT_TOL).mean() >= 0.9
-    clean = ok[: n // 2] & well[: n // 2]                  # noise-free + well-conditioned: the generating pose comes back
-    assert P.rot_angle(rot[: n // 2][clean], Rs[: n // 2][clean]).max() < 1e-3
+    print("P3P: %d frames with a pose (%d well-conditioned); kernel vs oracle: max rot diff %.2e rad, t %.2e" % (ok.sum(), well.sum(), a, t))
+    assert well.sum() >= 0.5 * ok.sum()
+    clean = well[: n // 2]                                 # noise-free + well-conditioned: the generating pose comes back
+    assert P.rot_angle(gpu[0][: n // 2][clean], Rs[: n // 2][clean]).max() < 1e-3
 
 
 def test_pnp_threshold_loop_with_24_landmarks(gpu_ops):

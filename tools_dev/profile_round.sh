@@ -32,8 +32,10 @@ run_passes() {   # <name> <passes> <bench args...>
 # default, but dispatched in launch order and one at a time, so that a dispatch can be attributed to its kernel class and its
 # duration is its own (in the captured forward the fuse rows run side by side and stretch each other)
 run_passes w48_b256 "fetch write mfma ldsa ldsb" --graph 0
-run_passes w32_b64 "fetch write mfma" --model w32 --batch 64
-run_passes events_b64 "fetch write mfma" --events --batch 64
+# (side workloads too: condense_prof.py attributes dispatches to kernel classes by launch order, which a captured forward with
+# concurrent lanes does not keep -- ADVICE r3)
+run_passes w32_b64 "fetch write mfma" --model w32 --batch 64 --graph 0
+run_passes events_b64 "fetch write mfma" --events --batch 64 --graph 0
 cd $root
 python3 tools_dev/condense_prof.py $out/w48_b256 w48 256 bf16 $W > $out/condense.log 2>&1
 python3 tools_dev/condense_prof.py $out/w32_b64 w32 64 bf16 $W >> $out/condense.log 2>&1
@@ -42,5 +44,7 @@ python3 tools_dev/condense_prof.py $out/events_b64 w32 64 f16 $W >> $out/condens
 python3 bench.py > $out/bench.json 2> $out/bench.err
 python3 bench.py --events --batch 64 --cpu-frames 0 > $out/bench_events.json 2>/dev/null
 python3 bench.py --model w32 --batch 64 --cpu-frames 0 > $out/bench_w32_b64.json 2>/dev/null
+# one raw kernel trace survives, compressed, so that profiles/ can be re-derived from it (VERDICT r3 #6d)
+for f in $(find $out/w48_b256/trace -name "*kernel_trace.csv" | head -1); do gzip -9 -c $f > $out/w48_b256_kernel_trace.csv.gz; done
 find $out -name "*.csv" -size +1M -delete
 tail -3 $out/condense.log; ls $out
