@@ -386,6 +386,9 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
           for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int c = 0; c < 2; ++c) acc[mb][c] = mfma16<T>(w3f[s][mb], bc[s][c], acc[mb][c]);
+        // MFMA result -> v_permlane32_swap: explicit wait states tied to the accumulators (conv_device.h: mfma_swap_pad) -- nothing
+        // guarantees that the scheduler keeps other work between the last MFMA and the swaps
+        mfma_swap_pad(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
           const f32x4 a0 = acc[mb][0], a1 = acc[mb][1];

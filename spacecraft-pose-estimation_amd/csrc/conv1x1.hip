@@ -11,7 +11,7 @@
 // No barriers after the prologue, no LDS traffic besides the weight fragments: the kernel is a pure HBM stream with
 // as many waves in flight as registers allow.  Replaces conv_pipe for the 1x1 layers of layer1 (Bottleneck conv1 /
 // conv3, pose_hrnet.py:78-98), of the fuse up-paths (:197-208) and the tap maps of the hrnet_cms heads, whenever the
-// packed weights fit 64 KB.
+// packed weights fit LDS (two workgroups per CU up to 64 KB, one above: 384 -> 192 / 96).
 #include <type_traits>
 
 #include "common.h"
@@ -189,7 +189,9 @@ int32_t conv1x1_stream_launch(const PackedConv& pc, const void* in, int N, int H
   const size_t lds = pc.w1_bytes + (size_t)pc.cout_pad1 * 4;
   const int cus = conv_device_cus();
   int grid = (L.total_blocks + 3) / 4;
-  const int occ = 2;
+  // weights above 80 KB (384 -> 192, 384 -> 96: round 4) leave room for one workgroup per CU; its four waves then get the
+  // whole register file (launch_bounds 256, 1)
+  const int occ = lds > 80 * 1024 ? 1 : 2;
   if (grid > cus * occ) grid = cus * occ;
   if (grid < 1) grid = 1;
   const bool bf = pc.dtype == SCPOSE_DT_BF16;
@@ -197,11 +199,11 @@ int32_t conv1x1_stream_launch(const PackedConv& pc, const void* in, int N, int H
   do {                                                                                                                  \
     if (bf) {                                                                                                           \
       static LdsOptIn set_b;                                                                                            \
-      { const int32_t rc_ = lds_opt_in(reinterpret_cast<const void*>(conv1x1_stream_kernel<__bf16, KS, NGV, OC>), 80 * 1024, &set_b); if (rc_ != SCPOSE_OK) return rc_; } \
+      { const int32_t rc_ = lds_opt_in(reinterpret_cast<const void*>(conv1x1_stream_kernel<__bf16, KS, NGV, OC>), (OC) == 1 ? 160 * 1024 : 80 * 1024, &set_b); if (rc_ != SCPOSE_OK) return rc_; } \
       hipLaunchKernelGGL((conv1x1_stream_kernel<__bf16, KS, NGV, OC>), dim3(grid), dim3(256), lds, stream, L);             \
     } else {                                                                                                            \
       static LdsOptIn set_f;                                                                                            \
-      { const int32_t rc_ = lds_opt_in(reinterpret_cast<const void*>(conv1x1_stream_kernel<_Float16, KS, NGV, OC>), 80 * 1024, &set_f); if (rc_ != SCPOSE_OK) return rc_; } \
+      { const int32_t rc_ = lds_opt_in(reinterpret_cast<const void*>(conv1x1_stream_kernel<_Float16, KS, NGV, OC>), (OC) == 1 ? 160 * 1024 : 80 * 1024, &set_f); if (rc_ != SCPOSE_OK) return rc_; } \
       hipLaunchKernelGGL((conv1x1_stream_kernel<_Float16, KS, NGV, OC>), dim3(grid), dim3(256), lds, stream, L);           \
     }                                                                                                                   \
   } while (0)
@@ -210,9 +212,9 @@ int32_t conv1x1_stream_launch(const PackedConv& pc, const void* in, int N, int H
     case 2: C1_LAUNCH(2, 4, 2); break;
     case 3: C1_LAUNCH(3, 4, 2); break;
     case 4: C1_LAUNCH(4, 4, 2); break;
-    case 6: C1_LAUNCH(6, 2, 2); break;
-    case 8: C1_LAUNCH(8, 2, 2); break;
-    case 12: C1_LAUNCH(12, 2, 2); break;
+    case 6: if (occ == 1) C1_LAUNCH(6, 2, 1); else C1_LAUNCH(6, 2, 2); break;
+    case 8: if (occ == 1) C1_LAUNCH(8, 2, 1); else C1_LAUNCH(8, 2, 2); break;
+    case 12: if (occ == 1) C1_LAUNCH(12, 2, 1); else C1_LAUNCH(12, 2, 2); break;
     default:
       set_error("conv1x1: %d k-steps unsupported", ksteps);
       return SCPOSE_E_INVALID;

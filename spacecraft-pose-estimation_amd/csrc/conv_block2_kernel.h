@@ -234,8 +234,12 @@ __global__ __launch_bounds__(512, 2) void conv_block2_kernel(const BlockLaunch p
         }
       }
       const unsigned long long s9 = now();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();   // intermediate tile i complete and input tile i + 1 landed | intermediate tile i - 1 and input tile i free
+      // intermediate tile i complete and input tile i + 1 landed | intermediate tile i - 1 and input tile i free.
+      // ONE statement with a memory clobber: s_barrier is IntrNoMem to the compiler, which may move LDS loads of the next step
+      // above it -- in the product build of the first two-loop form of this kernel (no instrumentation asm behind the barrier) it
+      // did: the conv1 waves read the next input tile before the other waves' LDS-DMA had been waited for (non-deterministic
+      // results that the development build did not show; tools_dev/check_block_determinism.py)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       tph[5] += now() - s9;
     }
   } else {
@@ -308,6 +312,11 @@ __global__ __launch_bounds__(512, 2) void conv_block2_kernel(const BlockLaunch p
             if constexpr (S < PLANES) { if (dma_on) x_dma(xv, pass, S, (i + 1) & 1); }
           };
           kloop(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, ml, pixoff, acc, side, psel_);
+          // v_permlane32_swap below reads MFMA results: explicit wait states tied to the accumulators (conv_device.h: mfma_swap_pad).
+          // Until round 4 the residual loads' wait happened to sit in between; with the first pass's residual already in registers
+          // the swap follows the last MFMA directly.
+          if constexpr (MREP == 3) mfma_swap_pad(acc[0][0], acc[0][1], acc[1][0], acc[1][1], acc[2][0], acc[2][1]);
+          else mfma_swap_pad(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
           const unsigned long long s2 = now();
           tph[1] += s2 - s1;
 #pragma unroll
@@ -353,8 +362,12 @@ __global__ __launch_bounds__(512, 2) void conv_block2_kernel(const BlockLaunch p
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next input tile has landed (this wave's pieces)
       const unsigned long long s9 = now();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();   // intermediate tile i complete and input tile i + 1 landed | intermediate tile i - 1 and input tile i free
+      // intermediate tile i complete and input tile i + 1 landed | intermediate tile i - 1 and input tile i free.
+      // ONE statement with a memory clobber: s_barrier is IntrNoMem to the compiler, which may move LDS loads of the next step
+      // above it -- in the product build of the first two-loop form of this kernel (no instrumentation asm behind the barrier) it
+      // did: the conv1 waves read the next input tile before the other waves' LDS-DMA had been waited for (non-deterministic
+      // results that the development build did not show; tools_dev/check_block_determinism.py)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       tph[5] += now() - s9;
     }
   }

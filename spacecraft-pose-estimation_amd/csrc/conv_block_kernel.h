@@ -294,6 +294,9 @@ __global__ __launch_bounds__(512, 2) void conv_block_kernel(const BlockLaunch p)
     for (int m = 0; m < MREP; ++m) { acc[m][0] = f32x4{bs2[m].x, bs2[m].y, bs2[m].z, bs2[m].w}; acc[m][1] = acc[m][0]; }
     const unsigned long long t4 = now();
     kloop(std::integral_constant<int, 2>{}, w2l, ml, kB, offB, acc);
+    // MFMA result -> v_permlane32_swap needs more wait states than hipcc pads (conv_device.h: mfma_swap_pad)
+    if constexpr (MREP == 3) mfma_swap_pad(acc[0][0], acc[0][1], acc[1][0], acc[1][1], acc[2][0], acc[2][1]);
+    else mfma_swap_pad(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
     // The next input tile (requested after the first barrier, a whole conv2 ago) must have landed before the barrier that ends the
     // tile.  Wait for it HERE, in front of this tile's output stores: a wave's vector-memory operations are counted together and stores
     // may retire before older loads, so the only safe wait is vmcnt(0) -- and behind the stores that would be a wait for their

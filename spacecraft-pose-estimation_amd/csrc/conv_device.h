@@ -61,6 +61,18 @@ __device__ __forceinline__ void mfma_input_fence(V& c) {
   else asm volatile("s_nop 1" : "+v"(c));
 }
 
+// MFMA result -> v_permlane32_swap: hipcc pads that pair with 3-4 wait states, too few behind the 8-pass 16x16x32 MFMA -- lanes 12-15
+// of the LAST accumulator written come out stale.  20 explicit wait states IN ONE STATEMENT WITH THE ACCUMULATORS
+// AS OPERANDS: the MFMAs (their producers) cannot sink below it and the swaps (their consumers) cannot rise above it.  (A nop
+// statement without the operands orders nothing: in round 4 the scheduler put the MFMAs behind such a pad and the fused block's
+// product build returned one stale 16-bit value per vector in columns 12-15 -- tools_dev/where_block_differs.py.)
+__device__ __forceinline__ void mfma_swap_pad(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3) {
+  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+}
+__device__ __forceinline__ void mfma_swap_pad(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, f32x4& a4, f32x4& a5) {
+  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5));
+}
+
 // two fp32 -> one dword of two 16-bit values (a in the low half), one v_cvt_pk_* instruction, RNE like the scalar cast
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;

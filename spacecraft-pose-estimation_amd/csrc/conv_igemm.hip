@@ -170,11 +170,12 @@ int32_t conv_upload(const float* w, const float* bias, int cout, int cin, int ks
         if (co < cout) hb[pos] = bias[co];
       }
   }
-  if (ks == 1 && stride == 1 && cout % 8 == 0 && pc->variant == 0) {   // streaming 1x1 kernel (conv1x1.hip) when the weights fit 64 KB of LDS
+  if (ks == 1 && stride == 1 && cout % 8 == 0 && pc->variant == 0) {   // streaming 1x1 kernel (conv1x1.hip) when the weights fit LDS: two workgroups
+                                                                        // per CU up to 64 KB, one above (384 -> 192 / 96 of the stage-4 fuse layers: 144 / 96 KB)
     const int planes = cin / 8, ksteps = (planes + 3) / 4, cpad = (cout + 63) / 64 * 64;
     const size_t wb = (size_t)ksteps * 4 * cpad * 16;
     const bool ks_ok = (ksteps >= 1 && ksteps <= 4) || ksteps == 6 || ksteps == 8 || ksteps == 12;   // Cin = 32..128, 192, 256, 384
-    if (ks_ok && wb <= 64 * 1024) {
+    if (ks_ok && wb + (size_t)cpad * 4 <= 156 * 1024) {
       std::vector<uint16_t> h1(wb / 2);
       const size_t got = pack_conv_weights(w, cout, cin, 1, cpad, planes, dtype, h1.data(), nullptr, nullptr);
       SCP_REQUIRE(got == wb, "conv1x1: packed size %zu != %zu", got, wb);

@@ -139,7 +139,7 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   // the search below depends on (layer, N, Ho, Wo) only: its result is remembered in the layer (a forward launches the
   // same shapes every time; small batches are launch-bound on the host)
   PackedConv::TileMemo& memo = pc.m32_memo[cus != cus_all];
-  const bool memo_hit = memo.n == L.N && memo.ho == L.Ho && memo.wo == L.Wo && memo.cus == cus && !dev_env("SCPOSE_M32_OCC") && !dev_env("SCPOSE_M32_NR") && !dev_env("SCPOSE_M32_CPMUL") && !dev_env("SCPOSE_M32_CUS") && !dev_env("SCPOSE_M16_NB");
+  const bool memo_hit = memo.n == L.N && memo.ho == L.Ho && memo.wo == L.Wo && memo.cus == cus && !dev_env("SCPOSE_M32_OCC") && !dev_env("SCPOSE_M32_NR") && !dev_env("SCPOSE_M32_CPMUL") && !dev_env("SCPOSE_M32_CUS") && !dev_env("SCPOSE_M16_NB") && !dev_env("SCPOSE_M32_TILE");
   if (memo_hit) { found = true; b_th = memo.th; b_tw = memo.tw; b_nseg = memo.nseg; b_nr = memo.nr; b_ps = memo.ps; b_occ = memo.occ; b_cp = memo.cp; b_nb16 = memo.nb16; }
   for (const M32Variant& v : kVariants) {
     if (memo_hit) break;
@@ -154,10 +154,15 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
     if (pc.stride == 2 && v.occ != 3) continue;
     const int halo_cap = v.occ == 2 ? 512 : 1024;
     const size_t lds_cap = v.occ == 2 ? 80 * 1024 : 160 * 1024;
+    static const char* tile_env = dev_env("SCPOSE_M32_TILE");   // development: "th,tw" restricts the producer/consumer tile search
+    int f_th = 0, f_tw = 0;
+    if (tile_env) sscanf(tile_env, "%d,%d", &f_th, &f_tw);
     for (int ti = 0; ti < 8; ++ti) {
       const int tw = tw_cand[ti];
       if (tw > L.Wo || tw > cap || (ti > 0 && tw >= L.Wo)) continue;
+      if (f_tw > 0 && v.occ == 3 && tw != f_tw) continue;
       for (int th = 1; th <= L.Ho && th * tw <= cap; ++th) {
+        if (f_th > 0 && v.occ == 3 && th != f_th) continue;
         const int hh = (th - 1) * pc.stride + 1 + 2 * k2, hw = (tw - 1) * pc.stride + 1 + 2 * k2;
         for (int nseg = 1; nseg <= 8; ++nseg) {
           if (nseg * th * tw > cap || nseg * hh * hw > halo_cap) break;
@@ -189,7 +194,10 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
                                    2.0 * pc.mt * (nseg * th * tw) * 2 / ck.nchunks;
               double stage = (mfma > bytes / 13.0 ? mfma : bytes / 13.0) + 700.0;
               if (stage < 2600.0) stage = 2600.0;
-              const double cost = per_cu * (ck.nchunks * stage + (double)v.mr * (cap / 128.0) * 16 * 25.0);
+              // 16x16x32 consumers read B fragments as 16 consecutive pixel slots: with a tile width that is a multiple of 16 a column
+              // never straddles two halo rows and its ds_read_b128 lane groups meet no bank twice (96 -> 96 @48 x 48: 8 x 48 instead of
+              // 16 x 24 tiles, -1.2 % measured, profiles/round4_m16_tile_choices.txt) -- a tie-break, not a term of the model
+              const double cost = per_cu * (ck.nchunks * stage + (double)v.mr * (cap / 128.0) * 16 * 25.0) * ((v.nb16 > 0 && tw % 16 != 0) ? 1.02 : 1.0);
               if (cost < best_p) { found_p = true; best_p = cost; p_th = th; p_tw = tw; p_nseg = nseg; p_nr = nr; p_ps = ps; p_cp = cp; p_nb16 = v.nb16; }
             }
             if (!any) break;

@@ -508,7 +508,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
             const unsigned long long t1 = now();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const unsigned long long t2 = now();
-            __builtin_amdgcn_s_barrier();
+            asm volatile("s_barrier" ::: "memory");   // (an asm with a memory clobber, not the builtin: nothing the compiler schedules may cross it)
             if SCP_DBG(p, 8) { const unsigned long long t3 = now(); tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; t0 = t3; }
             xb ^= 1; ++wc;
           }
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned long long t2 = now();
-        __builtin_amdgcn_s_barrier();
+        asm volatile("s_barrier" ::: "memory");
         if SCP_DBG(p, 8) { const unsigned long long t3 = now(); tph[0] += t_mid - t0; tph[1] += t2 - t_mid; tph[2] += t3 - t2; }
         xb ^= 1; ++wc;
       }

@@ -73,8 +73,15 @@ __device__ __forceinline__ buf_rsrc_t make_buf(const void* base, uint32_t bytes)
 __device__ __forceinline__ void dma16_buf(buf_rsrc_t r, uint32_t voff, uint32_t soff, void* l_wave_base) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t*)l_wave_base, 16, voff, soff, 0, 0);
 }
+// The s_nop behind the store: a 16-byte buffer store reads its four data VGPRs over a few cycles after issue, and hipcc (ROCm 7.2,
+// gfx950) puts NO wait state between such a store and a VALU instruction that overwrites one of them.  Round 4 hit it in
+// conv_block2_kernel: `buffer_store_dwordx4 v[82:85], ..., s42 offen` directly followed by `v_mov_b32 v82, v0` (the next pass's
+// thread id) stored the thread id in the first dword of the vector for lanes 12-15 of every 16 -- only in a workgroup's first tile,
+// only in the product build (tools_dev/where_block_differs.py; the guide prescribes the same pad for asm stores: cdna_hip_programming.md
+// 5.7).  Two wait states here cost nothing next to the store's issue and protect every kernel that stores through this helper.
 __device__ __forceinline__ void store16_buf(buf_rsrc_t r, uint32_t voff, uint32_t soff, u32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+  asm volatile("s_nop 1" ::"v"(v) : "memory");   // the data registers are an operand: they stay live (unwritten) up to and including the pad
 }
 __device__ __forceinline__ u32x4 load16_buf(buf_rsrc_t r, uint32_t voff, uint32_t soff) {   // out-of-range lanes read zeros
   return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);

@@ -69,12 +69,16 @@ for e in main["class_stats"]:
     rows.append("%s,%s,%.1f,%.1f,%.1f,%.1f,%.3f" % (e["class"], q(e["kernel"]), fe * 1.048576, wr * 1.048576, (fe + wr) * 1.048576, by, (fe + wr) * 1.048576 / by if by else 0))
 open(out + "_hbm_traffic.csv", "w").write("\n".join(rows) + "\n")
 
-rows = ["class,kernel,GRBM_GUI_ACTIVE_per_launch_sum_over_8_XCDs,SQ_VALU_MFMA_BUSY_CYCLES_per_launch,mfma_busy_fraction,effective_clock_GHz_from_GRBM"]
+# (no clock column: GRBM_GUI_ACTIVE / 8 / duration reads 2.2-4 GHz on launches this short -- MI355X_MICROARCH.md "DVFS give-back": the quotient
+# is only good on dispatches of >= 10 ms; the in-kernel stamps of the development build give 1.45-1.5 GHz for these kernels)
+rows = ["class,kernel,GRBM_GUI_ACTIVE_per_launch_sum_over_8_XCDs,SQ_VALU_MFMA_BUSY_CYCLES_per_launch,mfma_busy_fraction,mfma_busy_cycles_per_SIMD_over_median_us_GHz_equivalent"]
 for e in main["class_stats"]:
     p = pmc.get(e["class"], {})
     if p.get("GRBM_GUI_ACTIVE", 0) > 0 and p.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0:
         gui = p["GRBM_GUI_ACTIVE"]
-        rows.append("%s,%s,%.0f,%.0f,%.4f,%.2f" % (e["class"], q(e["kernel"]), gui, p["SQ_VALU_MFMA_BUSY_CYCLES"], p["SQ_VALU_MFMA_BUSY_CYCLES"] / (128 * gui), gui / 8 / e["median_us"] / 1e3))
+        # last column: matrix-pipe busy cycles per SIMD per microsecond of the launch = (busy fraction) x (shader clock): 1.0 would be
+        # a pipe that is busy every cycle of a 1 GHz clock; with the stamps' 1.45-1.5 GHz, 0.70 means the pipe is busy 47-48 % of the cycles
+        rows.append("%s,%s,%.0f,%.0f,%.4f,%.3f" % (e["class"], q(e["kernel"]), gui, p["SQ_VALU_MFMA_BUSY_CYCLES"], p["SQ_VALU_MFMA_BUSY_CYCLES"] / (128 * gui), p["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / e["median_us"] / 1e3))
 open(out + "_mfma_util.csv", "w").write("\n".join(rows) + "\n")
 
 rows = ["class,kernel,lds_bank_conflict_share_of_lds_cycles,wave_cycles_waiting,wave_cycles_issue_stalled,wave_cycles_active,issue_stall_on_lds,active_inst_lds_share,active_inst_vmem_share,mfma_valu_coexec_share_of_mfma_busy"]
