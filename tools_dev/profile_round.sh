@@ -37,6 +37,9 @@ run_passes w48_b256 "fetch write mfma ldsa ldsb" --graph 0
 run_passes w32_b64 "fetch write mfma" --model w32 --batch 64 --graph 0
 run_passes events_b64 "fetch write mfma" --events --batch 64 --graph 0
 cd $root
+# one raw kernel trace survives, compressed, so that profiles/ can be re-derived from it (VERDICT r3 #6d) -- before condense_prof.py,
+# which deletes the raw CSVs it has condensed
+for f in $(find $out/w48_b256/trace -name "*kernel_trace.csv" | head -1); do gzip -9 -c $f > $out/w48_b256_kernel_trace.csv.gz; done
 python3 tools_dev/condense_prof.py $out/w48_b256 w48 256 bf16 $W > $out/condense.log 2>&1
 python3 tools_dev/condense_prof.py $out/w32_b64 w32 64 bf16 $W >> $out/condense.log 2>&1
 python3 tools_dev/condense_prof.py $out/events_b64 w32 64 f16 $W >> $out/condense.log 2>&1
@@ -44,7 +47,5 @@ python3 tools_dev/condense_prof.py $out/events_b64 w32 64 f16 $W >> $out/condens
 python3 bench.py > $out/bench.json 2> $out/bench.err
 python3 bench.py --events --batch 64 --cpu-frames 0 > $out/bench_events.json 2>/dev/null
 python3 bench.py --model w32 --batch 64 --cpu-frames 0 > $out/bench_w32_b64.json 2>/dev/null
-# one raw kernel trace survives, compressed, so that profiles/ can be re-derived from it (VERDICT r3 #6d)
-for f in $(find $out/w48_b256/trace -name "*kernel_trace.csv" | head -1); do gzip -9 -c $f > $out/w48_b256_kernel_trace.csv.gz; done
 find $out -name "*.csv" -size +1M -delete
 tail -3 $out/condense.log; ls $out
