@@ -330,7 +330,8 @@ def main():
                     3: "conv_block2_kernel: fused BasicBlock 2 x (3x3 s1 %d->%d), one layer per wave, input read once + output written once" % (cin, cout),
                     4: "head_gather_kernel (k%d s%d, C=%d)" % (a // 10, a % 10, cin),
                     5: "stem_fused_kernel: conv1 + conv2 of the stem (3->64->64, both 3x3 s2), image read once + output written once",
-                    6: "bottleneck_kernel: fused Bottleneck 1x1 %d->64, 3x3 64->64, 1x1 64->%d + residual, input read once + output written once" % (cin, cout)}.get(
+                    6: "bottleneck_kernel: fused Bottleneck 1x1 %d->64, 3x3 64->64, 1x1 64->%d + residual, input read once + output written once" % (cin, cout),
+                    8: "fuse_down_kernel: fuse row 0 + the first 3x3 s2 hop of every down path from branch 0 (%d->%d), branch 0 read once" % (cin, cout)}.get(
                 kind, "conv %dx%d s%d %d->%d (MFMA implicit-GEMM)" % (a // 10, a // 10, a % 10, cin, cout))
             ai = flops / byts if byts else float("inf")
             sec = ms / 1e3
@@ -373,7 +374,7 @@ def main():
         roof["dispatch_gap_us_per_launch"] = round(gap_us, 2)
         roof["src_sha"] = sha
         # the next kernel classes by share of the forward, each against its own roofline (same definitions);
-        # class = kind:10*ksize+stride|nterms:Cin:Cout (kind 0 stem, 1 conv, 2 fuse sum, 3 fused BasicBlock, 4 head gather, 5 fused stem, 6 fused Bottleneck, 7 fused tail; '@pixels' where a layer shape runs at two map sizes)
+        # class = kind:10*ksize+stride|nterms:Cin:Cout (kind 0 stem, 1 conv, 2 fuse sum, 3 fused BasicBlock, 4 head gather, 5 fused stem, 6 fused Bottleneck, 7 fused tail, 8 fuse row 0 + down hops of branch 0; '@pixels' where a layer shape runs at two map sizes)
         roof["next_classes"] = [{k: v for k, v in describe(k2, *v2).items()
                                  if k in ("class", "share_of_forward", "avg_launch_us", "avg_launch_us_gap_corrected", "bound", "achieved", "unit", "frac", "frac_gap_corrected", "frac_of_sustained", "traffic")}
                                 for k2, v2 in ranked[1:6]]

@@ -216,6 +216,18 @@ int32_t bottleneck_launch(const void* in, const void* w1, const void* w2, const 
                           int cin, int dtype, void* out, uint32_t* sched /*11 zero-initialised device words: per-XCD tile queues [0..7], finished workgroups [8], device-wide queue of the first Bottleneck [9..10]*/,
                           hipStream_t stream);
 
+// fuse row 0 + the first hop of every down path from branch 0 of a HighResolutionModule, one pass over branch 0 (fuse_down.hip)
+struct FuseDownPacked {
+  void* d_w = nullptr;     // conv_s2r_pack of the concatenated first-hop convolutions [2 c0 | c0 | c0][c0][3][3]
+  float* d_b = nullptr;
+  int c0 = 0, nb = 0, dtype = 0;
+};
+bool fuse_down_supported(int nb, int c0, int c1);
+int32_t fuse_down_upload(const float* w, const float* bias, int nb, int c0, int dtype, FuseDownPacked* fd);
+void fuse_down_free(FuseDownPacked* fd);
+int32_t fuse_down_launch(const FuseDownPacked& fd, const void* x0, int N, int H, int W, const void* const* terms, void* y,
+                         void* const* outs, hipStream_t stream);
+
 // ---- elementwise ---------------------------------------------------------------------------
 int32_t fuse_sum_launch(const void* const* terms, const int32_t* shifts, int nterms, int N, int C,
                         int H, int W, int dtype, void* out, hipStream_t stream);

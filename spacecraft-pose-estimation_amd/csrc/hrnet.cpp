@@ -71,7 +71,7 @@ static bool fold(Weights& W, const std::string& conv, const std::string& bn, int
   return true;
 }
 
-enum OpKind { OP_STEM = 0, OP_CONV = 1, OP_FUSE = 2, OP_BLOCK = 3, OP_HEAD = 4, OP_STEM2 = 5, OP_BNECK = 6 };   // OP_STEM2: fused stem (stem_fused.hip); OP_BNECK: fused Bottleneck (bottleneck.hip)   // OP_BLOCK: fused BasicBlock (conv_block_kernel.h); OP_HEAD: head.hip
+enum OpKind { OP_STEM = 0, OP_CONV = 1, OP_FUSE = 2, OP_BLOCK = 3, OP_HEAD = 4, OP_STEM2 = 5, OP_BNECK = 6, OP_FDOWN = 8 };   // OP_FDOWN: fuse row 0 + first down hops of branch 0 (fuse_down.hip; 7 is the fused tail's profile signature)   // OP_STEM2: fused stem (stem_fused.hip); OP_BNECK: fused Bottleneck (bottleneck.hip)   // OP_BLOCK: fused BasicBlock (conv_block_kernel.h); OP_HEAD: head.hip
 
 struct TensorDesc {
   int C, ds;       // channels, log2 spatial downscale w.r.t. the network input
@@ -87,6 +87,8 @@ struct Op {
   int relu, out_f32;
   int nterms, term[4], shift[4];
   int head;          // OP_HEAD: index into head_bias; in = tap map, res = coarser level (f32) or -1
+  int nouts, outs[3];  // OP_FDOWN: the down paths' first-hop outputs (row 1's result, rows 2 / 3's intermediates); out = fuse row 0's sum,
+                     // term[] / shift[] = its low-resolution terms, conv = index into fdowns
   // Concurrency classes for the captured (hipGraph) forward: ops of one epoch on different lanes are independent
   // (the branches of a HighResolutionModule, pose_hrnet.py:247-253; the fuse rows :254-265; the transition convs
   // :333-372); epochs are separated by a join of all lanes.  The serial forward ignores both.
@@ -117,6 +119,7 @@ struct scpose_hrnet {
   float* d_stemf_b2 = nullptr;
   struct Bneck { void* w1 = nullptr; void* w2 = nullptr; void* w3 = nullptr; float* bias = nullptr; int cin = 256; };   // fused Bottlenecks (bottleneck.hip)
   std::vector<Bneck> bnecks;
+  std::vector<scpose::FuseDownPacked> fdowns;   // fuse row 0 + first down hops of branch 0 (fuse_down.hip), one per module that qualifies
   float* d_head_bias = nullptr; // [4][16] folded biases of the hrnet_cms heads
   uint32_t* d_sched = nullptr;  // 16 zero-initialised words per op: dynamic tile queues of the persistent kernels (conv_device.h: tile_claim)
   int head_k = 0, head_s = 1;   // transposed-conv kernel / stride of the heads (heat-map = S * branch-0 size)
@@ -308,6 +311,42 @@ struct Builder {
     push(op);
     return op.out;
   }
+  // Fuse row 0 and the first hop of every down path from branch 0 as one launch (fuse_down.hip; pose_hrnet.py:211-239, :256-263).
+  // fp: "stageS.M.fuse_layers"; low[j - 1]: the 1x1 up-path outputs of branches j = 1..nb-1 for row 0.  Returns fuse row 0's
+  // output and fills first[i - 1] with row i's first-hop tensor (row 1: its finished term; rows 2, 3: the chain's intermediate).
+  int fuse_down(int x0, const std::string& fp, const std::vector<int>& low, const std::vector<int>& cur, std::vector<int>* first) {
+    if (status != SCPOSE_OK) return -1;
+    const int nb = (int)cur.size(), c0 = cur[0];
+    std::vector<float> w((size_t)nb * c0 * c0 * 9), b((size_t)nb * c0);
+    size_t wo = 0, bo = 0;
+    for (int i = 1; i < nb; ++i) {
+      const int cout = i == 1 ? cur[1] : c0;   // row 1's single hop ends at its width; longer chains keep branch 0's until their last hop
+      std::vector<float> wi, bi;
+      const std::string cn = fmt2(fp, i);
+      if (!fold(*W, cn + ".0", cn + ".1", cout, c0, 3, false, &wi, &bi)) { status = SCPOSE_E_MISSING; return -1; }
+      std::copy(wi.begin(), wi.end(), w.begin() + wo); wo += wi.size();
+      std::copy(bi.begin(), bi.end(), b.begin() + bo); bo += bi.size();
+    }
+    FuseDownPacked fd;
+    const int32_t st = fuse_down_upload(w.data(), b.data(), nb, c0, net->desc.dtype, &fd);
+    net->fdowns.push_back(fd);   // (pushed before the status check: hrnet_free releases whatever was allocated)
+    if (st != SCPOSE_OK) { status = st; return -1; }
+    const int ds = net->tensors[x0].ds;
+    Op op{};
+    op.kind = OP_FDOWN; op.in = x0; op.res = -1; op.conv = (int)net->fdowns.size() - 1; op.relu = 1;
+    op.nterms = nb - 1;
+    for (int k = 0; k < nb - 1; ++k) { op.term[k] = low[k]; op.shift[k] = k + 1; }
+    op.nouts = nb - 1;
+    for (int i = 1; i < nb; ++i) { op.outs[i - 1] = new_tensor(i == 1 ? cur[1] : c0, ds + 1); first->push_back(op.outs[i - 1]); }
+    op.out = new_tensor(c0, ds);
+    push(op);
+    return op.out;
+  }
+  static std::string fmt2(const std::string& fp, int i) {   // "<fp>.<i>.0.0": row i, source branch 0, hop 0
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s.%d.0.0", fp.c_str(), i);
+    return buf;
+  }
   int fuse(const std::vector<int>& terms, const std::vector<int>& shifts, int C, int ds) {
     if (status != SCPOSE_OK) return -1;
     Op op{};
@@ -446,6 +485,54 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
       }
       B.parallel_end();
       std::vector<int> outs;
+      static const char* fd_env = dev_env("SCPOSE_FUSE_DOWN");
+      if (multi && !bneck_stage && fuse_down_supported(nb, cur[0], cur[1]) && !(fd_env && atoi(fd_env) == 0)) {
+        // Branch 0 is read ONCE (fuse_down.hip): its fuse row and the first hop of every down path that starts from it are one
+        // launch.  Two epochs instead of one: (A) lane 0: row 0's 1x1 up paths, then that launch; lanes 1..: everything of rows 1..
+        // that does not depend on it -- their up paths and the down chains from branches 1..; (B) the remaining hops of the
+        // chains from branch 0 and the sums of rows 1.., row i's on lane i.
+        std::vector<std::vector<int>> T(nb, std::vector<int>(nb, -1)), S(nb, std::vector<int>(nb, 0));
+        std::vector<int> first;
+        int y0 = -1;
+        B.parallel_begin(2);
+        for (int i = 0; i < nb; ++i) {
+          B.lane = i;
+          for (int j = 0; j < nb; ++j) {
+            const std::string fp = fmt("%s.fuse_layers.%d.%d", mp.c_str(), i, j);
+            if (j == i) {
+              T[i][j] = xs[j];
+            } else if (j > i) {
+              T[i][j] = B.conv(xs[j], fp + ".0", fp + ".1", cur[i], 1, 1, false);
+              S[i][j] = j - i;
+            } else if (j >= 1) {
+              int t = xs[j];
+              for (int k = 0; k < i - j; ++k) {
+                const bool last = k == i - j - 1;
+                t = B.conv(t, fmt("%s.%d.0", fp.c_str(), k), fmt("%s.%d.1", fp.c_str(), k), last ? cur[i] : cur[j], 3, 2, !last);
+              }
+              T[i][j] = t;
+            }
+          }
+          if (i == 0) y0 = B.fuse_down(xs[0], mp + ".fuse_layers", std::vector<int>(T[0].begin() + 1, T[0].end()), cur, &first);
+        }
+        B.parallel_end();
+        if (B.status != SCPOSE_OK) break;
+        outs.push_back(y0);
+        B.parallel_begin(2);
+        for (int i = 1; i < nb; ++i) {
+          B.lane = i;
+          const std::string fp = fmt("%s.fuse_layers.%d.0", mp.c_str(), i);
+          int t = first[i - 1];
+          for (int k = 1; k < i; ++k) {
+            const bool last = k == i - 1;
+            t = B.conv(t, fmt("%s.%d.0", fp.c_str(), k), fmt("%s.%d.1", fp.c_str(), k), last ? cur[i] : cur[0], 3, 2, !last);
+          }
+          T[i][0] = t;
+          if (B.status != SCPOSE_OK) break;
+          outs.push_back(B.fuse(T[i], S[i], cur[i], net->tensors[xs[i]].ds));
+        }
+        B.parallel_end();
+      } else {
       B.parallel_begin(2);   // the fuse rows: row i (its up / down paths, then its sum) on lane i
       for (int i = 0; i < (multi ? nb : 1); ++i) {
         B.lane = i;
@@ -470,6 +557,7 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
         outs.push_back(B.fuse(terms, shifts, cur[i], net->tensors[xs[i]].ds));
       }
       B.parallel_end();
+      }
       xs = outs;
       if (B.status != SCPOSE_OK) break;
       net->taps.emplace_back(mp + ".out0", xs[0]);
@@ -589,6 +677,7 @@ size_t hrnet_plan(scpose_hrnet* net, int n, int h, int w, int mode = 0) {
       cur_epoch = op.epoch;
     }
     if (op.out >= 0) P.off[op.out] = alloc(tensor_bytes(net->tensors[op.out], n, h, w));
+    for (int k = 0; k < op.nouts; ++k) P.off[op.outs[k]] = alloc(tensor_bytes(net->tensors[op.outs[k]], n, h, w));
     auto done = [&](int t) {
       if (t >= 0 && net->tensors[t].last_use == (int)i && !released[t]) {
         released[t] = 1;   // guard against double release (same tensor twice in one op)
@@ -718,6 +807,13 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
       const TensorDesc& ti = net->tensors[op.in];
       const scpose_hrnet::Bneck& bn = net->bnecks[op.conv];
       rc = bottleneck_launch(ptr(op.in), bn.w1, bn.w2, bn.w3, bn.bias, n, h >> ti.ds, w >> ti.ds, bn.cin, net->desc.dtype, ptr(op.out), net->d_sched + 16 * oi, st);
+    } else if (op.kind == OP_FDOWN) {
+      const TensorDesc& ti = net->tensors[op.in];
+      const void* terms[3] = {nullptr, nullptr, nullptr};
+      void* outs[3] = {nullptr, nullptr, nullptr};
+      for (int k = 0; k < op.nterms; ++k) terms[k] = ptr(op.term[k]);
+      for (int k = 0; k < op.nouts; ++k) outs[k] = ptr(op.outs[k]);
+      rc = fuse_down_launch(net->fdowns[op.conv], ptr(op.in), n, h >> ti.ds, w >> ti.ds, terms, ptr(op.out), outs, st);
     } else if (op.kind == OP_BLOCK) {
       const TensorDesc& ti = net->tensors[op.in];
       rc = block_launch(net->convs[op.conv], net->convs[op.conv2], ptr(op.in), n, h >> ti.ds, w >> ti.ds, ptr(op.out), st);
@@ -803,6 +899,17 @@ static void op_work(const scpose_hrnet* net, const Op& op, int h, int w, double*
     *f = 2.0 * px * (cin * 64 + 64.0 * 64 * 9 + 64.0 * 256 + (cin == 64 ? 64.0 * 256 : 0.0));
     *by = px * 2 * (unfused ? (cin + 64) + (64 + 64) + (64 + cin + 256) : cin + 256);
     sig[1] = 131; sig[2] = (int)cin; sig[3] = 256;
+  } else if (op.kind == OP_FDOWN) {
+    // fuse row 0 + the first down hops of branch 0: flops of the nb - 1 stride-2 convolutions; bytes: x0 in, y0 out, the
+    // low-resolution terms in, the hops' outputs out (unfused accounting: every convolution and the sum read x0 for themselves)
+    const TensorDesc& ti = net->tensors[op.in];
+    const double hi = h >> ti.ds, wi = w >> ti.ds, c0 = ti.C;
+    double cout = 0, low = 0;
+    for (int k = 0; k < op.nouts; ++k) cout += net->tensors[op.outs[k]].C;
+    for (int k = 0; k < op.nterms; ++k) low += c0 * (hi / (1 << op.shift[k])) * (wi / (1 << op.shift[k])) * 2;
+    *f = 2.0 * c0 * cout * 9 * (hi / 2) * (wi / 2);
+    *by = (unfused ? 2.0 + op.nouts : 2.0) * c0 * hi * wi * 2 + low + cout * (hi / 2) * (wi / 2) * 2;
+    sig[1] = 32; sig[2] = (int)c0; sig[3] = (int)cout;
   } else if (op.kind == OP_HEAD) {
     const TensorDesc& ti = net->tensors[op.in];
     const double hi = h >> ti.ds, wi = w >> ti.ds, S = net->head_s, J = net->desc.num_joints;
@@ -841,6 +948,7 @@ void hrnet_free(scpose_hrnet* net) {
     if (bn.w3) (void)hipFree(bn.w3);
     if (bn.bias) (void)hipFree(bn.bias);
   }
+  for (auto& fd : net->fdowns) fuse_down_free(&fd);
   if (net->d_stemf_w1) (void)hipFree(net->d_stemf_w1);
   if (net->d_stemf_w2) (void)hipFree(net->d_stemf_w2);
   if (net->d_stemf_b1) (void)hipFree(net->d_stemf_b1);
