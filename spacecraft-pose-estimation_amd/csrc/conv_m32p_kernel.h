@@ -345,6 +345,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
         if SCP_DBG(p, 8) {   // producers: [retire-buffer traffic][locate + X issue][W issue][wait][barrier]
           const unsigned long long t5 = now();
           tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; tph[3] += t4 - t3; tph[4] += t5 - t4;
+          if (c < n_st) tph[5] += t4 - t3;   // ... of which in the stages that store the previous tile
         }
         xb ^= 1;
       }
@@ -509,7 +510,10 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const unsigned long long t2 = now();
             asm volatile("s_barrier" ::: "memory");   // (an asm with a memory clobber, not the builtin: nothing the compiler schedules may cross it)
-            if SCP_DBG(p, 8) { const unsigned long long t3 = now(); tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; t0 = t3; }
+            if SCP_DBG(p, 8) {   // slots 3-5: the barrier wait again, by class of the stage that ends -- stores the previous tile / loads residual rows / last
+              const unsigned long long t3 = now(); tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2;
+              tph[3 + (c < n_st ? 0 : c == p.nchunks - 1 ? 2 : 1)] += t3 - t2; t0 = t3;
+            }
             xb ^= 1; ++wc;
           }
           {
@@ -678,7 +682,11 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned long long t2 = now();
         asm volatile("s_barrier" ::: "memory");
-        if SCP_DBG(p, 8) { const unsigned long long t3 = now(); tph[0] += t_mid - t0; tph[1] += t2 - t_mid; tph[2] += t3 - t2; }
+        if SCP_DBG(p, 8) {
+          const unsigned long long t3 = now(); tph[0] += t_mid - t0; tph[1] += t2 - t_mid; tph[2] += t3 - t2;
+          const int ce = c + (npp == 1 ? 1 : 0);
+          tph[3 + (ce < n_st ? 0 : ce == p.nchunks - 1 ? 2 : 1)] += t3 - t2;
+        }
         xb ^= 1; ++wc;
       }
     }
