@@ -50,7 +50,7 @@ constexpr int kCols1 = (kHPix + 15) / 16;      // 21 MFMA columns of conv1
 constexpr int kXS = (kHPix | 1) * 16;          // bytes of one t1 plane (325 slots: odd pitch)
 constexpr int kT2S = (kT * kT | 1) * 16;       // bytes of one t2 plane (257 slots)
 constexpr int kW1Bytes = 8 * 4 * 4 * 16 * 16;  // 32 KB
-constexpr int kW2LSteps = 12;                  // identity Bottleneck: k-steps of conv2's weights resident in LDS (48 KB); the other 6 stay in registers
+constexpr int kW2LSteps = 13;                  // identity Bottleneck: k-steps of conv2's weights resident in LDS (52 KB: what 160 KB leave); the other 5 stay in registers
 constexpr int kLds = 8 * kXS + 8 * kT2S + kW1Bytes + (64 + 64 + 256) * 4 + 16 + kW2LSteps * 4 * 1024;   // + the tile queue words + W2
 // first Bottleneck (PROJ): x has 64 channels, W1 is 8 KB, and the tile's 256 centre pixels of x (8 planes) are kept in LDS,
 // double-buffered, as the operand of the projection half of conv3
@@ -84,8 +84,24 @@ inline int bneck_row_channel(int row) {
 // PROJ = false: identity residual, Cin = 256 (layer1 blocks 1-3).  PROJ = true: the first Bottleneck (pose_hrnet.py:378-384,
 // :78-98 with `downsample`): Cin = 64, and conv3 runs over the concatenated operand [t2 ; x] with weights [W3 | Wds] and bias
 // b3 + bds -- the 1x1 projection of the residual is two more k-steps of conv3 and is summed in the fp32 accumulators.
+template <int S, int E, typename F>
+__device__ __forceinline__ void static_for_b(F&& f) {
+  if constexpr (S < E) { f(std::integral_constant<int, S>{}); static_for_b<S + 1, E>(f); }
+}
+
+// k-steps of the NEXT tile's x vectors that are requested in phase B instead of phase C (identity Bottleneck).  Measured, layer1 of
+// W48 384^2 at batch 256, same box: 0: 3.58 ms, 2: 3.44 ms (-47 us per Bottleneck); 3 and 4 spill (the ring's registers hold the
+// residual vectors during phase B: 64 + 12 per early k-step + conv2's 40 weight registers + its fragments).
+// The kernel sits on the CU's vector-memory instruction rate: per wave and tile 24 x loads + 16 residual loads + 16 stores +
+// 10 weight reloads = 66 one-KiB instructions x 8 waves x ~70 cycles = 37 k cycles, the tile takes 36 k (SCPOSE_BNECK_DBG=1).
+// Moving instructions between phases only fills idle slots: keeping the last 2 (identity) / 4 (first Bottleneck) row pairs'
+// output vectors in registers and storing them in the next tile's phase B measured -0.6 % and was dropped.
+#ifndef SCPOSE_BNECK_EARLY
+#define SCPOSE_BNECK_EARLY 2
+#endif
 template <int DT, bool PROJ>
 __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p) {
+  constexpr int EARLY = PROJ ? 0 : SCPOSE_BNECK_EARLY;   // k-steps of the next tile's x vectors requested in phase B
   constexpr int CINP = PROJ ? 8 : 32;          // input planes
   constexpr int KA = CINP / 4;                 // conv1 k-steps
   constexpr int KC = PROJ ? 4 : 2;             // conv3 k-steps
@@ -289,6 +305,16 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
     const unsigned long long ts2 = now();
 
     // ---- B: conv2 (3x3, 64 -> 64) on the 256 output pixels -> t2: tile rows wq, wq + 4, wq + 8, wq + 12 ----
+    // The next tile's x vectors of the first EARLY k-steps are requested HERE, not in phase C: the vector-memory path of the CU is
+    // idle during phases A and B and carries all of a tile's loads and stores in phase C, which is 55 % of the tile time.  (Their
+    // registers are free: the ring is consumed in phase A.)
+    if constexpr (EARLY > 0) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (t_next >= 0) locate(t_next);
+      else { vo[0] = vo[1] = vo[2] = BUF_OOB; cx[0] = cx[1] = cx[2] = -1; }
+      static_for_b<0, EARLY>([&](auto sc) { request(sc); });
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // two row groups at a time where the weights come from LDS (one A fragment then feeds two MFMAs)
     constexpr int CC = PROJ ? 1 : 2;
 #pragma unroll 1
@@ -361,12 +387,14 @@ __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p)
     // of plane 2 * block + psel
     {
       __builtin_amdgcn_sched_barrier(0);
-      if (t_next >= 0) locate(t_next);
-      else { vo[0] = vo[1] = vo[2] = BUF_OOB; cx[0] = cx[1] = cx[2] = -1; }   // last tile: the requests still run (they read nothing), so that the
-                                                           // ring is redefined on every path and is not live across phase B
+      if constexpr (EARLY == 0) {
+        if (t_next >= 0) locate(t_next);
+        else { vo[0] = vo[1] = vo[2] = BUF_OOB; cx[0] = cx[1] = cx[2] = -1; }   // last tile: the requests still run (they read nothing), so that the
+                                                             // ring is redefined on every path and is not live across phase B
+      }
       auto pair = [&](auto cpc) {
         constexpr int cp = decltype(cpc)::value;
-        request(cpc);                                      // next tile's x vectors of k-step cp: in front of this pair's stores
+        request(std::integral_constant<int, cp + EARLY>{});   // next tile's x vectors of k-step cp + EARLY (none past the last): in front of this pair's stores
         f32x4 acc[2][2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
