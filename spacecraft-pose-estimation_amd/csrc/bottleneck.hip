@@ -99,9 +99,12 @@ __device__ __forceinline__ void static_for_b(F&& f) {
 #ifndef SCPOSE_BNECK_EARLY
 #define SCPOSE_BNECK_EARLY 2
 #endif
+#ifndef SCPOSE_BNECK_EARLY_PROJ   // the first Bottleneck has two k-steps of x in all (64 input channels).  Same box: 0: 426 us, 1: 370 us; 2 spills
+#define SCPOSE_BNECK_EARLY_PROJ 1   // (six registers, whatever part of conv2's weights moves to the 10 KB of LDS that are left)
+#endif
 template <int DT, bool PROJ>
 __global__ __launch_bounds__(512, 2) void bottleneck_kernel(const BneckLaunch p) {
-  constexpr int EARLY = PROJ ? 0 : SCPOSE_BNECK_EARLY;   // k-steps of the next tile's x vectors requested in phase B
+  constexpr int EARLY = PROJ ? SCPOSE_BNECK_EARLY_PROJ : SCPOSE_BNECK_EARLY;   // k-steps of the next tile's x vectors requested in phase B
   constexpr int CINP = PROJ ? 8 : 32;          // input planes
   constexpr int KA = CINP / 4;                 // conv1 k-steps
   constexpr int KC = PROJ ? 4 : 2;             // conv3 k-steps

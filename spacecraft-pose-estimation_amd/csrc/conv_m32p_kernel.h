@@ -195,6 +195,8 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
         }
       }
     };
+    // the first tile's first halo chunk is requested before anything else: it comes from HBM and lands under the weight loads below
+    if (it_begin < it_end) { locate_halo(it_begin); issue_x(0, 0); }
     constexpr int WSLOTS = (KK * 2 * MT * 16 + 4095) / 4096;   // 16-byte slots per thread of a 2-plane chunk
     u32x4 wreg[WREG > 0 ? WREG : 1][WSLOTS];
     if constexpr (WREG > 0) {
@@ -300,7 +302,6 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
     for (int k = 0; k < NQ; ++k) qb_cur[k] = qb_prev[k] = buf ? (size_t)BUF_OOB : ~(size_t)0;
     int wc = 0, xb = 0;
     if (it_begin < it_end) {
-      locate_halo(it_begin);
       if (w_resident) {   // every chunk, in storage order, once per launch
         const int nbytes = p.nchunks * ksteps_full * (2 * MT * 16);
         for (int o = 0; o < nbytes; o += 4096) {
@@ -310,7 +311,6 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
       } else {
         issue_w(it_begin, 0, 0);
       }
-      issue_x(0, 0);
     }
     __syncthreads();   // bias, stage 0 (compiler: vmcnt(0) + lgkmcnt(0) + barrier)
 
