@@ -347,7 +347,8 @@ int32_t fuse_down_launch(const FuseDownPacked& fd, const void* x0, int N, int H,
   const size_t in_frame = (size_t)planes * H * W * 16;
   SCP_REQUIRE(in_frame < 0xfffffff0ull, "fuse_down: one %dx%d frame does not fit a 32-bit buffer descriptor", H, W);
   // tensors are addressed through 32-bit buffer descriptors: batches whose branch-0 tensor reaches 4 GiB run as several launches
-  const int max_n = (int)(0xfffffff0ull / in_frame);
+  int max_n = (int)(0xfffffff0ull / in_frame);
+  { static const char* e = dev_env("SCPOSE_FD_MAXN"); if (e && atoi(e) > 0 && atoi(e) < max_n) max_n = atoi(e); }   // tests: force the split on a small batch
   for (int n0 = 0; n0 < N; n0 += max_n) {
     const int n = N - n0 < max_n ? N - n0 : max_n;
     FdLaunch L{};
