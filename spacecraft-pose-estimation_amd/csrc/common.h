@@ -188,6 +188,9 @@ int32_t block_launch(const PackedConv& c1, const PackedConv& c2, const void* in,
 int conv_device_cus();
 unsigned long long* conv_dbg_buffer(hipStream_t stream);   // development instrumentation
 void conv_dbg_set_grid(int grid);
+// PackedConv::mrep value of the 48-row Cout block of the producer/consumer kernel's 3 x 8 form (conv_m32p_kernel.h, M16 = 3): one and
+// a half 32-row units have no integer; mt = 48
+constexpr int kMrep48 = 15;
 // 32x32x16-MFMA kernel (conv_m32_kernel.h): layer eligibility + variant, packing, launch
 bool conv_m32_choose(int cin, int cout, int ks, int stride, int* mr, int* wm, int* cp);
 size_t pack_conv_weights_m32(const float* w, int cout, int cin, int ks, int mt, int cp, int dtype,

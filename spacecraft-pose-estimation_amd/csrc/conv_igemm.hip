@@ -147,7 +147,7 @@ int32_t conv_upload(const float* w, const float* bias, int cout, int cin, int ks
   std::vector<float> hb;
   if (conv_m32_choose(cin, cout, ks, stride, &pc->mrep, &pc->wm, &pc->cp)) {   // 32x32x16 MFMA kernel
     pc->variant = 1;
-    pc->mt = 32 * pc->mrep * pc->wm;
+    pc->mt = pc->mrep == kMrep48 ? 48 : 32 * pc->mrep * pc->wm;
     pc->n_mblk = (cout + pc->mt - 1) / pc->mt;
     pc->wbytes = pack_conv_weights_m32(w, cout, cin, ks, pc->mt, pc->cp, dtype, nullptr, &pc->nchunks, &pc->ksteps_full);
     host.resize(pc->wbytes / 2);

@@ -22,6 +22,7 @@ static const M32Variant kVariants[] = {
   {3, 1, 3, 1, 0}, {3, 1, 2, 2, 0}, {3, 1, 1, 3, 0}, {3, 1, 2, 3, 0}, {3, 1, 3, 3, 0},
   {2, 1, 2, 1, 0}, {2, 1, 4, 1, 0}, {2, 1, 3, 2, 0}, {2, 1, 1, 3, 0}, {2, 1, 2, 3, 0}, {2, 1, 3, 3, 0},
   {3, 1, 1, 3, 2}, {3, 1, 2, 3, 4}, {3, 1, 3, 3, 5}, {3, 1, 3, 3, 6},
+  {kMrep48, 1, 4, 3, 8},   // 48-row blocks, eight columns per consumer wave (512-pixel tile groups)
 };
 
 // 16x16x32 consumers: stride-1 3x3 layers with 96-row Cout blocks whose input is a whole number of 32-channel pairs of plane
@@ -29,6 +30,7 @@ static const M32Variant kVariants[] = {
 // schedule needs: 96 -> 96, 192 -> 192, 384 -> 384 of HRNet-W48.  SCPOSE_M16=0 (development) keeps them on 32x32x16.
 static bool conv_m16_eligible(const PackedConv& pc) {
   static const char* e = dev_env("SCPOSE_M16");
+  if (pc.mrep == kMrep48) return true;   // (conv_m32_choose checked the layer; this family has no 32x32x16 form)
   return pc.ks == 3 && pc.stride == 1 && pc.mrep == 3 && pc.wm == 1 && pc.cp == 2 && (pc.cin / 16) % 2 == 0 && pc.cin / 16 >= 3 && !(e && atoi(e) == 0);
 }
 
@@ -43,17 +45,22 @@ bool conv_m32_choose(int cin, int cout, int ks, int stride, int* mr, int* wm, in
   int m = 0, w = 1;
   if (cout % 96 == 0) m = 3;          // Cout blocks of 96 (HRNet-W48: 96, 192, 384)
   else if (cout % 64 == 0) m = 2;     // Cout blocks of 64 (HRNet-W32: 64, 128, 256; layer1)
-  else if (cout == 48 && (stride == 2 || cin >= 96)) m = 2;   // one 64-row block with 16 rows of padding: input-bound
-                                                               // stride-2 layers and the deep-K transition conv
+  else if (cout == 48 && (stride == 2 || cin >= 96)) {
+    // stride 2 (input-bound): one 64-row block with 16 rows of padding.  Stride 1 with a deep K (transition1, 256 -> 48: MFMA-bound):
+    // a 48-row block on the 16x16x32 consumers' 3 x 8 form when K is a whole number of 32-channel pairs of plane pairs -- the 64-row
+    // form spent a quarter of its MFMAs on the padding rows (SCPOSE_M48=0, development: the 64-row form)
+    static const char* e48 = dev_env("SCPOSE_M48");
+    m = (stride == 1 && (cin / 16) % 2 == 0 && cin / 16 >= 4 && !(e48 && atoi(e48) == 0)) ? kMrep48 : 2;
+  }
   else return false;
   *mr = m; *wm = w;
   const int planes = cin / 8;
   // whole K in one chunk with resident weights when it fits comfortably, else stream 2-plane chunks
-  const int mt = 32 * m * w;
+  const int mt = m == kMrep48 ? 48 : 32 * m * w;
   const size_t whole = (size_t)(planes / 2) * 9 * 2 * mt * 16;
   // (stride 2 runs on the producer/consumer kernel only, which needs >= 3 K-chunks: always stream 2-plane chunks there --
   // a single resident chunk, e.g. 48 -> 64, would pass create and then find no tiling at the first forward)
-  *cp = (stride == 1 && cout == mt && whole <= 60 * 1024 && planes <= 6) ? planes : 2;
+  *cp = (m != kMrep48 && stride == 1 && cout == mt && whole <= 60 * 1024 && planes <= 6) ? planes : 2;
   return true;
 }
 
@@ -188,7 +195,8 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
               if (ck.nchunks < 3 || m32p_lds_bytes(pc, ck, ps, cap) > lds_cap) continue;
               any = true;
               const double per_cu = (double)((items + cus - 1) / cus);
-              const double mfma = (double)v.mr * (cap / 128.0) * (cp / 2) * pc.ks * pc.ks * 32.0 * 1.35;
+              const double mr_eff = v.mr == kMrep48 ? 1.5 : (double)v.mr;   // 32-row units of the Cout block
+              const double mfma = mr_eff * (cap / 128.0) * (cp / 2) * pc.ks * pc.ks * 32.0 * 1.35;
               const bool res_w = m32p_wbufs(pc, ck, ps, cap) > 2;
               const double bytes = (res_w ? 0.0 : (double)ck.ksteps_full * 2 * pc.mt * 16) + (double)cp * ps +
                                    2.0 * pc.mt * (nseg * th * tw) * 2 / ck.nchunks;
@@ -197,7 +205,7 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
               // 16x16x32 consumers read B fragments as 16 consecutive pixel slots: with a tile width that is a multiple of 16 a column
               // never straddles two halo rows and its ds_read_b128 lane groups meet no bank twice (96 -> 96 @48 x 48: 8 x 48 instead of
               // 16 x 24 tiles, -1.2 % measured, profiles/round4_m16_tile_choices.txt) -- a tie-break, not a term of the model
-              const double cost = per_cu * (ck.nchunks * stage + (double)v.mr * (cap / 128.0) * 16 * 25.0) * ((v.nb16 > 0 && tw % 16 != 0) ? 1.02 : 1.0);
+              const double cost = per_cu * (ck.nchunks * stage + mr_eff * (cap / 128.0) * 16 * 25.0) * ((v.nb16 > 0 && tw % 16 != 0) ? 1.02 : 1.0);
               if (cost < best_p) { found_p = true; best_p = cost; p_th = th; p_tw = tw; p_nseg = nseg; p_nr = nr; p_ps = ps; p_cp = cp; p_nb16 = v.nb16; }
             }
             if (!any) break;
@@ -213,7 +221,7 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   // unless those would leave the chip under-filled (at most one round of items: small batches, deep branches), where the
   // layer is a chain of DMA round trips and the small-tile producer/consumer candidates are 1.7-2x faster
   // (W32 batch 64: 128->128 @16x16 30.8 -> 14.9 us, 256->256 @8x8 40.1 -> 23.0 us before deeper chunks)
-  if (!memo_hit && found_p && (!found || pc.mrep == 3 || pc.stride == 2 || pc.cout == 48 || b_items <= (long)cus * b_occ)) {
+  if (!memo_hit && found_p && (!found || pc.mrep == 3 || pc.mrep == kMrep48 || pc.stride == 2 || pc.cout == 48 || b_items <= (long)cus * b_occ)) {
     found = true; b_th = p_th; b_tw = p_tw; b_nseg = p_nseg; b_nr = p_nr; b_ps = p_ps; b_occ = 3; b_cp = p_cp; b_nb16 = p_nb16;
   }
   SCP_REQUIRE(found, "conv m32: no tiling for %dx%d output", L.Ho, L.Wo);

@@ -47,6 +47,20 @@ static_assert(m16_wait(6, 0, false, true) == 3 && m16_wait(6, 2, false, true) ==
 static_assert(m16_wait(6, 0, false, false) == 3 && m16_wait(6, 3, false, false) == 2 && m16_wait(6, 5, false, false) == 0, "");
 static_assert(m16_wait(2, 0, false, true) == 1 && m16_wait(2, 1, false, true) == 4 && m16_wait(5, 4, false, true) == 10 && m16_wait(4, 3, false, true) == 8, "");
 
+// 48-row Cout blocks (three 16-row blocks, NB = 8 columns per consumer wave: 3 x 8 accumulators).  A prefetching k-step requests the
+// next one's NB + 3 fragments in the order A0 B0 A1 B1 A2 B2 B3 .. (one A and one B behind columns 0-2, one B behind the others);
+// a burst (first k-step of a half) in the order A0 A1 A2 B0 B1 ...  lgkmcnt value in front of column n (-1: nothing new to wait for).
+constexpr int m48_issued(int n) { return n <= 3 ? 2 * n : n + 3; }   // requests of a prefetching k-step in front of its column n
+constexpr int m48_wait(int NB, int n, bool first, bool more) {
+  const int total = NB + 3, inew = more ? m48_issued(n) : 0;
+  if (first) return total - (4 + n) + inew;
+  if (n == 0) return total - 5;
+  if (n == 1) return -1;
+  return total - (n + 4) + inew;
+}
+static_assert(m48_wait(8, 0, true, true) == 7 && m48_wait(8, 7, true, true) == 10 && m48_wait(8, 2, false, true) == 9 && m48_wait(8, 5, false, true) == 10 &&
+              m48_wait(8, 7, false, false) == 0 && m48_wait(8, 2, false, false) == 5 && m48_wait(8, 0, false, true) == 6, "");
+
 // WREG > 0: the layer has ONE Cout block of WREG K-chunks and the producers keep all of its packed weights in
 // their (otherwise idle) registers -- 7 x 16 B per thread and chunk -- and refill the LDS chunk buffers with
 // ds_write_b128 instead of LDS-DMA: 7 of the ~16 memory instructions a producer wave issues per stage disappear.
@@ -71,12 +85,15 @@ static_assert(m16_wait(2, 0, false, true) == 1 && m16_wait(2, 1, false, true) ==
 //     waited for with counted lgkmcnt (LDS returns in order).
 //   * fp32 summation order differs from the 32x32x16 form (taps pair up differently inside an MFMA); it is fixed for a layer
 //     shape, so the invariance properties (batch position, batch size, eager = captured) hold as before.
-template <int DT, int KS, int STRIDE, int MR, int NR, int WREG = 0, int C16 = 0>
+// M16 > 0 (round 4): the Cout block is M16 16-row blocks instead of MR 32-row ones -- M16 = 3 with C16 = 8: 48-row blocks on 3 x 8
+// accumulators per consumer wave (512-pixel tile groups), for the one stride-1 layer with 48 output channels and a deep K
+// (transition1: 256 -> 48), which the 64-row form ran with a quarter of its MFMAs on padding rows.
+template <int DT, int KS, int STRIDE, int MR, int NR, int WREG = 0, int C16 = 0, int M16 = 0>
 __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename DtOf<DT>::type T;
   typedef typename FragOf<T>::type frag_t;
-  constexpr int MT = 32 * MR;
+  constexpr int MT = M16 > 0 ? 16 * M16 : 32 * MR;
   constexpr int KK = KS * KS;
   constexpr int MAXP = 4;
   constexpr int PXCAP = C16 ? 64 * C16 : 4 * NR * 32;   // pixel slots of a tile group (16x16x32 consumers: four waves x C16 columns of 16)
@@ -359,12 +376,12 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
     // =====================================================================================
     // consumers, 16x16x32 form (see the header comment): LDS reads, MFMAs, epilogue into the retire buffer
     // =====================================================================================
-    static_assert(KS == 3 && MT == 96, "16x16x32 consumers: 3x3 layers, 96-row Cout blocks");
+    static_assert(KS == 3 && (MT == 96 || MT == 48), "16x16x32 consumers: 3x3 layers, 96- or 48-row Cout blocks");
     constexpr int MB = MT / 16;          // 16-row blocks of the Cout block
     constexpr int NB = C16;              // 16-pixel columns of a consumer wave (PXCAP = 64 NB pixel slots per tile group)
     constexpr int RING = NB + 1;
     constexpr int TAPB = 2 * MT * 16;    // bytes of one tap (both planes) in the packed weight image
-    static_assert(NB == 2 || NB == 4 || NB == 5 || NB == 6, "16x16x32 consumers: column counts with a prefetch schedule");
+    static_assert(MB == 6 ? (NB == 2 || NB == 4 || NB == 5 || NB == 6) : (MB == 3 && NB == 8), "16x16x32 consumers: column counts with a prefetch schedule");
     typedef f32x4 acc_t;
     // Lane (q = lane >> 4, l15 = lane & 15): plane q & 1 of a plane pair; class q >> 1 picks the tap of a k-step's pair.
     // Pairs are chosen so that the two classes' fragment addresses differ by a constant: one pixel (taps kx, kx + 1 of a row) or
@@ -414,6 +431,22 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
     auto kcol = [&](auto s_, auto n_, auto more_, auto first_, frag_t* CA, frag_t* NA, uint32_t wa1n, uint32_t wa3n, uint32_t xln) {
       constexpr int S = decltype(s_)::value, N = decltype(n_)::value;
       constexpr bool MORE = decltype(more_)::value, FIRST = decltype(first_)::value;
+      if constexpr (MB == 3) {   // three MFMAs per column: one A request (columns 0-2) and one B request of the next k-step between them
+        constexpr int W3 = m48_wait(NB, N, FIRST, MORE);
+        if constexpr (W3 >= 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(W3 < 0 ? 0 : W3) : "memory");
+        if constexpr (N == 0) {
+#pragma unroll
+          for (int m = 0; m < MB; ++m) lds_landed(CA[m]);
+        }
+        frag_t& b3 = bR[m16_ring(N, S, RING)];
+        lds_landed(b3);
+        using SN3 = std::integral_constant<int, S + 1>;
+        mfma16_acc<T>(acc[0][N], CA[0], b3);
+        if constexpr (MORE && N < 3) rd_a(SN3{}, std::integral_constant<int, N < 3 ? N : 0>{}, NA, wa1n, wa3n);
+        mfma16_acc<T>(acc[1][N], CA[1], b3);
+        if constexpr (MORE) rd_b(SN3{}, n_, xln);
+        mfma16_acc<T>(acc[2][N], CA[2], b3);
+      } else {
       constexpr int W = m16_wait(NB, N, FIRST, MORE);
       if constexpr (W >= 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(W < 0 ? 0 : W) : "memory");
       if constexpr (N == 0) {
@@ -435,6 +468,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
       mfma16_acc<T>(acc[4][N], CA[4], b);
       if constexpr (MORE) rd_b(SN{}, n_, xln);
       mfma16_acc<T>(acc[5][N], CA[5], b);
+      }
     };
     auto kstep = [&](auto s_, auto more_, auto first_, frag_t* CA, frag_t* NA, uint32_t wa1n, uint32_t wa3n, uint32_t xln) {
       kcol(s_, std::integral_constant<int, 0>{}, more_, first_, CA, NA, wa1n, wa3n, xln);
@@ -443,6 +477,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
       if constexpr (NB > 3) kcol(s_, std::integral_constant<int, 3>{}, more_, first_, CA, NA, wa1n, wa3n, xln);
       if constexpr (NB > 4) kcol(s_, std::integral_constant<int, 4>{}, more_, first_, CA, NA, wa1n, wa3n, xln);
       if constexpr (NB > 5) kcol(s_, std::integral_constant<int, 5>{}, more_, first_, CA, NA, wa1n, wa3n, xln);
+      if constexpr (NB > 6) { kcol(s_, std::integral_constant<int, 6>{}, more_, first_, CA, NA, wa1n, wa3n, xln); kcol(s_, std::integral_constant<int, 7>{}, more_, first_, CA, NA, wa1n, wa3n, xln); }
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
@@ -474,12 +509,13 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
             (void)wa0;
             {   // the first fragments fly while the accumulators are initialised
               rd_a(I0{}, I0{}, a0, wa1, wa3); rd_a(I0{}, I1{}, a0, wa1, wa3); rd_a(I0{}, I2{}, a0, wa1, wa3);
-              rd_a(I0{}, I3{}, a0, wa1, wa3); rd_a(I0{}, I4{}, a0, wa1, wa3); rd_a(I0{}, I5{}, a0, wa1, wa3);
+              if constexpr (MB > 3) { rd_a(I0{}, I3{}, a0, wa1, wa3); rd_a(I0{}, I4{}, a0, wa1, wa3); rd_a(I0{}, I5{}, a0, wa1, wa3); }
               rd_b(I0{}, I0{}, xl); rd_b(I0{}, I1{}, xl);
               if constexpr (NB > 2) rd_b(I0{}, I2{}, xl);
               if constexpr (NB > 3) rd_b(I0{}, I3{}, xl);
               if constexpr (NB > 4) rd_b(I0{}, I4{}, xl);
               if constexpr (NB > 5) rd_b(I0{}, I5{}, xl);
+              if constexpr (NB > 6) { rd_b(I0{}, I6{}, xl); rd_b(I0{}, I7{}, xl); }
             }
             if (c == 0 && u == 0) {   // accumulators start at the bias of their rows: row(j) = 16 m + 4 q + j
               const float* bq = bias_l + mb * MT + 4 * (lane_s >> 4);
@@ -556,6 +592,29 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
                   : [wm] "v"(wa0), [x0] "v"(xa[0]), [x1] "v"(xa[1]), [x2] "v"(xa[2]), [x3] "v"(xa[3]), [x4] "v"(xa[4]), [x5] "v"(xa[5]),
                     [o0] "n"(2 * TAPB + 0), [o1] "n"(2 * TAPB + 256), [o2] "n"(2 * TAPB + 512), [o3] "n"(2 * TAPB + 768), [o4] "n"(2 * TAPB + 1024), [o5] "n"(2 * TAPB + 1280)
                   : "memory");
+              } else if constexpr (NB == 8) {   // 48-row blocks: three A fragments (2 TAPB + m * 256 with TAPB = 2 * 48 * 16), eight B
+                asm volatile(
+                  "s_mov_b64 %[keep], exec\n\t"
+                  "s_mov_b32 exec_lo, 0\n\t"
+                  "ds_read_b128 %[a0], %[wm] offset:3072\n\t"
+                  "ds_read_b128 %[a1], %[wm] offset:3328\n\t"
+                  "ds_read_b128 %[a2], %[wm] offset:3584\n\t"
+                  "ds_read_b128 %[b0], %[x0]\n\t"
+                  "ds_read_b128 %[b1], %[x1]\n\t"
+                  "ds_read_b128 %[b2], %[x2]\n\t"
+                  "ds_read_b128 %[b3], %[x3]\n\t"
+                  "ds_read_b128 %[b4], %[x4]\n\t"
+                  "ds_read_b128 %[b5], %[x5]\n\t"
+                  "ds_read_b128 %[b6], %[x6]\n\t"
+                  "ds_read_b128 %[b7], %[x7]\n\t"
+                  "s_mov_b64 exec, %[keep]"
+                  : [keep] "=&s"(keep), [a0] "+v"(a0[0]), [a1] "+v"(a0[1]), [a2] "+v"(a0[2]),
+                    [b0] "+v"(bR[m16_ring(0, 4, RING)]), [b1] "+v"(bR[m16_ring(1, 4, RING)]), [b2] "+v"(bR[m16_ring(2, 4, RING)]), [b3] "+v"(bR[m16_ring(3, 4, RING)]),
+                    [b4] "+v"(bR[m16_ring(4, 4, RING)]), [b5] "+v"(bR[m16_ring(5, 4, RING)]), [b6] "+v"(bR[m16_ring(NB == 8 ? 6 : 0, 4, RING)]), [b7] "+v"(bR[m16_ring(NB == 8 ? 7 : 0, 4, RING)])
+                  : [wm] "v"(wa0), [x0] "v"(xa[0]), [x1] "v"(xa[1]), [x2] "v"(xa[2]), [x3] "v"(xa[3]), [x4] "v"(xa[4]), [x5] "v"(xa[5]),
+                    [x6] "v"(xa[NB == 8 ? 6 : 0]), [x7] "v"(xa[NB == 8 ? 7 : 0])
+                  : "memory");
+                static_assert(NB != 8 || 2 * TAPB == 3072, "");
               } else if constexpr (NB == 5) {
                 asm volatile(
                   "s_mov_b64 %[keep], exec\n\t"
@@ -658,6 +717,26 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
           } else {
             // residual half-slots are read one row block ahead of the one being finalised (the in-place writes would otherwise
             // order every read behind the previous write)
+            if constexpr (NB > 6) {   // 3 x 8 form: four columns at a time (no row-ahead prefetch)
+#pragma unroll
+              for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int n0 = 0; n0 < NB; n0 += 4) {
+                  uint2 r4[4];
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) r4[k] = *reinterpret_cast<const uint2*>(slot(m, n0 + k));
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) {
+                    const int n = n0 + k;
+                    const uint2 x = r4[k];
+                    const float v0 = acc[m][n][0] + from_bits<T>(x.x & 0xffff), v1 = acc[m][n][1] + from_bits<T>(x.x >> 16);
+                    const float v2 = acc[m][n][2] + from_bits<T>(x.y & 0xffff), v3 = acc[m][n][3] + from_bits<T>(x.y >> 16);
+                    uint2 o;
+                    o.x = relu2_16(pack2<T>(v0, v1), relu_floor); o.y = relu2_16(pack2<T>(v2, v3), relu_floor);
+                    *reinterpret_cast<uint2*>(slot(m, n)) = o;
+                  }
+                }
+            } else {
             uint2 rr[2][NB];
 #pragma unroll
             for (int n = 0; n < NB; ++n) rr[0][n] = *reinterpret_cast<const uint2*>(slot(0, n));
@@ -676,6 +755,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
                 o.x = relu2_16(pack2<T>(v0, v1), relu_floor); o.y = relu2_16(pack2<T>(v2, v3), relu_floor);
                 *reinterpret_cast<uint2*>(slot(m, n)) = o;
               }
+            }
             }
           }
         }
@@ -892,9 +972,9 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
   }
 }
 
-template <int DT, int STRIDE, int MR, int NR, int WREG = 0, int C16 = 0>
+template <int DT, int STRIDE, int MR, int NR, int WREG = 0, int C16 = 0, int M16 = 0>
 int32_t m32p_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
-  auto kern = conv_m32p_kernel<DT, 3, STRIDE, MR, NR, WREG, C16>;
+  auto kern = conv_m32p_kernel<DT, 3, STRIDE, MR, NR, WREG, C16, M16>;
   static LdsOptIn big_lds;   // per device (common.h)
   { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(kern), 160 * 1024, &big_lds); if (rc != SCPOSE_OK) return rc; }
   hipLaunchKernelGGL(kern, dim3(L.grid), dim3(512), lds, st, L);
@@ -911,6 +991,7 @@ int32_t m32p_dispatch(int stride, int mr, int nr, int c16, const ConvLaunch& L, 
       if (c16 == 4) return m32p_launch_one<DT, 1, 3, 2, 0, 4>(L, lds, st);
       if (c16 == 2) return m32p_launch_one<DT, 1, 3, 1, 0, 2>(L, lds, st);
     }
+    if (stride == 1 && mr == kMrep48 && c16 == 8) return m32p_launch_one<DT, 1, 2, 4, 0, 8, 3>(L, lds, st);   // 48-row blocks: 3 x 8 accumulators
     set_error("conv m32p: 16x16x32 consumer variant stride=%d mr=%d columns=%d not built", stride, mr, c16);
     return SCPOSE_E_INVALID;
   }

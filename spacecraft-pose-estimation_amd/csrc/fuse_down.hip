@@ -48,11 +48,6 @@ struct FdLaunch {
   int32_t tiles_x, tiles_y, tiles_total, tiles_per_wg, grid;
 };
 
-inline int fd_row_channel(int row) {   // MFMA row -> channel inside its 16-block (conv_s2r.hip: s2r_row_channel)
-  const int q = row >> 2, reg = row & 3;
-  return (q & 1) * 8 + (q >> 1) * 4 + reg;
-}
-
 }  // namespace
 
 template <int DT, int PLANES, int NBLK, int G, int NW>

@@ -47,6 +47,12 @@ CASES = [
     (32, 96, 3, 1, 12, 12, 7, True, True),      # 2 K-chunks only: single-role kernel, not producer/consumer
     (384, 384, 3, 1, 5, 5, 9, True, True),
     (96, 96, 3, 1, 1, 1, 4, True, True),
+    # 48-row Cout blocks on the 16x16x32 consumers' 3 x 8 form (conv_m32p_kernel.h, M16 = 3): deep-K stride-1 layers with 48 output
+    # channels (transition1 is the one in HRNet); residual epilogue, ragged maps, several images per work item, one-pixel maps
+    (256, 48, 3, 1, 20, 28, 3, True, True),
+    (128, 48, 3, 1, 24, 24, 2, True, False),
+    (192, 48, 3, 1, 5, 7, 9, False, True),
+    (256, 48, 3, 1, 1, 1, 4, True, True),
     # register-weight stride-2 kernel (conv_s2r.hip): every (Cin, channel-group) variant, ragged / odd maps, one-row maps
     (48, 192, 3, 2, 48, 48, 2, False, True),
     (48, 48, 3, 2, 18, 50, 3, False, False),
