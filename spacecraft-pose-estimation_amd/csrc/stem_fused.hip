@@ -55,6 +55,7 @@ struct StemFusedLaunch {
   int32_t N, H, W, Ho, Wo;
   int32_t tiles_x, tiles_y, tiles_total, grid;
   uint32_t* sched;       // dynamic tile queue (conv_device.h: tile_claim)
+  FastDiv fd_tiles_img, fd_tiles_x;   // the tile decode's divisions (three decodes per tile were ~300 scalar instructions of division)
 };
 
 // MFMA accumulator row (4 * (lane >> 4) + reg) -> channel within the 16-channel block (same map as conv_igemm.hip):
@@ -107,32 +108,35 @@ __global__ __launch_bounds__(512, 2) void stem_fused_kernel(const StemFusedLaunc
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
       w2f[s][mb] = *reinterpret_cast<const frag_t*>(static_cast<const char*>(p.w2) + (((s * 4 + 2 * ch + mb) * 4 + q) * 16 + r) * 16);
-  float4 bs1[4], bs2[2];
+  float4 bs1[4];
+  // conv2's biases wait in LDS (behind the tile queue words) for the tile's epilogue: eight registers that the k-loops need more --
+  // with them in registers the kernel spilled two values whose reload (and its vmcnt(0)) sat at the head of conv1, right behind the
+  // next tile's input loads: the prefetch was waited for before conv1 instead of flying under it
+  float* b2l = reinterpret_cast<float*>(tq + 4);
+  for (int e = tid; e < 64; e += 512) b2l[e] = p.b2[e];
 #pragma unroll
   for (int m = 0; m < 4; ++m) bs1[m] = *reinterpret_cast<const float4*>(p.b1 + m * 16 + q * 4);
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb) bs2[mb] = *reinterpret_cast<const float4*>(p.b2 + (2 * ch + mb) * 16 + q * 4);
 
   // conv1 operand addressing: dword i of this lane's fragment sits at B0(pixel) + dl[i]
   int dl[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) dl[i] = q < 3 ? q * (kIRow * 2) + 4 * i : (i < 3 ? i : 2) * (kIRow * 2) + 16;
-  // conv2 operand addressing: k-step s, k-group q -> (tap, plane) pair t = 4 s + q
-  int k2[18];
-#pragma unroll
-  for (int s = 0; s < 18; ++s) {
-    const int t = 4 * s + q, tap = t >> 3, plane = t & 7, ky = tap / 3, kx = tap - 3 * ky;
-    k2[s] = plane * kMS + (ky * kMW + kx) * 16;
-  }
+  // conv2 operand addressing: k-step s, k-group q -> (tap, plane) pair t = 4 s + q: plane = t & 7 = q + 4 (s & 1), tap = t >> 3 =
+  // s >> 1 -- so a fragment address is one of TWO per-lane plane offsets plus a compile-time tap offset (an immediate of the
+  // ds_read); eighteen per-lane offsets in registers spilled, and the reload's vmcnt(0) sat in front of conv1, behind the next
+  // tile's input loads
+  const int k2p0 = q * kMS, k2p1 = (4 + q) * kMS;
+  auto k2t = [](int s) constexpr -> int { const int tap = s >> 1, ky = tap / 3, kx = tap - 3 * ky; return (ky * kMW + kx) * 16; };
 
   // tiles come from the launch's dynamic queue (conv_device.h): this tile and the next are always known (the next patch is
   // fetched under this tile's conv1); the one after is claimed at the top of the tile and published through LDS in front of
   // the tile's last barrier
   if (tid == 0) { tq[0] = tile_claim(p.sched, p.tiles_total); tq[1] = tq[0] < 0 ? -1 : tile_claim(p.sched, p.tiles_total); }
+  auto fdiv = [](int n, const FastDiv& f) -> int { return (int)((__umulhi((uint32_t)n, f.mul) + (uint32_t)n * f.add) >> f.shift); };
   auto decode = [&](int t, int& img, int& oy0, int& ox0) {
-    img = t / tiles_per_img;
+    img = fdiv(t, p.fd_tiles_img);
     const int rem = t - img * tiles_per_img;
-    const int ty = rem / p.tiles_x;
+    const int ty = fdiv(rem, p.fd_tiles_x);
     oy0 = ty * kTH; ox0 = (rem - ty * p.tiles_x) * kTW;
   };
 
@@ -211,8 +215,11 @@ __global__ __launch_bounds__(512, 2) void stem_fused_kernel(const StemFusedLaunc
     int img, oy0, ox0;
     decode(t, img, oy0, ox0);
     const bool more = t_next >= 0;
-    int t_after = -1;
-    if (tid == 0 && more) t_after = tile_claim(p.sched, p.tiles_total);   // returns under conv1 / conv2
+    // the tile after the next: the counter's RAW value is kept and compared with the tile count only where it is published (in front
+    // of the tile's last barrier).  Turned into a tile id on the spot -- tile_claim() -- the compiler waited for the returning atomic
+    // three instructions after issuing it (vmcnt(0)): wave 0 stood still for the atomic's round trip at the top of every tile.
+    uint32_t claim_raw = 0xffffffffu;
+    if (tid == 0 && more) claim_raw = __hip_atomic_fetch_add(p.sched, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (more) fetch(t_next);                               // global loads fly under conv1
 
     // ---- conv1 -> intermediate tile ----
@@ -251,17 +258,18 @@ __global__ __launch_bounds__(512, 2) void stem_fused_kernel(const StemFusedLaunc
     for (int mb = 0; mb < 2; ++mb) { acc[mb][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mb][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const char* bcol0 = mid + ((2 * (2 * cpair)) * kMW + 2 * r) * 16;
     const char* bcol1 = bcol0 + 2 * kMW * 16;
+    const char* const bc[2][2] = {{bcol0 + k2p0, bcol0 + k2p1}, {bcol1 + k2p0, bcol1 + k2p1}};   // [column][k-step parity]
     frag_t bq[3][2];                                       // fragments two k-steps ahead (see conv_s2r.hip)
 #pragma unroll
     for (int s0 = 0; s0 < 2; ++s0) {
-      bq[s0][0] = *reinterpret_cast<const frag_t*>(bcol0 + k2[s0]);
-      bq[s0][1] = *reinterpret_cast<const frag_t*>(bcol1 + k2[s0]);
+      bq[s0][0] = *reinterpret_cast<const frag_t*>(bc[0][s0 & 1] + k2t(s0));
+      bq[s0][1] = *reinterpret_cast<const frag_t*>(bc[1][s0 & 1] + k2t(s0));
     }
 #pragma unroll
     for (int s = 0; s < 18; ++s) {
       if (s + 2 < 18) {
-        bq[(s + 2) % 3][0] = *reinterpret_cast<const frag_t*>(bcol0 + k2[s + 2]);
-        bq[(s + 2) % 3][1] = *reinterpret_cast<const frag_t*>(bcol1 + k2[s + 2]);
+        bq[(s + 2) % 3][0] = *reinterpret_cast<const frag_t*>(bc[0][s & 1] + k2t(s + 2));
+        bq[(s + 2) % 3][1] = *reinterpret_cast<const frag_t*>(bc[1][s & 1] + k2t(s + 2));
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void stem_fused_kernel(const StemFusedLaunc
     const size_t plane_sz = (size_t)p.Ho * p.Wo;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
-      const float4 bs = bs2[mb];
+      const float4 bs = *reinterpret_cast<const float4*>(b2l + (2 * ch + mb) * 16 + q * 4);
       uint32_t a[4], b[4];
       a[0] = __float_as_uint(acc[mb][0][0] + bs.x); a[1] = __float_as_uint(acc[mb][0][1] + bs.y);
       a[2] = __float_as_uint(acc[mb][0][2] + bs.z); a[3] = __float_as_uint(acc[mb][0][3] + bs.w);
@@ -299,13 +307,13 @@ __global__ __launch_bounds__(512, 2) void stem_fused_kernel(const StemFusedLaunc
         *reinterpret_cast<u32x4_t*>(static_cast<char*>(p.out) + (((size_t)img * 8 + plane) * plane_sz + (size_t)oy * p.Wo + ox) * 16) = ov;
       }
     }
-    if (tid == 0) tq[2] = t_after;
+    if (tid == 0) tq[2] = claim_raw < (uint32_t)p.tiles_total ? (int)claim_raw : -1;
     __syncthreads();                                       // intermediate tile free again; next patch committed; tq[2] published
   }
   if (tid == 0) tile_retire(p.sched);
 }
 
-size_t stem_fused_lds_bytes() { return (size_t)kLutBytes + kInBytes + kMidBytes + 16; }
+size_t stem_fused_lds_bytes() { return (size_t)kLutBytes + kInBytes + kMidBytes + 16 + 64 * 4; }
 
 // Host: pack the two BN-folded convolutions (OIHW f32) for the kernel.  w1: [64][3][3][3], w2: [64][64][3][3].
 void stem_fused_pack(const float* w1, const float* b1, const float* w2, const float* b2, int dtype, std::vector<uint16_t>* pw1,
@@ -354,6 +362,7 @@ int32_t stem_fused_launch(const void* in, int in_fmt, const void* w1, const void
   L.N = N; L.H = H; L.W = W; L.Ho = H / 4; L.Wo = W / 4;
   L.tiles_x = (L.Wo + kTW - 1) / kTW; L.tiles_y = (L.Ho + kTH - 1) / kTH;
   L.tiles_total = N * L.tiles_x * L.tiles_y;
+  L.fd_tiles_img = make_fastdiv(L.tiles_x * L.tiles_y); L.fd_tiles_x = make_fastdiv(L.tiles_x);
   L.grid = conv_device_cus() < L.tiles_total ? conv_device_cus() : L.tiles_total;
   L.sched = sched;
   const size_t lds = stem_fused_lds_bytes();
