@@ -46,6 +46,7 @@ struct FdLaunch {
   uint32_t in_bytes;
   int32_t N, H, W, Ho, Wo;
   int32_t tiles_x, tiles_y, tiles_total, tiles_per_wg, grid;
+  FastDiv fd_tiles_img, fd_tiles_x;   // tile decode by exact multiply-shift
 };
 
 }  // namespace
@@ -103,10 +104,11 @@ __global__ __launch_bounds__(NW * 64, 2) void fuse_down_kernel(const FdLaunch p)
   const int wg = xcd_remap(blockIdx.x, p.grid);
   const int t_begin = wg * p.tiles_per_wg;
   const int t_end = min(p.tiles_total, t_begin + p.tiles_per_wg);
+  auto fdiv = [](int n, const FastDiv& f) -> int { return (int)((__umulhi((uint32_t)n, f.mul) + (uint32_t)n * f.add) >> f.shift); };
   auto decode = [&](int t, int& img, int& oy0, int& ox0) {
-    img = t / tiles_per_img;
+    img = fdiv(t, p.fd_tiles_img);
     const int rem = t - img * tiles_per_img;
-    const int ty = rem / p.tiles_x;
+    const int ty = fdiv(rem, p.fd_tiles_x);
     oy0 = ty * kTH; ox0 = (rem - ty * p.tiles_x) * kTW;
   };
   const buf_rsrc_t rs_in = make_buf(p.in, p.in_bytes), rs_y = make_buf(p.y, p.in_bytes);
@@ -371,6 +373,7 @@ int32_t fuse_down_launch(const FuseDownPacked& fd, const void* x0, int N, int H,
     L.N = n; L.H = H; L.W = W; L.Ho = Ho; L.Wo = Wo;
     L.tiles_x = (Wo + kTW - 1) / kTW; L.tiles_y = (Ho + kTH - 1) / kTH;
     L.tiles_total = n * L.tiles_x * L.tiles_y;
+    L.fd_tiles_img = make_fastdiv(L.tiles_x * L.tiles_y); L.fd_tiles_x = make_fastdiv(L.tiles_x);
     int grid = conv_device_cus();
     if (grid > L.tiles_total) grid = L.tiles_total;
     L.tiles_per_wg = (L.tiles_total + grid - 1) / grid;
