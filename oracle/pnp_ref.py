@@ -1,5 +1,6 @@
 """ctypes front end of oracle/pnp_ref.c plus the synthetic pose / keypoint generator
-(TEST ORACLE, not product -- see pnp_ref.c for the pinning status: PARITY UNPINNED)."""
+(TEST ORACLE, not product -- see pnp_ref.c for the pinning status: camera model and confidence filter pinned to the
+reference's own code, cv2.solvePnPRansac internals unpinned)."""
 import ctypes
 import os
 import subprocess
@@ -108,6 +109,15 @@ def undistort(uv, K=CAMERA_K, dist=CAMERA_DIST):
     lib().pnp_ref_undistort(_p(np.ascontiguousarray(K, dtype=np.float64)), _p(np.ascontiguousarray(dist, dtype=np.float64)),
                             _p(uv), c_int(len(uv)), _p(xy))
     return xy
+
+
+def conf_mask(conf, conf_thr0=0.95, min_pts=15, thr_decay=0.8, thr_iters=100):
+    """export_predicted_poses_real.py:186-197 for one frame's scores: the boolean mask of the landmarks that reach the solver."""
+    c = np.ascontiguousarray(conf, dtype=np.float32)
+    mask = np.zeros(len(c), dtype=np.uint8)
+    lib().pnp_ref_conf_mask.restype = c_int
+    lib().pnp_ref_conf_mask(_p(c), c_int(len(c)), c_double(conf_thr0), c_int(min_pts), c_double(thr_decay), c_int(thr_iters), _p(mask))
+    return mask.astype(bool)
 
 
 def rng_draws(count, n):

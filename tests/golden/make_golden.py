@@ -15,6 +15,14 @@ container (it never ships; /root/reference does not exist on the GPU box):
     merged heat-map (lib/core/function.py:360-365: SHIFT_HEATMAP column shift, then (output + flipped) * 0.5) are
     applied to the reference flip_back's output here, since function.py itself needs yacs/json_tricks/torchvision.
 
+  * pose_estimation/export_predicted_poses_real.py (quat2dcm, project, the confidence-threshold loop :186-197) and
+    object_detection/speed_plus_utils/utils.py (Camera, quat2dcm, project :108-139) -- the reference's FIRST-PARTY camera
+    model, imported under stubs for cv2 / kornia (absent from the image); the threshold loop is inline in main(), so its
+    own source lines are located in the imported module and executed here on seeded scores.  The fixture
+    (camera_reference_outputs.npz) holds seeded poses, the projections of landmarks.csv under camera.json's / calibration.json's
+    intrinsics with and without distortion, the direction-cosine matrices, and the masks.  cv2.solvePnPRansac itself stays
+    unpinned (no OpenCV here).
+
 Only data is written (npz): no reference source text.  Re-run: python tests/golden/make_golden.py
 """
 import importlib
@@ -213,6 +221,84 @@ def host_vectors():
     print("host vectors: acc", acc, "cnt", cnt, "loss", out["loss_use0"], out["loss_use1"])
 
 
+def camera_vectors():
+    """Camera model + confidence filter through the reference's own code (SURVEY.md section 8 a11, 8d, section 9 "PnP")."""
+    import inspect
+    import json
+    import re
+    install_cv2_stub()
+    for name in ("kornia", "kornia.geometry", "kornia.geometry.conversions"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["kornia.geometry.conversions"].angle_axis_to_quaternion = None
+    sys.modules["kornia.geometry.conversions"].QuaternionCoeffOrder = None
+    top = os.path.dirname(REF)
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    exp = load("ref_export_poses", os.path.join(top, "pose_estimation/export_predicted_poses_real.py"))
+    cwd = os.getcwd()
+    os.chdir(os.path.join(top, "object_detection"))        # utils.Camera opens 'speed_plus_utils/camera.json' relative to the cwd
+    try:
+        utl = load("ref_speed_utils", os.path.join(top, "object_detection/speed_plus_utils/utils.py"))
+    finally:
+        os.chdir(cwd)
+    import pandas as pd
+    lm = pd.read_csv(os.path.join(top, "object_detection/speed_plus_utils/landmarks.csv"))[["x", "y", "z"]].values   # as :156 reads it
+    with open(os.path.join(top, "object_detection/speed_plus_utils/calibration.json")) as f:
+        cal = json.load(f)
+    K = np.array(cal["intrinsics"]["camera_matrix"]); dist = np.array(cal["intrinsics"]["distortion_coefficients"])   # as :183-184
+
+    rng = np.random.default_rng(2025)
+    n = 24
+    q = rng.standard_normal((n, 4)); q[0] = (1, 0, 0, 0); q[1] = (0, 2, 0, 0)       # identity; a half turn, not normalised
+    r = np.stack([rng.uniform(-0.25, 0.25, n), rng.uniform(-0.15, 0.15, n), np.ones(n)], 1) * rng.uniform(3.0, 10.0, (n, 1))
+    out = {"landmarks": lm, "K_calibration": K, "dist_calibration": dist, "K_camera": np.array(utl.Camera.K),
+           "dist_camera": np.array(utl.Camera.dcoef), "q": q, "r": r}
+    out["dcm_export"] = np.stack([exp.quat2dcm(qi) for qi in q])
+    out["dcm_utils"] = np.stack([utl.quat2dcm(qi) for qi in q])
+    out["proj_distorted"] = np.stack([utl.project(qi, ri, lm) for qi, ri in zip(q, r)])            # utils.py:108-139, Camera.dcoef
+    out["proj_pinhole"] = np.stack([exp.project(qi, ri, K, lm) for qi, ri in zip(q, r)])            # export...:92-123, dist = 0
+
+    # ---- the confidence-threshold loop: the reference's own lines of main(), found by their anchors and executed as they stand ----
+    src = inspect.getsource(exp.main).splitlines()
+    first = next(i for i, l in enumerate(src) if "confidence_values = " in l)
+    last = next(i for i, l in enumerate(src) if "cv2.solvePnPRansac(" in l)
+    block = src[first:last]
+    while block and not block[-1].strip():
+        block.pop()
+    indent = len(block[0]) - len(block[0].lstrip())
+    code = compile("\n".join(l[indent:] for l in block), "<export_predicted_poses_real.py:%d-%d of main()>" % (first, last), "exec")
+    assert re.search(r"confidence_threshold \*= 0\.8", "\n".join(block)) and "max_iters = 100" in "\n".join(block)
+    cases = []
+    for j in (11, 24):
+        c = rng.uniform(0.0, 1.0, (12, j)).astype(np.float32)
+        c[0] = 1.0                                           # everything passes at once
+        c[1] = 0.0                                           # nothing ever passes: 100 iterations, empty mask
+        c[2, : j // 2] = 1e-12                               # below the last threshold 0.95 * 0.8^100
+        c[3] = np.float32(0.95)                              # equal to the first threshold: strict '>'
+        c[4, 0] = np.float32(0.95 * 0.8 ** 100)              # equal to the last threshold after rounding to float32
+        c[5] = np.float32(0.95 * 0.8 ** 7)                   # equal to an intermediate threshold
+        c[6] = np.linspace(0.05, 1.0, j, dtype=np.float32)
+        c[7, 4:] = -1.0                                      # exactly four usable landmarks
+        c[8] = np.nextafter(np.float32(0.95 * 0.8 ** 3), np.float32(1.0))   # one ulp above a threshold
+        cases.append(c)
+    for c in cases:
+        masks = np.zeros(c.shape, dtype=bool); thr = np.zeros(len(c)); its = np.zeros(len(c), dtype=np.int64)
+        for i, row in enumerate(c):
+            kp = np.concatenate([np.zeros((len(row), 2), np.float32), row[:, None]], 1)
+            ns = {"np": np, "correspondence": {"keypoints": kp.flatten()}}
+            exec(code, ns)
+            masks[i] = ns["good_confidence_indices"]; thr[i] = ns["confidence_threshold"]; its[i] = ns["curr_iters"]
+        out["conf_j%d" % c.shape[1]] = c; out["mask_j%d" % c.shape[1]] = masks
+        out["thr_j%d" % c.shape[1]] = thr; out["iters_j%d" % c.shape[1]] = its
+    np.savez_compressed(os.path.join(HERE, "camera_reference_outputs.npz"), **out)
+    print("camera vectors: %d poses, masks pass counts" % n, out["mask_j11"].sum(1), out["mask_j24"].sum(1))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     hrnet_vectors()
@@ -220,3 +306,4 @@ if __name__ == "__main__":
     cms_vectors()
     decode_vectors()
     host_vectors()
+    camera_vectors()

@@ -134,3 +134,22 @@ def test_pnp_empty_batch_and_bad_args(gpu_ops):
     with pytest.raises(gpu_ops.nat.NativeError, match="landmarks"):
         gpu_ops.pnp_epnp_ransac(torch.zeros(1, 65, 3).cuda(), torch.zeros(65, 3, dtype=torch.float64).cuda(),
                                 torch.from_numpy(P.CAMERA_K).cuda(), None)
+
+
+@pytest.mark.parametrize("j,spoil", [(11, False), (11, True), (24, False), (24, True)])
+def test_pnp_filter_and_projection_against_the_reference_camera_fixture(gpu_ops, j, spoil):
+    """The kernel's confidence filter and camera model against vectors made by the REFERENCE's own code
+    (tests/golden/camera_reference_outputs.npz: export_predicted_poses_real.py:186-197 executed line for line on seeded scores;
+    speed_plus_utils/utils.py:108-139 project): key points are exact reference-model projections under the fixture's poses, so the
+    frame's answer is known -- status = the number of landmarks the reference's loop admits (P3P for four, -1 below), the pose =
+    the generating one; with `spoil` the landmarks the loop drops are 300 px off, so admitting one would show in the pose."""
+    from test_camera_golden import G, frames_from_fixture, expected_status
+    lm = G["landmarks"] if j == 11 else np.random.default_rng(24).uniform(-0.6, 0.6, (24, 3))
+    kp, Rs, ts, count = frames_from_fixture(j, lm, spoil)
+    rot, tv, st, _ = _gpu(gpu_ops, kp, landmarks=np.ascontiguousarray(lm))
+    p3p = count == 4
+    assert np.array_equal(st[~p3p], expected_status(count)[~p3p]) and set(st[p3p].tolist()) <= {4, -2}
+    ok = st >= 5
+    assert P.rot_angle(rot[ok], Rs[ok]).max() < 2e-5
+    assert (np.linalg.norm(tv[ok] - ts[ok], axis=1) / np.linalg.norm(ts[ok], axis=1)).max() < 2e-5
+    _check((rot, tv, st, None), P.solve_batch(kp, landmarks=lm))
