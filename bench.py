@@ -96,6 +96,15 @@ def parse():
                     help="side line: the small FITTED HRNet of tests/golden/chain_checkpoint.npz on synthetic landmark frames (128x128 crops "
                          "whose content determines the key points), PnP chained to the decoded key points; reports the pose error against "
                          "the generating poses.  The only configuration whose heat-maps carry a pose (VERDICT r3 #3)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="side line: files -> poses through the product CLI path (synthetic 1920x1200 JPEG frames on disk -> data loader -> "
+                         "validate() -> pred.mat -> export -> opencv_poses.json), frames/s per stage beside the reference-style host loader "
+                         "(tools_dev/pipeline_bench.py)")
+    ap.add_argument("--pipeline-frames", type=int, default=512)
+    ap.add_argument("--pipeline-workers", type=int, default=min(8, os.cpu_count() or 1))
+    ap.add_argument("--cpu-stub", action="store_true",
+                    help="(tests only) run the multi-rank step loop on CPU tensors over gloo with a stand-in engine: exercises the sharding, "
+                         "gather, timing and printing code, measures nothing")
     return ap.parse_args()
 
 
@@ -137,8 +146,86 @@ def cpu_baseline(cfg, sd, image, nframes, kp_sample):
             "stage_s_per_frame": {"hrnet": t_net / nframes, "decode": t_dec / nframes, "pnp": t_pnp / nframes}}
 
 
+# ---- --cpu-stub: the multi-rank step loop of THIS file on CPU tensors over gloo (tests/test_parallel_gloo.py) ----------------------
+# A stand-in for torch.cuda, the engine and the two ops, so that the code a first multi-GPU run executes -- rank != 0 without host
+# buffers, the double-buffered blocks, the all-gather into `gathered`, barrier + all_reduce(MAX) timing, rank 0 alone printing --
+# has run before.  It computes nothing and measures nothing: the line it prints says so.
+class _CpuEvent:
+    def __init__(self, enable_timing=False):
+        self.t = None
+
+    def record(self, stream=None):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+class _CpuStream:
+    def wait_event(self, e):
+        pass
+
+
+class _CpuShim:
+    Event = _CpuEvent
+
+    def __init__(self):
+        import contextlib
+        self._null = contextlib.nullcontext
+
+    def is_available(self): return True
+    def set_device(self, d): pass
+    def Stream(self, device=None): return _CpuStream()
+    def current_stream(self): return _CpuStream()
+    def stream(self, s): return self._null()
+    def synchronize(self): pass
+
+
+class _StubGraph:
+    nodes = 0
+
+    def __init__(self, eng, x, c, s):
+        self.eng, self.x, self.c, self.s = eng, x, c, s
+
+    def replay(self):
+        return self.eng.forward_decode(self.x, self.c, self.s, True)
+
+
+class _StubEngine:
+    """forward_decode = a deterministic function of the frames (their mean), so that a wrong shard shows in the result."""
+    def __init__(self, joints): self.j = joints
+    def tail_fused(self, n, h, w): return True
+    def forward_decode(self, x, c, s, post=True, profile=False):
+        m = x.reshape(x.shape[0], -1).float().mean(1)
+        return m.view(-1, 1, 1).expand(-1, self.j, 3).contiguous()
+    def capture_decode(self, x, c, s, post=True, concurrent=True): return _StubGraph(self, x, c, s)
+    def profile_read(self): return [{"ms": 1.0, "flops_per_frame": 1e9, "bytes_per_frame": 1e6, "kind": 1, "a": 31, "cin": 96, "cout": 96}]
+    @staticmethod
+    def kernel_classes(recs): return ["1:31:96:96" for _ in recs]
+    def stats(self, h, w): return {"launches": 1, "flops_per_frame": 1e9, "act_bytes_per_frame": 1e6}
+
+
+class _StubOps:
+    """pnp_epnp_ransac(rows=...) = row i <- [rank, local frame index, mean of the frame's key points, 0..., status 11]."""
+    def __init__(self, rank): self.rank = rank
+    def pnp_epnp_ransac(self, kp, lm, K, dist, rows=None):
+        n = kp.shape[0]
+        rows.zero_()
+        rows[:, 0] = float(self.rank); rows[:, 1] = torch.arange(n, dtype=torch.float64); rows[:, 2] = kp.reshape(n, -1).double().mean(1)
+        rows[:, 12] = 11.0
+        return rows
+
+
 def main():
     args = parse()
+    stub = bool(args.cpu_stub)
+    cuda = _CpuShim() if stub else torch.cuda
+    if args.pipeline:
+        sys.path.insert(0, os.path.join(ROOT, "tools_dev"))
+        import pipeline_bench
+        res = pipeline_bench.run(args.pipeline_frames, args.pipeline_workers, 64 if args.batch == BATCH_PER_GPU else args.batch, args.model)
+        print(json.dumps({"metric": "frames/sec files -> poses (product CLI path)", "unit": "frames/s", **res}))
+        return
     if args.events:
         args.model, args.dtype = "w32", "f16"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -148,7 +235,7 @@ def main():
         from importlib import import_module
         par = import_module("spacecraft-pose-estimation_amd.parallel")
         have = par.visible_gpu_count()
-        if have is not None and have < args.gpus:
+        if have is not None and have < args.gpus and not args.cpu_stub:
             raise SystemExit("bench.py: --gpus %d but only %d device(s) visible" % (args.gpus, have))
         raise SystemExit(par.spawn_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
@@ -158,10 +245,10 @@ def main():
         if rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world), file=sys.stderr)
         args.gpus = world
-    if not torch.cuda.is_available():
+    if not cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    cuda.set_device(local_rank)
+    dev = torch.device("cpu") if stub else torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -169,11 +256,14 @@ def main():
         import scpose  # noqa: F401
         from importlib import import_module
         par = import_module("spacecraft-pose-estimation_amd.parallel")
-        dist.init_process_group("nccl", init_method=par.init_method(), rank=rank, world_size=world, device_id=dev)
+        if stub:
+            dist.init_process_group("gloo", init_method=par.init_method(), rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", init_method=par.init_method(), rank=rank, world_size=world, device_id=dev)
 
     import scpose  # noqa: F401  (alias of the hyphenated package)
     from importlib import import_module
-    ops = import_module("spacecraft-pose-estimation_amd.ops")
+    ops = _StubOps(rank) if stub else import_module("spacecraft-pose-estimation_amd.ops")
     syn = import_module("spacecraft-pose-estimation_amd.synthetic")   # product-side data generation (no oracle/)
 
     image = args.image or (IMAGE if args.model == "w48" else 256)
@@ -186,8 +276,10 @@ def main():
         args.chained = True
     else:
         cfg = syn.hrnet_cfg(48 if args.model == "w48" else 32, JOINTS, image)
-        sd = syn.random_checkpoint(cfg, seed=0)
-    eng = ops.HrnetEngine(cfg, sd, dtype=args.dtype, device=dev)
+        sd = None if stub else syn.random_checkpoint(cfg, seed=0)
+    if stub:
+        args.chained = True      # the stand-in PnP folds the decoded key points into its rows: a frame on the wrong rank shows
+    eng = _StubEngine(JOINTS) if stub else ops.HrnetEngine(cfg, sd, dtype=args.dtype, device=dev)
     B = args.batch
     if args.graph < 0:
         args.graph = 1
@@ -214,8 +306,9 @@ def main():
     heat = [torch.empty((B, JOINTS, hh, hh), dtype=torch.float32, device=dev) for _ in range(2)]
     block = [torch.empty((B, 13), dtype=torch.float64, device=dev) for _ in range(2)]
     gathered = [torch.empty((world * B, 13), dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
-    host_buf = [torch.empty((world * B, 13), dtype=torch.float64).pin_memory() for _ in range(2)] if rank == 0 else None
-    side = torch.cuda.Stream(device=dev)
+    host_buf = [torch.empty((world * B, 13), dtype=torch.float64) if stub else torch.empty((world * B, 13), dtype=torch.float64).pin_memory()
+                for _ in range(2)] if rank == 0 else None
+    side = cuda.Stream(device=dev)
     # captured forward, one graph per output buffer (same kernels, same results; scpose.h: scpose_hrnet_graph_*)
     # --fused-decode 1 (default): scpose_hrnet_forward_decode -- the key points come out of the network's last kernel
     # (head_fused.hip: last fuse sum + final_layer + decode in one pass), no heat-map is written or re-read
@@ -234,12 +327,12 @@ def main():
     def step(profile, timed=False):
         k = counter[0] & 1
         counter[0] += 1
-        main = torch.cuda.current_stream()
+        main = cuda.current_stream()
         if done[k] is not None:
             main.wait_event(done[k])              # buffers k were last read by the side stream two steps ago
         fwd_start = None
         if timed:
-            fwd_start = torch.cuda.Event(enable_timing=True)
+            fwd_start = cuda.Event(enable_timing=True)
             fwd_start.record(main)
         kp = None
         if graphs is not None and not profile:
@@ -249,21 +342,19 @@ def main():
             # eager (--graph 0) and the roofline pass: the SAME launch list as the captured key-point forward (fused tail with the
             # decode inside, no heat-map written), with per-launch events when profiling
             kp = eng.forward_decode(frames, center, scale, True, profile=profile)
-            kp.record_stream(side)                # allocated on the main stream, read by PnP on the side stream when --chained
+            if not stub:
+                kp.record_stream(side)                # allocated on the main stream, read by PnP on the side stream when --chained
         else:
             eng.forward(frames, out=heat[k], profile=profile)
-        fwd_done = torch.cuda.Event(enable_timing=timed)
+        fwd_done = cuda.Event(enable_timing=timed)
         fwd_done.record(main)
         if timed:
             fwd_events.append((fwd_start, fwd_done))
-        with torch.cuda.stream(side):
+        with cuda.stream(side):
             side.wait_event(fwd_done)
             if kp is None:
                 kp = ops.decode(heat[k], center, scale, True)
-            rot, tv, st = ops.pnp_epnp_ransac(kp if args.chained else kp_syn, lm, Kc, dc)
-            block[k][:, 0:9] = rot.view(B, 9)
-            block[k][:, 9:12] = tv
-            block[k][:, 12] = st.double()
+            ops.pnp_epnp_ransac(kp if args.chained else kp_syn, lm, Kc, dc, rows=block[k])   # the kernel writes [R, t, status] rows itself
             if world > 1:
                 dist.all_gather_into_tensor(gathered[k], block[k])
                 out = gathered[k]
@@ -271,7 +362,7 @@ def main():
                 out = block[k]
             if rank == 0:
                 host_buf[k].copy_(out, non_blocking=True)   # (R, t, status) of every frame on rank 0's host
-            done[k] = torch.cuda.Event()
+            done[k] = cuda.Event()
             done[k].record(side)
         if profile:   # per-launch HIP events of this forward (blocks the host until the forward has finished)
             recs = eng.profile_read()
@@ -284,7 +375,7 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        cuda.synchronize()
 
     for _ in range(args.warmup):
         step(False)
@@ -380,7 +471,16 @@ def main():
                                 for k2, v2 in ranked[1:6]]
         fwd_ms = sum(v[0] for v in prof_ms.values()) / max(prof_steps, 1)   # sum of per-launch event intervals (event overhead included)
         cpu = None
-        if world == 1 and args.cpu_frames > 0:
+        stub_check = None
+        if stub:   # every rank's block must sit at its place in rank 0's host buffer, in frame order, with that rank's own frames behind it
+            stub_check = True
+            hb = host.numpy()
+            for r in range(world):
+                fr = syn.rgb_crops(B, image, torch.Generator().manual_seed(1000 + r))
+                want = fr.reshape(B, -1).float().mean(1).double().numpy()
+                blk = hb[r * B:(r + 1) * B]
+                stub_check = stub_check and bool((blk[:, 0] == r).all() and (blk[:, 1] == np.arange(B)).all() and np.array_equal(blk[:, 2], want))
+        if world == 1 and args.cpu_frames > 0 and not stub:
             cpu = cpu_baseline(cfg, sd, image, args.cpu_frames, kp_np)
         st = eng.stats(image, image)
         chain_report = None
@@ -395,7 +495,8 @@ def main():
                             "inliers_min": int(hb[:, 12].min()),
                             "note": "landmarks are drawn up to one crop pixel (side / 128 frame px) from their projection (synthetic.landmark_frames)"}
         line = {
-            "metric": "poses/sec end-to-end (HRNet+PnP) at batch 256; keypoint/pose err vs ref",
+            "metric": "STUB: multi-rank step loop on CPU tensors over gloo, nothing is computed or measured (--cpu-stub)" if stub else
+                      "poses/sec end-to-end (HRNet+PnP) at batch 256; keypoint/pose err vs ref",
             "value": round(total_frames / elapsed, 2), "unit": "poses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -424,6 +525,8 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        if stub:
+            line["stub_check"] = stub_check
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

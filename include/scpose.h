@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SCPOSE_ABI_VERSION 6
+#define SCPOSE_ABI_VERSION 7
 
 enum {
   SCPOSE_OK = 0,
@@ -266,6 +266,14 @@ int32_t scpose_pnp_epnp_ransac(const float* kp_xyc, const double* landmarks, con
                                int32_t max_iters, double reproj_err, double confidence,
                                double* rot, double* tvec, double* rvec, int32_t* status,
                                void* stream);
+/* (ABI 7) Same solve, one output: rows = device f64 N x 13, row i = [R (9, row-major), t (3), (double)status] of frame i --
+ * the record export_predicted_poses_real.py:224-226 builds per frame, laid out as the block a rank all-gathers (SURVEY.md
+ * section 8e) and copies to the host, so a step needs no assembly launches between the solve and the collective. */
+int32_t scpose_pnp_epnp_ransac_rows(const float* kp_xyc, const double* landmarks, const double* K,
+                                    const double* dist, int32_t n, int32_t j, double conf_thr0,
+                                    int32_t min_pts, double thr_decay, int32_t thr_iters,
+                                    int32_t max_iters, double reproj_err, double confidence,
+                                    double* rows, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Single-layer entry points (unit-level parity of the kernels the forward is made of).

@@ -46,8 +46,13 @@ def parse_args():
     parser.add_argument("--logDir", help="log directory", type=str, default="")
     parser.add_argument("--dataDir", help="data directory", type=str, default="")
     parser.add_argument("--prevModelDir", help="prev Model directory", type=str, default="")
-    parser.add_argument("--device_crop", action="store_true",
-                        help="(extension) warp the crops on the GPU (scpose_crop_warp) instead of in the data loader")
+    parser.add_argument("--device_crop", action="store_true", default=True,
+                        help="(extension, the default) warp the crops on the GPU (scpose_crop_warp): the loader only decodes the frames")
+    parser.add_argument("--host_crop", dest="device_crop", action="store_false",
+                        help="(extension) warp and normalise the crops in the data loader, as the reference does")
+    parser.add_argument("--log_metrics", action="store_true",
+                        help="(extension) compute the loss / PCK the reference logs per batch; they need the heat-maps, so the forward "
+                             "then writes them instead of handing key points out of its last kernel (same pred .mat, bit for bit)")
     return parser.parse_args()
 
 
@@ -81,10 +86,12 @@ def main():
     lo, hi = parallel.shard_range(len(valid_dataset), rank, ws)
     subset = torch.utils.data.Subset(valid_dataset, range(lo, hi)) if ws > 1 else valid_dataset
     valid_dataset.device_crop = bool(args.device_crop)
+    valid_dataset.want_target = bool(args.log_metrics)     # gaussian targets feed the logged loss / PCK only
     valid_loader = torch.utils.data.DataLoader(subset, batch_size=cfg.TEST.BATCH_SIZE_PER_GPU * len(cfg.GPUS),
                                                shuffle=False, num_workers=cfg.WORKERS, pin_memory=not args.device_crop,
                                                collate_fn=valid_dataset.collate_device_crop if args.device_crop else None)
-    validate(cfg, valid_loader, valid_dataset, model, criterion, final_output_dir, tb_log_dir, pred_file_name="pred_test")
+    validate(cfg, valid_loader, valid_dataset, model, criterion, final_output_dir, tb_log_dir, pred_file_name="pred_test",
+             log_metrics=bool(args.log_metrics))
 
 
 if __name__ == "__main__":

@@ -21,7 +21,7 @@ if os.environ.get("SCPOSE_DEV") == "1":
 
 DT_BF16, DT_F16 = 0, 1
 IN_F32_NCHW, IN_U8_NHWC = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class HrnetDesc(ctypes.Structure):
@@ -87,6 +87,8 @@ SYMBOLS = {
     "scpose_pnp_epnp_ransac": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_double,
                                          c_int32, c_double, c_int32, c_int32, c_double, c_double, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p]),
+    "scpose_pnp_epnp_ransac_rows": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_double,
+                                              c_int32, c_double, c_int32, c_int32, c_double, c_double, c_void_p, c_void_p]),
     "scpose_conv_create": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                      POINTER(c_void_p)]),
     "scpose_conv_destroy": (c_int32, [c_void_p]),

@@ -32,11 +32,25 @@ def dist_acc(dists, thr=0.5):
     return float((dists[valid] < thr).sum()) / n if n else -1
 
 
+def _max_preds_any(hm):
+    """get_max_preds for a NumPy array (the reference's call) or a torch tensor; a device tensor stays on the device for the
+    arg-max and only its (N, J, 2) coordinates come to the host (the reference -- and round 4 here -- copied the whole heat-map
+    tensor to the host for a number that is only logged, lib/core/function.py:376)."""
+    if isinstance(hm, np.ndarray):
+        return get_max_preds(hm)[0]
+    import torch
+    from .. import ops
+    t = hm.detach()
+    if not t.is_cuda:
+        t = t.to(torch.device("cuda", torch.cuda.current_device()))
+    return ops.max_preds(t.float().contiguous())[0].cpu().numpy()
+
+
 def accuracy(output, target, hm_type="gaussian", thr=0.5):
     if hm_type != "gaussian":
         raise ValueError("accuracy: only gaussian heat-maps are supported")
-    pred, _ = get_max_preds(output)
-    gt, _ = get_max_preds(target)
+    pred = _max_preds_any(output)
+    gt = _max_preds_any(target)
     n, j, h, w = output.shape
     scale = np.tile(np.array([h, w], dtype=np.float64) / 10.0, (n, 1))
     dists = _normalised_distances(pred, gt, scale)

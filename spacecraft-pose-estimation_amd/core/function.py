@@ -75,6 +75,11 @@ def _run(config, val_loader, val_dataset, models, criterion, output_dir, pred_fi
         m.eval()
     model = models[0]
     warned = False
+    # The fused path (models/pose_hrnet.py: forward_decode) whenever nothing downstream needs a heat-map: one model, no flip test,
+    # no loss / accuracy logging.  Same key points, bit for bit (tests/test_gpu_e2e.py).
+    fast = (len(models) == 1 and not flip_test and not (log_metrics and criterion is not None) and hasattr(model, "forward_decode"))
+    if fast:
+        logger.info("validate: fused forward -> key-point path (no heat-maps); pass log_metrics / a flip test to get the heat-map path")
     dev = torch.device("cuda", torch.cuda.current_device())
     dist = parallel.init() if parallel.world()[0] > 1 else None
     num_samples = len(val_dataset)
@@ -87,7 +92,13 @@ def _run(config, val_loader, val_dataset, models, criterion, output_dir, pred_fi
                 input = ops.crop_warp(input, meta["trans"].numpy(), (int(size[0]), int(size[1])), device=dev)
             else:
                 input = input.to(dev, non_blocking=True)
-            output = _last(model(input))
+            c = meta["center"].float()
+            s = meta["scale"].float()
+            if fast:   # key points straight from the network's last kernel: no heat-map is written, copied or re-read
+                xyc = model.forward_decode(input, c.to(dev, non_blocking=True), s.to(dev, non_blocking=True), bool(config.TEST.POST_PROCESS))
+                output = None
+            else:
+                output = _last(model(input))
             if len(models) > 1:       # ensemble mean (:530-536): sum in model order, one division by len(models)
                 output = output.clone()
                 for k, other in enumerate(models[1:], start=2):
@@ -97,7 +108,9 @@ def _run(config, val_loader, val_dataset, models, criterion, output_dir, pred_fi
                 # flip_back + SHIFT_HEATMAP + average (:354-366) in one device kernel, no D2H round trip
                 output = ops.flip_merge(output, out_f, val_dataset.flip_pairs, config.TEST.SHIFT_HEATMAP)
             num_images = input.size(0)
-            if log_metrics and criterion is not None and tuple(target.shape) != tuple(output.shape):
+            if fast:
+                pass
+            elif log_metrics and criterion is not None and tuple(target.shape) != tuple(output.shape):
                 if not warned:    # the reference would raise inside the loss here
                     logger.warning("MODEL.HEATMAP_SIZE targets %s do not match the model's heat-maps %s: loss / accuracy "
                                    "logging is skipped", tuple(target.shape[2:]), tuple(output.shape[2:]))
@@ -106,12 +119,11 @@ def _run(config, val_loader, val_dataset, models, criterion, output_dir, pred_fi
                 target_d = target.to(dev, non_blocking=True)
                 loss = criterion(output, target_d, target_weight.to(dev, non_blocking=True))
                 losses.update(loss.item(), num_images)
-                _, avg_acc, cnt, _ = accuracy(output.cpu().numpy(), target.numpy())
+                _, avg_acc, cnt, _ = accuracy(output, target_d)      # both arg-max passes on the device tensors
                 acc.update(avg_acc, cnt)
-            c = meta["center"].float()
-            s = meta["scale"].float()
             score = meta["score"].double() if torch.is_tensor(meta["score"]) else torch.tensor(meta["score"]).double()
-            xyc = get_final_preds_device(config, output, c.to(dev), s.to(dev))
+            if not fast:
+                xyc = get_final_preds_device(config, output, c.to(dev), s.to(dev))
             local_preds.append(xyc)
             boxes = torch.zeros((num_images, 6), dtype=torch.float64)
             boxes[:, 0:2] = c[:, 0:2].double(); boxes[:, 2:4] = s[:, 0:2].double()

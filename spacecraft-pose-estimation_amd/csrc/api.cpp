@@ -66,6 +66,18 @@ extern "C" int32_t scpose_pnp_epnp_ransac(const float* kp_xyc, const double* lan
                     static_cast<hipStream_t>(stream));
 }
 
+extern "C" int32_t scpose_pnp_epnp_ransac_rows(const float* kp_xyc, const double* landmarks, const double* K,
+                                               const double* dist, int32_t n, int32_t j, double conf_thr0,
+                                               int32_t min_pts, double thr_decay, int32_t thr_iters,
+                                               int32_t max_iters, double reproj_err, double confidence,
+                                               double* rows, void* stream) {
+  if (n == 0) return SCPOSE_OK;
+  SCP_REQUIRE(kp_xyc && landmarks && K && rows, "pnp_rows: null argument");
+  return pnp_launch(kp_xyc, landmarks, K, dist, n, j, conf_thr0, min_pts, thr_decay, thr_iters,
+                    max_iters, reproj_err, confidence, nullptr, nullptr, nullptr, nullptr,
+                    static_cast<hipStream_t>(stream), rows);
+}
+
 extern "C" int32_t scpose_conv_create(const float* weight, const float* bias, int32_t cout,
                                       int32_t cin, int32_t ksize, int32_t stride, int32_t dtype,
                                       scpose_conv_t* out) {

@@ -260,7 +260,7 @@ int32_t decode_launch(const float* hm, int N, int J, int H, int W, const float* 
 int32_t pnp_launch(const float* kp_xyc, const double* landmarks, const double* K,
                    const double* dist, int N, int J, double conf_thr0, int min_pts, double thr_decay,
                    int thr_iters, int max_iters, double reproj_err, double confidence, double* rot,
-                   double* tvec, double* rvec, int32_t* status, hipStream_t stream);
+                   double* tvec, double* rvec, int32_t* status, hipStream_t stream, double* rows = nullptr);
 
 // f32 -> 16-bit storage on the host (round to nearest even), matching the device casts.
 uint16_t host_f32_to_16(float f, int dtype);

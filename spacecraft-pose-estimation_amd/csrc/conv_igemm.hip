@@ -175,7 +175,10 @@ int32_t conv_upload(const float* w, const float* bias, int cout, int cin, int ks
     const int planes = cin / 8, ksteps = (planes + 3) / 4, cpad = (cout + 63) / 64 * 64;
     const size_t wb = (size_t)ksteps * 4 * cpad * 16;
     const bool ks_ok = (ksteps >= 1 && ksteps <= 4) || ksteps == 6 || ksteps == 8 || ksteps == 12;   // Cin = 32..128, 192, 256, 384
-    if (ks_ok && wb + (size_t)cpad * 4 <= 156 * 1024) {
+    // (the one-workgroup-per-CU variant -- more than 80 KB of LDS -- is built for k-step counts 6 / 8 / 12 only: shallower layers with
+    // that many weights, e.g. 128 -> 384, keep the conv_pipe path instead of launching a 2-per-CU variant past its LDS opt-in)
+    const size_t lds1 = wb + (size_t)cpad * 4;
+    if (ks_ok && lds1 <= (ksteps <= 4 ? 80 * 1024 : 156 * 1024)) {
       std::vector<uint16_t> h1(wb / 2);
       const size_t got = pack_conv_weights(w, cout, cin, 1, cpad, planes, dtype, h1.data(), nullptr, nullptr);
       SCP_REQUIRE(got == wb, "conv1x1: packed size %zu != %zu", got, wb);

@@ -88,7 +88,10 @@ static_assert(m48_wait(8, 0, true, true) == 7 && m48_wait(8, 7, true, true) == 1
 // M16 > 0 (round 4): the Cout block is M16 16-row blocks instead of MR 32-row ones -- M16 = 3 with C16 = 8: 48-row blocks on 3 x 8
 // accumulators per consumer wave (512-pixel tile groups), for the one stride-1 layer with 48 output channels and a deep K
 // (transition1: 256 -> 48), which the 64-row form ran with a quarter of its MFMAs on padding rows.
-template <int DT, int KS, int STRIDE, int MR, int NR, int WREG = 0, int C16 = 0, int M16 = 0>
+// ADDR: 0 = every tensor of the launch is buffer-addressed (< 4 GiB), 1 = 64-bit pointers, 2 = decided at run time (p.in_bytes).  The
+// 16x16x32-consumer variants are built for 0 and 1 separately: with both paths in one kernel the producers' stage loop is twice the
+// code and spills 70 SGPRs (round 5).
+template <int DT, int KS, int STRIDE, int MR, int NR, int WREG = 0, int C16 = 0, int M16 = 0, int ADDR = 2>
 __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename DtOf<DT>::type T;
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
 
     // Tensors below 4 GiB are addressed through buffer descriptors (conv_pipe_kernel.h: dma16_buf): per-item 32-bit
     // lane offsets, chunk / plane displacement in an SGPR, padding lanes out of range.  Larger ones keep 64-bit pointers.
-    const bool buf = p.in_bytes != 0;
+    const bool buf = ADDR == 2 ? p.in_bytes != 0 : ADDR == 0;
     const buf_rsrc_t rs_w = make_buf(p.wpk, (uint32_t)(p.n_mblk * p.nchunks * (int)chunk_wbytes));
     const buf_rsrc_t rs_in = make_buf(p.in, p.in_bytes), rs_res = make_buf(p.res ? p.res : p.out, p.out_bytes),
                      rs_out = make_buf(p.out, p.out_bytes);
@@ -972,14 +975,24 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
   }
 }
 
-template <int DT, int STRIDE, int MR, int NR, int WREG = 0, int C16 = 0, int M16 = 0>
-int32_t m32p_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
-  auto kern = conv_m32p_kernel<DT, 3, STRIDE, MR, NR, WREG, C16, M16>;
+template <int DT, int STRIDE, int MR, int NR, int WREG = 0, int C16 = 0, int M16 = 0, int ADDR = 2>
+int32_t m32p_launch_addr(const ConvLaunch& L, size_t lds, hipStream_t st) {
+  auto kern = conv_m32p_kernel<DT, 3, STRIDE, MR, NR, WREG, C16, M16, ADDR>;
   static LdsOptIn big_lds;   // per device (common.h)
   { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(kern), 160 * 1024, &big_lds); if (rc != SCPOSE_OK) return rc; }
   hipLaunchKernelGGL(kern, dim3(L.grid), dim3(512), lds, st, L);
   SCP_CHECK_HIP(hipGetLastError());
   return SCPOSE_OK;
+}
+
+template <int DT, int STRIDE, int MR, int NR, int WREG = 0, int C16 = 0, int M16 = 0>
+int32_t m32p_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
+  if constexpr (C16 != 0) {   // one addressing mode per kernel (see ADDR)
+    return L.in_bytes != 0 ? m32p_launch_addr<DT, STRIDE, MR, NR, WREG, C16, M16, 0>(L, lds, st)
+                           : m32p_launch_addr<DT, STRIDE, MR, NR, WREG, C16, M16, 1>(L, lds, st);
+  } else {
+    return m32p_launch_addr<DT, STRIDE, MR, NR, WREG, C16, M16, 2>(L, lds, st);
+  }
 }
 
 template <int DT>

@@ -194,8 +194,9 @@ __global__ __launch_bounds__(512, 2) void conv_s2r_kernel(const S2rLaunch p) {
     }
     // next tile landed (this wave's pieces) -- vmcnt(0): stores may retire before older loads, so a counted wait that
     // skips this tile's output stores would not guarantee the DMA has landed
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                          // ... and everybody is done with this buffer (LDS reads are consumed)
+    // (one asm statement with a memory clobber: the builtin barrier is IntrNoMem to the compiler, which may then hoist the next
+    // tile's ordinary LDS loads above it, into a buffer other waves' LDS-DMA is still filling -- conv_block2_kernel.h)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                          // ... and everybody is done with this buffer (LDS reads are consumed)
   }
 }
 
@@ -329,8 +330,9 @@ __global__ __launch_bounds__(768, 3) void conv_s2r12_kernel(const S2r12Launch p)
       store16_buf(rs_out, voff, 0u, __builtin_bit_cast(u32x4, ov));
     }
     // next tile landed (this wave's plane) -- vmcnt(0), not a counted wait: stores may retire before older loads
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                          // ... and everybody is done with this buffer
+    // (one asm statement with a memory clobber: the builtin barrier is IntrNoMem to the compiler, which may then hoist the next
+    // tile's ordinary LDS loads above it, into a buffer other waves' LDS-DMA is still filling -- conv_block2_kernel.h)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                          // ... and everybody is done with this buffer
   }
 }
 

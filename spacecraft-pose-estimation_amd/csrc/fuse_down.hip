@@ -276,8 +276,9 @@ __global__ __launch_bounds__(NW * 64, 2) void fuse_down_kernel(const FdLaunch p)
     // next tile landed (this wave's pieces).  vmcnt(0) also waits for this tile's stores; a counted wait that leaves them in
     // flight (the DMA was issued first) measured the same here and 1-2 % SLOWER in the fused BasicBlock and the producer/consumer
     // kernels (round 4), and round 2 saw sporadic wrong results with it in the stride-2 kernels
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                          // ... and everybody is done with this buffer (LDS reads are consumed)
+    // (one asm statement with a memory clobber: the builtin barrier is IntrNoMem to the compiler, which may then hoist the next
+    // tile's ordinary LDS loads above it, into a buffer other waves' LDS-DMA is still filling -- conv_block2_kernel.h)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                          // ... and everybody is done with this buffer (LDS reads are consumed)
   }
 }
 

@@ -490,7 +490,7 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
         // Branch 0 is read ONCE (fuse_down.hip): its fuse row and the first hop of every down path that starts from it are one
         // launch.  Two epochs instead of one: (A) lane 0: row 0's 1x1 up paths, then that launch; lanes 1..: everything of rows 1..
         // that does not depend on it -- their up paths and the down chains from branches 1..; (B) the remaining hops of the
-        // chains from branch 0 and the sums of rows 1.., row i's on lane i.
+        // chains from branch 0 and the sums of rows 1.., row i's on lane i - 1.
         std::vector<std::vector<int>> T(nb, std::vector<int>(nb, -1)), S(nb, std::vector<int>(nb, 0));
         std::vector<int> first;
         int y0 = -1;
@@ -520,7 +520,7 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
         outs.push_back(y0);
         B.parallel_begin(2);
         for (int i = 1; i < nb; ++i) {
-          B.lane = i;
+          B.lane = i - 1;   // row 1 on lane 0 (the stream the epoch is captured on): nb = 2 then forks nothing, nb = 3 / 4 one lane fewer
           const std::string fp = fmt("%s.fuse_layers.%d.0", mp.c_str(), i);
           int t = first[i - 1];
           for (int k = 1; k < i; ++k) {

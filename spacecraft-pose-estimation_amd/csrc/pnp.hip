@@ -43,6 +43,7 @@ struct PnpArgs {
   double* tvec;             // N x 3
   double* rvec;             // N x 3 or null
   int32_t* status;          // N
+  double* rows;             // N x 13 [R (9, row-major), t (3), status] or null: when set, the only output written (rot / tvec / status may be null)
   int N, J;
   double conf_thr0, thr_decay;
   int min_pts, thr_iters, max_iters;
@@ -1105,22 +1106,29 @@ __global__ __launch_bounds__(256) void pnp_kernel(const PnpArgs a) {
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     if (status > 0) rodrigues_vec2mat(rvec, R);
     else { rvec[0] = rvec[1] = rvec[2] = 0; tvec[0] = tvec[1] = tvec[2] = 0; }
-    for (int k = 0; k < 9; k++) a.rot[(size_t)frame * 9 + k] = R[k];
-    for (int k = 0; k < 3; k++) a.tvec[(size_t)frame * 3 + k] = tvec[k];
+    if (a.rows) {   // the block a rank all-gathers / copies to the host: one row per frame, no assembly launches
+      double* row = a.rows + (size_t)frame * 13;
+      for (int k = 0; k < 9; k++) row[k] = R[k];
+      for (int k = 0; k < 3; k++) row[9 + k] = tvec[k];
+      row[12] = (double)status;
+    } else {
+      for (int k = 0; k < 9; k++) a.rot[(size_t)frame * 9 + k] = R[k];
+      for (int k = 0; k < 3; k++) a.tvec[(size_t)frame * 3 + k] = tvec[k];
+      a.status[frame] = status;
+    }
     if (a.rvec) for (int k = 0; k < 3; k++) a.rvec[(size_t)frame * 3 + k] = rvec[k];
-    a.status[frame] = status;
   }
 }
 
 int32_t pnp_launch(const float* kp_xyc, const double* landmarks, const double* K, const double* dist,
                    int N, int J, double conf_thr0, int min_pts, double thr_decay, int thr_iters,
                    int max_iters, double reproj_err, double confidence, double* rot, double* tvec,
-                   double* rvec, int32_t* status, hipStream_t stream) {
+                   double* rvec, int32_t* status, hipStream_t stream, double* rows) {
   SCP_REQUIRE(J >= 1 && J <= kMaxJ, "pnp: J=%d landmarks (1..%d)", J, kMaxJ);
   SCP_REQUIRE(confidence > 0 && confidence < 1, "pnp: confidence %g must be in (0,1)", confidence);
   SCP_REQUIRE(N >= 0, "pnp: N=%d", N);
   if (N == 0) return SCPOSE_OK;
-  PnpArgs a{kp_xyc, landmarks, K, dist, rot, tvec, rvec, status, N, J, conf_thr0, thr_decay, min_pts, thr_iters,
+  PnpArgs a{kp_xyc, landmarks, K, dist, rot, tvec, rvec, status, rows, N, J, conf_thr0, thr_decay, min_pts, thr_iters,
             max_iters, reproj_err, confidence, 0};
   { static const char* e = dev_env("SCPOSE_PNP_SPEC"); a.dbg_no_spec = (kDevBuild && e && atoi(e) == 0) ? 1 : 0; }
   // 36 864 B of work matrices + 72 B per landmark and frame (37 656 B at J = 11).  Two frames per workgroup: measured alone

@@ -56,6 +56,7 @@ class JointsDataset(Dataset):
         self.transform = transform
         self.numpy_transform = numpy_transform
         self.device_crop = False   # True: hand whole frames to the GPU crop kernel instead of warping here
+        self.want_target = True    # False: skip generate_target (the maps feed only the loss / PCK that validate() logs)
         self.db = []
 
     def _get_db(self):
@@ -95,7 +96,11 @@ class JointsDataset(Dataset):
         for i in range(self.num_joints):
             if joints_vis[i, 0] > 0.0:
                 joints[i, 0:2] = affine_transform(joints[i, 0:2], trans)
-        target, target_weight = self.generate_target(joints, joints_vis)
+        if self.want_target:
+            target, target_weight = self.generate_target(joints, joints_vis)
+        else:
+            target = np.zeros((self.num_joints, 1, 1), dtype=np.float32)
+            target_weight = np.asarray(joints_vis[:, 0:1], dtype=np.float32).copy()
         meta = {"image": image_file, "filename": db_rec.get("filename", ""), "imgnum": db_rec.get("imgnum", ""),
                 "joints": joints, "joints_vis": joints_vis, "center": c, "scale": s, "rotation": r, "score": score}
         if self.device_crop:

@@ -158,6 +158,34 @@ class PoseHighResolutionNet(nn.Module):
             raise ops.nat.NativeError("pose_hrnet.forward needs a ROCm device tensor: there is no CPU fallback")
         return self._get_engine(x.device)(x)
 
+    def forward_decode(self, x, center, scale, post_process=True):
+        """Key points (N, J, 3) [x_img, y_img, maxval] straight from the network (scpose_hrnet_forward_decode): for pose_hrnet with a
+        1x1 final layer the last fuse row, final_layer and get_final_preds (lib/core/inference.py:49-79) are one kernel and no
+        heat-map is written; bit-identical to get_final_preds_device(cfg, self(x), center, scale).  Batches of one shape replay a
+        captured hipGraph of the forward (concurrent branches), bound to buffers owned by the module; a batch of another shape
+        (the last, ragged one of a data set) runs the same launches eagerly."""
+        if self.training:
+            raise RuntimeError("the MI355X pose_hrnet is inference-only: call .eval() (training is out of scope)")
+        if not x.is_cuda:
+            raise ops.nat.NativeError("pose_hrnet.forward_decode needs a ROCm device tensor: there is no CPU fallback")
+        eng = self._get_engine(x.device)
+        x = x.contiguous() if x.dtype == torch.uint8 else x.float().contiguous()
+        center = center.to(x.device, torch.float32).contiguous(); scale = scale.to(x.device, torch.float32).contiguous()
+        key = (tuple(x.shape), x.dtype, bool(post_process), id(eng))
+        g = getattr(self, "_fast_graph", None)
+        if g is None or g[0] != key:
+            seen = getattr(self, "_fast_seen", None)
+            self._fast_seen = key
+            if seen != key:          # first batch of this shape: eager (a shape seen once is not worth a capture)
+                return eng.forward_decode(x, center, scale, post_process)
+            if g is not None:
+                g[1].close()
+            bx, bc, bs = x.clone(), center.clone(), scale.clone()
+            g = self._fast_graph = (key, eng.capture_decode(bx, bc, bs, post_process, concurrent=True), bx, bc, bs)
+        _, graph, bx, bc, bs = g
+        bx.copy_(x); bc.copy_(center); bs.copy_(scale)
+        return graph.replay().clone()
+
     def init_weights(self, pretrained=""):
         raise RuntimeError("init_weights: training-time initialisation is out of scope; load a checkpoint instead")
 

@@ -202,9 +202,11 @@ def heatmap_accumulate(acc, x, div=1.0):
 
 # ------------------------------------------------------------------ PnP
 def pnp_epnp_ransac(kp_xyc, landmarks, K, dist, conf_thr0=0.95, min_pts=15, thr_decay=0.8, thr_iters=100,
-                    max_iters=10000, reproj_err=15.0, confidence=0.99, want_rvec=False):
+                    max_iters=10000, reproj_err=15.0, confidence=0.99, want_rvec=False, rows=None):
     """kp_xyc (N,J,3) f32 device; landmarks (J,3), K (3,3), dist (5,) f64 device.
-    Returns rot (N,3,3) f64, tvec (N,3) f64, status (N,) i32 [, rvec (N,3)]."""
+    Returns rot (N,3,3) f64, tvec (N,3) f64, status (N,) i32 [, rvec (N,3)].
+    rows: a contiguous (N,13) f64 device buffer -> the kernel writes [R (9), t (3), status] per frame straight into it
+    (scpose_pnp_epnp_ransac_rows) and `rows` is returned: the block a rank all-gathers and copies to the host."""
     _need_cuda(kp_xyc, landmarks, K, dist)
     kp = kp_xyc.contiguous().float()
     n, j, _ = kp.shape
@@ -222,6 +224,13 @@ def pnp_epnp_ransac(kp_xyc, landmarks, K, dist, conf_thr0=0.95, min_pts=15, thr_
         dd = torch.cat([dd, torch.zeros(1, dtype=torch.float64, device=dd.device)])
     elif dd.numel() != 5:
         raise nat.NativeError("pnp_epnp_ransac: %d distortion coefficients; supported are 4 or 5 (k1,k2,p1,p2[,k3])" % dd.numel())
+    if rows is not None:
+        if tuple(rows.shape) != (n, 13) or rows.dtype != torch.float64 or not rows.is_contiguous() or rows.device != dev:
+            raise nat.NativeError("pnp_epnp_ransac: rows must be a contiguous float64 (%d, 13) tensor on %s" % (n, dev))
+        nat.check(nat.lib().scpose_pnp_epnp_ransac_rows(_ptr(kp), _ptr(lm), _ptr(Kd), _ptr(dd), n, j, conf_thr0, min_pts, thr_decay,
+                                                        thr_iters, max_iters, reproj_err, confidence, _ptr(rows), _stream()),
+                  "pnp_epnp_ransac_rows")
+        return rows
     rot = torch.empty((n, 3, 3), dtype=torch.float64, device=dev)
     tv = torch.empty((n, 3), dtype=torch.float64, device=dev)
     rv = torch.empty((n, 3), dtype=torch.float64, device=dev)

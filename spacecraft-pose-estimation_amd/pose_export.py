@@ -37,10 +37,10 @@ def solve_poses(preds, landmarks, K, dist, device=None, **kw):
     n = preds.shape[0]
     lo, hi = parallel.shard_range(n, rank, ws)
     kp = torch.from_numpy(np.ascontiguousarray(preds[lo:hi], dtype=np.float32)).to(dev)
-    rot, tv, st = ops.pnp_epnp_ransac(kp, torch.from_numpy(np.asarray(landmarks, dtype=np.float64)).to(dev),
-                                      torch.from_numpy(np.asarray(K, dtype=np.float64)).to(dev),
-                                      torch.from_numpy(np.asarray(dist, dtype=np.float64)).to(dev), **kw)
-    block = torch.cat([rot.reshape(-1, 9), tv, st.double().unsqueeze(1)], 1)
+    block = torch.empty((hi - lo, 13), dtype=torch.float64, device=dev)     # [R (9), t (3), status] rows, written by the kernel itself
+    ops.pnp_epnp_ransac(kp, torch.from_numpy(np.asarray(landmarks, dtype=np.float64)).to(dev),
+                        torch.from_numpy(np.asarray(K, dtype=np.float64)).to(dev),
+                        torch.from_numpy(np.asarray(dist, dtype=np.float64)).to(dev), rows=block, **kw)
     block = parallel.gather_rows(block, n, dist_pg).cpu().numpy()
     return block[:, :9].reshape(-1, 3, 3), block[:, 9:12], block[:, 12].astype(np.int32)
 

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(nat):
     lib = nat.lib()
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.scpose_abi_version() == nat.ABI_VERSION == 6
+    assert lib.scpose_abi_version() == nat.ABI_VERSION == 7
 
 
 def test_signatures_have_no_torch_types():

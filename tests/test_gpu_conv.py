@@ -76,6 +76,12 @@ CASES = [
     (48, 64, 3, 2, 24, 24, 2, False, True),
     (96, 96, 3, 2, 20, 12, 2, False, False),
     (64, 96, 3, 2, 16, 16, 1, False, True),
+    # streaming 1x1 kernel, one workgroup per CU (more than 80 KB of weights in LDS: built for 6 / 8 / 12 k-steps); and a shallow layer with
+    # that many weights, which must fall back to conv_pipe instead of launching a two-per-CU variant past its LDS opt-in
+    (384, 192, 1, 1, 12, 12, 3, False, False),
+    (384, 96, 1, 1, 12, 12, 3, True, True),
+    (128, 384, 1, 1, 10, 10, 2, False, True),
+    (128, 512, 1, 1, 6, 6, 2, True, False),
 ]
 
 

@@ -213,14 +213,26 @@ def test_cli_tools_test_and_pose_export(pk, tmp_path):
     rel = np.abs(preds[:, :, 2] - ref[:, :, 2]).max() / np.abs(ref[:, :, 2]).max()
     assert rel < 5e-2, "maxvals of the CLI run deviate %.3g from the fp32 oracle" % rel
 
-    # the same run with the crops warped on the GPU (scpose_crop_warp): identical crops -> identical predictions
-    out2 = tmp_path / "out_dc"
-    cmd2 = cmd[:2] + ["--device_crop"] + cmd[2:]
-    cmd2[cmd2.index("OUTPUT_DIR") + 1] = str(out2)
-    r = subprocess.run(cmd2, cwd=os.path.join(ROOT, "landmark_regression"), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    preds_dc = loadmat(out2 / "EventsDataset" / "pose_hrnet" / "w32_256" / "pred_test.mat")["preds"]
-    assert np.array_equal(preds_dc, preds)
+    # What the CLI does by default (round 5): crops warped on the GPU (scpose_crop_warp) and key points straight out of the network's
+    # last kernel (no heat-map).  The reference's data flow -- crops warped and normalised in the loader, heat-maps written, loss /
+    # PCK logged, get_final_preds on the heat-maps -- is --host_crop --log_metrics.  Every combination must give the same pred .mat,
+    # bit for bit; so must a batch size of 2, whose second and third batch replay the captured forward (models/pose_hrnet.py).
+    def run(tag, flags, batch="4"):
+        o = tmp_path / ("out_" + tag)
+        c2 = cmd[:2] + flags + cmd[2:]
+        c2[c2.index("OUTPUT_DIR") + 1] = str(o)
+        c2[c2.index("TEST.BATCH_SIZE_PER_GPU") + 1] = batch
+        r2 = subprocess.run(c2, cwd=os.path.join(ROOT, "landmark_regression"), capture_output=True, text=True, timeout=600)
+        assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
+        return loadmat(o / "EventsDataset" / "pose_hrnet" / "w32_256" / "pred_test.mat")["preds"], r2.stdout + r2.stderr
+    assert "fused forward -> key-point path" in r.stdout + r.stderr                  # the default run above took the fused path
+    for tag, flags, batch in (("ref_flow", ["--host_crop", "--log_metrics"], "4"), ("dev_crop_heatmaps", ["--log_metrics"], "4"),
+                              ("host_crop_fused", ["--host_crop"], "4"), ("graph_replay", [], "2"), ("legacy_flag", ["--device_crop"], "4")):
+        preds_v, log = run(tag, flags, batch)
+        assert np.array_equal(preds_v, preds), tag
+        assert ("fused forward -> key-point path" in log) == ("--log_metrics" not in flags), tag
+        if "--log_metrics" in flags:
+            assert "Accuracy" in log and "Loss" in log
 
     # stage 3 on known-answer keypoints written in the same .mat format
     kp, Rs, ts = P.synth_keypoints(6, np.random.default_rng(4), 0.5, 0.0)

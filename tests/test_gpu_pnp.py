@@ -153,3 +153,21 @@ def test_pnp_filter_and_projection_against_the_reference_camera_fixture(gpu_ops,
     assert P.rot_angle(rot[ok], Rs[ok]).max() < 2e-5
     assert (np.linalg.norm(tv[ok] - ts[ok], axis=1) / np.linalg.norm(ts[ok], axis=1)).max() < 2e-5
     _check((rot, tv, st, None), P.solve_batch(kp, landmarks=lm))
+
+
+def test_pnp_rows_entry_point_writes_the_gather_block(gpu_ops):
+    """scpose_pnp_epnp_ransac_rows (ABI 7): the same solve, written as one (N, 13) [R, t, status] row per frame -- bit-identical
+    to the three-output entry point, failures (identity / zero / negative status) included."""
+    rng = np.random.default_rng(77)
+    kp, _, _ = P.synth_keypoints(64, rng, 1.0, 0.2)
+    kp[3, :, 2] = 0.0; kp[9, 4:, 2] = -1.0          # a frame with no usable landmark, one with exactly four
+    rot, tv, st, _ = _gpu(gpu_ops, kp)
+    rows = torch.full((64, 13), float("nan"), dtype=torch.float64, device="cuda")
+    out = gpu_ops.pnp_epnp_ransac(torch.from_numpy(kp).cuda(), torch.from_numpy(P.LANDMARKS).cuda(), torch.from_numpy(P.CAMERA_K).cuda(),
+                                  torch.from_numpy(P.CAMERA_DIST).cuda(), rows=rows)
+    assert out is rows
+    r = rows.cpu().numpy()
+    assert np.array_equal(r[:, :9], rot.reshape(64, 9)) and np.array_equal(r[:, 9:12], tv) and np.array_equal(r[:, 12], st.astype(np.float64))
+    with pytest.raises(gpu_ops.nat.NativeError, match="rows"):
+        gpu_ops.pnp_epnp_ransac(torch.from_numpy(kp).cuda(), torch.from_numpy(P.LANDMARKS).cuda(), torch.from_numpy(P.CAMERA_K).cuda(),
+                                torch.from_numpy(P.CAMERA_DIST).cuda(), rows=torch.zeros(64, 12, dtype=torch.float64, device="cuda"))

@@ -86,3 +86,33 @@ def test_spawn_local_ranks_runs_the_bench_exchange(tmp_path, capfd):
     env = dict(os.environ, FAIL_RANK="1")
     rc = par.spawn_local_ranks([sys.executable, str(script)], 2, env=env, timeout=240)
     assert rc != 0
+
+
+def _stub_line(out):
+    import json
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one rank prints: %r" % out[-500:]
+    return json.loads(lines[0])
+
+
+def test_bench_step_loop_two_ranks_over_gloo(capfd):
+    """bench.py's OWN multi-rank step loop (`--cpu-stub`: CPU tensors, gloo, a stand-in engine and PnP): rank 1 without host buffers,
+    the double-buffered blocks, all_gather_into_tensor into `gathered`, barrier + all_reduce(MAX) timing, the roofline pass on every
+    rank, rank 0 alone printing one JSON line whose rows carry every rank's own frames at its place (stub_check) -- so the first real
+    multi-GPU run is not the first execution of that code.  Both launch modes: `bench.py --gpus 2` starting its
+    ranks itself (parallel.spawn_local_ranks, file-store rendezvous) and the driver's torch.distributed.run."""
+    import subprocess
+    args = ["--cpu-stub", "--gpus", "2", "--image", "32", "--batch", "16", "--steps", "4", "--warmup", "2"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SCPOSE_RDZV_FILE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=300, env=env, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _stub_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["config"]["frames_per_step"] == 32 and line["poses_total"] == 32 and line["poses_ok"] == 32
+    assert line["stub_check"] is True and line["steps"] == 4 and line["metric"].startswith("STUB")
+    assert line["ms_per_step"] > 0 and line["roofline"]["profiled_steps"] >= 1
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args,
+                       capture_output=True, text=True, timeout=300, env=env, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _stub_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["stub_check"] is True and line["poses_ok"] == 32

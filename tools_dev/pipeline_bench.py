@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Files -> poses throughput of the PRODUCT path: synthetic full-size frames on disk -> EventsDataset ->
+validate() (GPU crop warp, fused forward -> key points) -> pred.mat -> pose_export.export() (batched EPnP+RANSAC) ->
+opencv_poses.json, i.e. what `evaluate_pipeline.py` runs per scene (reference :69-91), timed stage by stage in one process --
+beside the reference-style loader (crops warped and normalised on the host, WORKERS: 0 as events-config.yaml:10 has it).
+
+    python bench.py --pipeline [--pipeline-frames 512] [--pipeline-workers 8] [--batch 64]
+    python tools_dev/pipeline_bench.py --frames 512 --workers 8 --batch 64 --model w48
+
+Prints one JSON line.  Frames: 1920 x 1200 JPEG (SPEED+ geometry: speed_plus_utils/camera.json), a smooth background with the
+eleven landmarks of a seeded pose drawn as blobs; 64 distinct files, listed `frames / 64` times each in the COCO dict.  Weights
+are random (the numbers are throughput, not accuracy).  Nothing here imports oracle/."""
+import argparse
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def make_scene(root, nframes, syn, np, unique=64, size=(1920, 1200), fmt="jpg"):
+    from PIL import Image
+    os.makedirs(os.path.join(root, "frames"), exist_ok=True)
+    os.makedirs(os.path.join(root, "data"), exist_ok=True)
+    rng = np.random.default_rng(5)
+    kp, _, _ = syn.keypoints(unique, rng, noise_px=0.0)
+    yy, xx = np.mgrid[0:size[1], 0:size[0]].astype(np.float32)
+    boxes = []
+    for i in range(unique):
+        img = (40 + 30 * np.sin(xx / 300.0 + i) + 20 * np.cos(yy / 200.0)).astype(np.float32)
+        for (u, v, _c) in kp[i]:
+            x0, x1 = int(max(u - 12, 0)), int(min(u + 13, size[0])); y0, y1 = int(max(v - 12, 0)), int(min(v + 13, size[1]))
+            if x1 > x0 and y1 > y0:
+                img[y0:y1, x0:x1] += 180 * np.exp(-((xx[y0:y1, x0:x1] - u) ** 2 + (yy[y0:y1, x0:x1] - v) ** 2) / 32.0)
+        rgb = np.clip(np.stack([img, img * 0.95, img * 0.9], 2), 0, 255).astype(np.uint8)
+        Image.fromarray(rgb).save(os.path.join(root, "frames", "f%03d.%s" % (i, fmt)), quality=90)
+        lo = kp[i, :, :2].min(0) - 40; hi = kp[i, :, :2].max(0) + 40
+        boxes.append([float(lo[0]), float(lo[1]), float(hi[0] - lo[0]), float(hi[1] - lo[1])])
+    images, anns = [], []
+    for k in range(nframes):
+        i = k % unique
+        images.append({"id": k + 1, "file_name": "f%03d.%s" % (i, fmt), "width": size[0], "height": size[1]})
+        anns.append({"image_id": k + 1, "bbox": boxes[i], "keypoints": [2.0] * 33, "id": k, "category_id": 1})
+    with open(os.path.join(root, "data", "real_test.json"), "w") as f:
+        json.dump({"images": images, "annotations": anns}, f)
+    with open(os.path.join(root, "landmarks.csv"), "w") as f:
+        f.write("x,y,z\n" + "\n".join(",".join(repr(float(v)) for v in r) for r in syn.TANGO_LANDMARKS))
+    with open(os.path.join(root, "calib.json"), "w") as f:
+        json.dump({"intrinsics": {"camera_matrix": syn.SPEEDPLUS_K.tolist(), "distortion_coefficients": syn.SPEEDPLUS_DIST.tolist()}}, f)
+    return sum(os.path.getsize(os.path.join(root, "frames", n)) for n in os.listdir(os.path.join(root, "frames"))) / unique
+
+
+def run(frames=512, workers=8, batch=64, model="w48", keep=None):
+    import numpy as np
+    import torch
+    import torch.utils.data
+    import scpose  # noqa: F401
+    from importlib import import_module
+    P = "spacecraft-pose-estimation_amd"
+    syn = import_module(P + ".synthetic"); config_mod = import_module(P + ".config"); models = import_module(P + ".models")
+    dataset = import_module(P + ".dataset"); transforms = import_module(P + ".utils.transforms")
+    function = import_module(P + ".core.function"); pose_export = import_module(P + ".pose_export")
+    if not torch.cuda.is_available():
+        raise SystemExit("pipeline bench needs a ROCm GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(0)
+    root = keep or tempfile.mkdtemp(prefix="scpose_pipeline_")
+    t0 = time.perf_counter()
+    mean_bytes = make_scene(root, frames, syn, np)
+    t_gen = time.perf_counter() - t0
+    image = 384 if model == "w48" else 256
+    yaml_path = os.path.join(ROOT, "landmark_regression", "experiments", "bench", "w48_384.yaml" if model == "w48" else "w32_256.yaml")
+    cfg = config_mod._defaults()
+    opts = ["OUTPUT_DIR", os.path.join(root, "out"), "LOG_DIR", os.path.join(root, "log"), "DATA_DIR", os.path.join(root, "frames"),
+            "DATASET.ROOT", os.path.join(root, "data"), "DATASET.TEST_SET", "test", "MODEL.NUM_JOINTS", "11",
+            "TEST.BATCH_SIZE_PER_GPU", str(batch), "PRINT_FREQ", "100000"]
+    config_mod.update_config(cfg, types.SimpleNamespace(cfg=yaml_path, opts=opts, modelDir="", logDir="", dataDir=""))
+    net = getattr(models, cfg.MODEL.NAME).get_pose_net(cfg, is_train=False)
+    net.load_state_dict(syn.random_checkpoint(syn.hrnet_cfg(48 if model == "w48" else 32, 11, image), seed=0), strict=False)
+    net = net.cuda().eval()
+    tf = transforms.Compose([transforms.ToTensor(), transforms.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])])
+
+    def loader(device_crop, nworkers, want_target):
+        ds = getattr(dataset, cfg.DATASET.DATASET)(cfg, cfg.DATASET.ROOT, cfg.DATA_DIR, cfg.DATASET.TEST_SET, False, tf)
+        ds.device_crop = device_crop; ds.want_target = want_target
+        return ds, torch.utils.data.DataLoader(ds, batch_size=batch, shuffle=False, num_workers=nworkers, pin_memory=not device_crop,
+                                               collate_fn=ds.collate_device_crop if device_crop else None)
+
+    def time_loader(device_crop, nworkers, want_target, limit):
+        ds, ld = loader(device_crop, nworkers, want_target)
+        n, t = 0, time.perf_counter()
+        for b in ld:
+            n += len(b[3]["image"])
+            if n >= limit:
+                break
+        return n / (time.perf_counter() - t)
+
+    out = {"frames": frames, "frame": "1920x1200 JPEG q90, %.0f KB mean" % (mean_bytes / 1e3), "batch": batch, "model": model,
+           "host_cores": os.cpu_count(), "workers": workers, "scene_generation_s": round(t_gen, 1)}
+    # ---- loaders alone (no GPU work): what feeds the path ----
+    small = min(frames, 4 * batch)
+    out["loader_fps"] = {
+        "reference_style_host_crop_workers0": round(time_loader(False, 0, True, min(small, 64)), 1),      # events-config.yaml:10 (WORKERS: 0), crops + targets on the host
+        "host_crop_workers%d" % workers: round(time_loader(False, workers, True, small), 1),
+        "decode_only_workers0": round(time_loader(True, 0, False, min(small, 64)), 1),                    # product default: the loader only decodes
+        "decode_only_workers%d" % workers: round(time_loader(True, workers, False, frames), 1)}
+    # ---- product path, files -> pred.mat -> opencv_poses.json ----
+    crit = None
+    final = os.path.join(root, "out_final"); os.makedirs(final, exist_ok=True)
+    stages = {}
+    for tag, dc, nw in (("product_device_crop_workers%d" % workers, True, workers), ("product_device_crop_workers0", True, 0)):
+        ds, ld = loader(dc, nw, False)
+        # warm-up on one batch (engine build, graph capture are one-off costs of a process, like the reference's model load)
+        it = iter(ld); first = next(it); del it
+        size = cfg.MODEL.IMAGE_SIZE
+        import_module(P + ".ops")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        function.validate(cfg, ld, ds, net, crit, final, final, pred_file_name="pred_test", log_metrics=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pose_export.export(os.path.join(root, "frames"), os.path.join(root, "data", "real_test.json"), os.path.join(final, "pred_test.mat"),
+                           os.path.join(root, "landmarks.csv"), os.path.join(root, "calib.json"), os.path.join(root, "poses"), overlay=False)
+        t2 = time.perf_counter()
+        stages[tag] = {"files_to_pred_mat_fps": round(frames / (t1 - t0), 1), "pred_mat_to_poses_json_fps": round(frames / (t2 - t1), 1),
+                       "files_to_poses_fps": round(frames / (t2 - t0), 1)}
+    out["pipeline"] = stages
+    # ---- the GPU part alone on resident crops of the same shape (what bench.py's headline measures, at this batch size) ----
+    u8 = torch.randint(0, 256, (batch, image, image, 3), dtype=torch.uint8, device="cuda")
+    c = torch.full((batch, 2), image / 2.0, device="cuda"); s = torch.full((batch, 2), image / 200.0 * 1.5, device="cuda")
+    for _ in range(3):
+        net.forward_decode(u8, c, s, True)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        net.forward_decode(u8, c, s, True)
+    torch.cuda.synchronize()
+    out["gpu_forward_decode_fps_resident_crops"] = round(10 * batch / (time.perf_counter() - t0), 1)
+    if keep is None:
+        shutil.rmtree(root, ignore_errors=True)
+    return out
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=512)
+    ap.add_argument("--workers", type=int, default=min(8, os.cpu_count() or 1))
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--model", default="w48", choices=["w48", "w32"])
+    ap.add_argument("--keep", default=None, help="directory to build the scene in (kept)")
+    a = ap.parse_args(argv)
+    res = run(a.frames, a.workers, a.batch, a.model, a.keep)
+    print(json.dumps({"metric": "frames/sec files -> poses (product CLI path)", "unit": "frames/s", **res}))
+
+
+if __name__ == "__main__":
+    main()
