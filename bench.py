@@ -96,6 +96,9 @@ def parse():
                     help="side line: the small FITTED HRNet of tests/golden/chain_checkpoint.npz on synthetic landmark frames (128x128 crops "
                          "whose content determines the key points), PnP chained to the decoded key points; reports the pose error against "
                          "the generating poses.  The only configuration whose heat-maps carry a pose (VERDICT r3 #3)")
+    ap.add_argument("--fitted-w48", action="store_true",
+                    help="like --fitted, but HRNet-W48 384x384 (the headline geometry) on the constructed peaked-heat-map checkpoint "
+                         "synthetic.w48_chain_checkpoint instead of the small fitted W16 / 128 network; reports the pose error at the chosen batch")
     ap.add_argument("--pipeline", action="store_true",
                     help="side line: files -> poses through the product CLI path (synthetic 1920x1200 JPEG frames on disk -> data loader -> "
                          "validate() -> pred.mat -> export -> opencv_poses.json), frames/s per stage beside the reference-style host loader "
@@ -228,6 +231,8 @@ def main():
         return
     if args.events:
         args.model, args.dtype = "w32", "f16"
+    if args.fitted_w48:
+        args.fitted, args.model = True, "w48"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # stand-alone multi-GPU launch: this parent never touches the GPU -- the device count comes from the KFD
         # topology in sysfs, not from torch.cuda.device_count() (which can go through hipGetDeviceCount on ROCm)
@@ -268,7 +273,14 @@ def main():
 
     image = args.image or (IMAGE if args.model == "w48" else 256)
     chain = None
-    if args.fitted:
+    if args.fitted_w48:
+        # the headline geometry with a checkpoint whose heat-maps carry a pose: the CONSTRUCTED W48 checkpoint (synthetic.w48_chain_checkpoint)
+        image = 384
+        cfg = syn.w48_chain_cfg(image)
+        sd = syn.w48_chain_checkpoint(0)
+        chain = syn.landmark_frames(args.batch, np.random.default_rng(3000 + rank), image, blob_sigma=syn.W48_CHAIN_BLOB_SIGMA)
+        args.chained = True
+    elif args.fitted:
         image = 128
         cfg = syn.chain_cfg(image)
         sd = syn.load_chain_checkpoint(os.path.join(ROOT, "tests", "golden", "chain_checkpoint.npz"))
@@ -505,7 +517,7 @@ def main():
             "config": {"workload": "%sHRNet-%s %dx%d %d joints, batch %d per GPU + batched EPnP-RANSAC HIP kernel%s%s" % (
                            "BASELINE configs[4] side line: mixed RGB + event-frame batch, " if args.events else
                            "side line: fitted chain checkpoint on synthetic landmark frames, " if args.fitted else "",
-                           "W16-chain" if args.fitted else args.model.upper(), image, image, JOINTS, B, " (PnP chained to decoded keypoints)" if args.chained else "",
+                           "W48-chain (constructed checkpoint)" if (args.fitted and image == 384) else "W16-chain" if args.fitted else args.model.upper(), image, image, JOINTS, B, " (PnP chained to decoded keypoints)" if args.chained else "",
                            "; %d frames per step frame-sharded over %d GPUs%s" % (world * B, world, " = BASELINE configs[3]" if world * B == 2048 and world == 8 else "") if world > 1 else ""),
                        "frames_per_step": world * B, "parallelism": "frame-sharded x%d, all-gather of (R,t,status); PnP/gather/D2H of step i overlap the forward of step i+1" % world,
                        "pnp_input": "decoded" if args.chained else "synthetic projected landmarks, 1 px noise, 10% outliers",

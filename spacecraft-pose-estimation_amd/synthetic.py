@@ -231,3 +231,98 @@ def load_chain_checkpoint(path):
         a = z[k]
         sd[k[3:]] = torch.from_numpy(a.astype(np.int64)) if a.dtype.kind in "iu" else torch.from_numpy(a.astype(np.float32))
     return sd
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# A CONSTRUCTED HRNet-W48 384 x 384 checkpoint whose heat-maps are peaked (the headline geometry of BASELINE.json: fitting all
+# 63.6 M parameters of that network on host cores is out of reach, so the weights are written down instead of trained).
+# ---------------------------------------------------------------------------------------------------------------------------
+W48_CHAIN_BLOB_SIGMA = 7.5      # crop pixels at 384 x 384 (1.9 heat-map pixels), the blobs landmark_frames draws for this checkpoint
+W48_CHAIN_EPS = 0.02
+
+
+def w48_chain_cfg(image=384):
+    return hrnet_cfg(48, 11, image)
+
+
+def w48_chain_checkpoint(seed=0, eps=W48_CHAIN_EPS):
+    """state_dict of w48_chain_cfg(): random_checkpoint(seed) with the branch-0 path turned into "detect the landmark colours,
+    then carry the eleven maps to final_layer", every residual / cross-branch path kept RANDOM but scaled by `eps`:
+
+      * conv1 + bn1 + ReLU (3 -> 64, stride 2): 18 units P = relu(v_c - a_l), N = relu(a_l - v_c) of the [1 2 1] x [1 2 1] / 16 blurred
+        colour v (c = r, g, b; a_l = the three levels a landmark colour's component takes at a blob centre), the other 46 random * eps;
+      * conv2 + bn2 + ReLU (64 -> 64, stride 2): units 0..10 = relu(1 - sum_c |v_c - a_jc| / r_j) = relu(1 - sum_c (P + N) / r_j), an L1
+        bump around landmark j's colour (r_j below the distance to the nearest other colour), again through the blur kernel; the
+        rest random * eps.  A map peaks where its blob is brightest, and falls monotonically with the blob's gaussian;
+      * layer1.0.downsample, transition1.0: identity on the leading channels (+ eps * random); the last BatchNorm of every Bottleneck
+        and of every BasicBlock of branch 0, and of every fuse up-path into branch 0: gamma, beta * eps -- so a block is
+        relu(x + eps * f(x)) with f the random-init function of random_checkpoint; branches 1-3 stay O(1) random;
+      * final_layer: identity on channels 0..10 (+ eps * random), zero bias.
+
+    So every kernel of the forward computes on real data, the eleven heat-maps are narrow peaks (~0.9) on a near-zero floor with
+    margins far above 16-bit rounding noise, and the key points of lib/core/inference.get_final_preds are the drawn landmark
+    positions.  Deterministic in `seed` (the fixture tests/golden/chain_w48_reference.npz stores the seed, not 127 MB of weights)."""
+    cfg = w48_chain_cfg()
+    sd = random_checkpoint(cfg, seed)
+    mean = np.array([0.485, 0.456, 0.406]); std = np.array([0.229, 0.224, 0.225])
+    blur = torch.tensor([[1.0, 2.0, 1.0], [2.0, 4.0, 2.0], [1.0, 2.0, 1.0]]) / 16.0
+    att = W48_CHAIN_BLOB_SIGMA ** 2 / (W48_CHAIN_BLOB_SIGMA ** 2 + 0.5 + 2.0)      # peak attenuation by the two blurs (variances 0.5, 2 crop px^2)
+    levels = (20.0 + att * 200.0 * np.array([0.0, 0.5, 1.0])) / 255.0            # landmark_frames: background U(0, 40) + 200 * colour
+
+    def identity_bn(prefix, n, beta=None):
+        sd[prefix + ".weight"][:n] = 1.0
+        sd[prefix + ".bias"][:n] = 0.0 if beta is None else torch.as_tensor(beta, dtype=torch.float32)
+        sd[prefix + ".running_mean"][:n] = 0.0
+        sd[prefix + ".running_var"][:n] = 1.0 - 1e-5
+
+    def scale_bn(prefix, s):
+        sd[prefix + ".weight"] *= s
+        sd[prefix + ".bias"] *= s
+
+    # ---- conv1: colour features of the blurred, de-normalised image ----
+    w = sd["conv1.weight"]; w *= eps
+    beta = np.zeros(18)
+    for c in range(3):
+        for l in range(3):
+            k = 6 * c + 2 * l
+            w[k] = 0.0; w[k + 1] = 0.0
+            w[k, c] = float(std[c]) * blur; beta[k] = mean[c] - levels[l]              # P = relu(v_c - a_l)
+            w[k + 1, c] = -float(std[c]) * blur; beta[k + 1] = levels[l] - mean[c]     # N = relu(a_l - v_c)
+    scale_bn("bn1", eps)
+    identity_bn("bn1", 18, beta)
+    # ---- conv2: one L1 bump per landmark colour ----
+    cols = LANDMARK_COLOURS[:11]
+    a = (20.0 + att * 200.0 * cols) / 255.0
+    dist = np.abs(a[:, None, :] - a[None, :, :]).sum(2) + 1e9 * np.eye(11)
+    r = np.minimum(0.9 * dist.min(1), 0.35 * (att * 200.0 / 255.0) * cols.sum(1))
+    w = sd["conv2.weight"]; w *= eps
+    for j in range(11):
+        w[j] = 0.0
+        for c in range(3):
+            l = int(round(cols[j, c] * 2))
+            k = 6 * c + 2 * l
+            w[j, k] = -blur / float(r[j]); w[j, k + 1] = -blur / float(r[j])
+    scale_bn("bn2", eps)
+    identity_bn("bn2", 11, np.ones(11))
+    # ---- carry channels 0..10 along branch 0 ----
+    w = sd["layer1.0.downsample.0.weight"]; w[:64] *= eps
+    for k in range(64):
+        w[k, k, 0, 0] += 1.0
+    identity_bn("layer1.0.downsample.1", 64)
+    for b in range(4):
+        scale_bn("layer1.%d.bn3" % b, eps)
+    w = sd["transition1.0.0.weight"]; w *= eps
+    for k in range(48):
+        w[k, k, 1, 1] += 1.0
+    identity_bn("transition1.0.1", 48)
+    for name in list(sd):
+        p = name.split(".")
+        if p[0] in ("stage2", "stage3", "stage4") and p[2] == "branches" and p[3] == "0" and p[5] == "bn2" and p[6] == "weight":
+            scale_bn(name[:-len(".weight")], eps)                     # BasicBlocks of branch 0
+        if p[0] in ("stage2", "stage3", "stage4") and p[2] == "fuse_layers" and p[3] == "0" and p[5] == "1" and p[6] == "weight":
+            scale_bn(name[:-len(".weight")], eps)                     # up paths into branch 0 (fuse_layers.0.j = [conv1x1, bn, upsample])
+    w = sd["final_layer.weight"]; w *= eps
+    for j in range(11):
+        w[j, j, 0, 0] += 1.0
+    sd["final_layer.bias"].zero_()
+    return sd

@@ -416,3 +416,33 @@ def test_layer1_is_batch_invariant_under_the_xcd_local_tile_queue(gpu_ops, n):
             one = eng.forward_tap(u8[k:k + 1].contiguous(), tap)
             assert torch.equal(one[0], full[k]), "%s: frame %d of %d differs from the same frame run alone" % (tap, k, n)
     eng.close()
+
+
+def test_batch_2048_equals_eight_batches_of_256(gpu_ops):
+    """BASELINE.json configs[3]'s frame count (2048 frames of HRNet-W48 384x384; on 8 GPUs each rank takes 256) on ONE device, so that
+    every 32-bit buffer-descriptor path meets tensors of that size before a multi-GPU run does: layer1's 256-channel tensor is 9.7 GB
+    (the Bottleneck kernels split the batch into frame ranges), branch 0 is 1.8 GB, the stem's input 0.9 GB.  Property: the key
+    points of the whole batch (fused forward -> decode) are, bit for bit, those of its 256-frame chunks -- the batch-size invariance
+    every kernel is built for -- and a second run gives the same bits."""
+    cfg = R.w48_cfg()
+    eng = gpu_ops.HrnetEngine(cfg, R.make_state_dict(cfg, seed=3))
+    n, size = 2048, 384
+    g = torch.Generator().manual_seed(2048)
+    base = torch.randint(0, 256, (256, size, size, 3), generator=g, dtype=torch.uint8).cuda()
+    x = torch.empty((n, size, size, 3), dtype=torch.uint8, device="cuda")
+    for k in range(8):                                    # eight distinct chunks from one seeded block: frame i of chunk k = base[i] rolled by k rows
+        x[256 * k:256 * (k + 1)] = torch.roll(base, shifts=17 * k, dims=1)
+    c = torch.full((n, 2), size / 2.0, device="cuda"); s = torch.full((n, 2), size / 200.0 * 1.5, device="cuda")
+    need = eng.workspace_bytes(n, size, size)
+    assert need < 120e9, "workspace for 2048 frames: %.1f GB" % (need / 1e9)
+    kp = eng.forward_decode(x, c, s, True).clone()
+    assert kp.shape == (n, 11, 3) and torch.isfinite(kp).all()
+    assert torch.equal(eng.forward_decode(x, c, s, True), kp), "two runs of the 2048-frame batch differ"
+    for k in (0, 3, 7):
+        part = eng.forward_decode(x[256 * k:256 * (k + 1)].contiguous(), c[:256], s[:256], True)
+        assert torch.equal(part, kp[256 * k:256 * (k + 1)]), "chunk %d of the 2048-frame batch differs from the same frames as a batch of 256" % k
+    assert not torch.equal(kp[:256], kp[256:512])
+    hm = eng(x[1024:1024 + 512].contiguous())            # the heat-map path at 512 frames (2.4 GB of float32 maps) agrees with the fused one
+    assert torch.equal(gpu_ops.decode(hm, c[:512], s[:512], True), kp[1024:1536])
+    print("batch 2048: workspace %.1f GB" % (need / 1e9))
+    eng.close()
