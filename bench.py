@@ -103,7 +103,7 @@ def parse():
                     help="side line: files -> poses through the product CLI path (synthetic 1920x1200 JPEG frames on disk -> data loader -> "
                          "validate() -> pred.mat -> export -> opencv_poses.json), frames/s per stage beside the reference-style host loader "
                          "(tools_dev/pipeline_bench.py)")
-    ap.add_argument("--pipeline-frames", type=int, default=512)
+    ap.add_argument("--pipeline-frames", type=int, default=2048)
     ap.add_argument("--pipeline-workers", type=int, default=min(8, os.cpu_count() or 1))
     ap.add_argument("--cpu-stub", action="store_true",
                     help="(tests only) run the multi-rank step loop on CPU tensors over gloo with a stand-in engine: exercises the sharding, "

@@ -32,6 +32,12 @@
  *     handle per stream.
  *   - "blocked" activation layout used between layers: [N][C/8][H][W][8] 16-bit elements
  *     (bf16 or f16), C a multiple of 8.
+ *   - NO CPU ENTRY POINTS: this library has no host implementation of any function below and no fallback -- every
+ *     function needs a gfx950 device and fails with SCPOSE_E_HIP without one.  (SURVEY.md section 8b sketched
+ *     `scpose_cpu_*` twins for the CPU baseline; they are deliberately not part of the ABI: the CPU restatement of
+ *     the path is test infrastructure and lives under oracle/ -- hrnet_ref.py, decode_ref.py, pnp_ref.c, warp_ref.py --
+ *     where only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it; tests/test_abi.py checks
+ *     that nothing under the package, the CLIs or bench.py's measured path imports it.)
  */
 #ifndef SCPOSE_H
 #define SCPOSE_H
@@ -230,6 +236,14 @@ int32_t scpose_max_preds(const float* heatmaps, int32_t n, int32_t j, int32_t h,
 int32_t scpose_crop_warp(const uint8_t* frames, const int64_t* offsets, const int32_t* frame_hw,
                          const double* minv, int32_t n, int32_t out_h, int32_t out_w, int32_t swap_rb,
                          uint8_t* crops, void* stream);
+/* (ABI 7) The same warp when only a WINDOW of every frame is resident: windows = packed uint8 (roi_h x roi_w x 3) blocks at
+ * offsets[i], roi_xywh = device i32 N x 4 [x0, y0, w, h] of window i inside its frame, frame_hw = the FULL frame's size (the
+ * border rule is the frame's).  The caller guarantees that every tap the warp reads inside the frame lies inside the window
+ * (dataset/JointsDataset.py computes it from the affine); taps outside a window read 0.  Same crops, bit for bit, for a
+ * fraction of the host-to-device bytes (a 1920 x 1200 frame is 6.9 MB, the window of a 300 px target 0.5 MB). */
+int32_t scpose_crop_warp_roi(const uint8_t* windows, const int64_t* offsets, const int32_t* frame_hw,
+                             const int32_t* roi_xywh, const double* minv, int32_t n, int32_t out_h,
+                             int32_t out_w, int32_t swap_rb, uint8_t* crops, void* stream);
 
 /* Flip test (cfg.TEST.FLIP_TEST, lib/core/function.py:347-366): out = (a + flip_back(b)) * 0.5 where b
  * is the forward of the x-flipped input; flip_back (lib/utils/transforms.py:15-29) mirrors b in x and

@@ -81,6 +81,8 @@ SYMBOLS = {
                                    c_void_p]),
     "scpose_crop_warp": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                    c_void_p]),
+    "scpose_crop_warp_roi": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                       c_void_p]),
     "scpose_heatmap_accumulate": (c_int32, [c_void_p, c_void_p, c_float, c_int64, c_void_p]),
     "scpose_flip_merge": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                     c_void_p]),

@@ -87,9 +87,11 @@ def _run(config, val_loader, val_dataset, models, criterion, output_dir, pred_fi
     with torch.no_grad():
         end = time.time()
         for i, (input, target, target_weight, meta) in enumerate(val_loader):
-            if isinstance(input, (list, tuple)):   # dataset.device_crop: whole frames -> uint8 NHWC crops on the GPU
+            if isinstance(input, (list, tuple, dict)):   # dataset.device_crop: frame windows -> uint8 NHWC crops on the GPU
                 size = config.MODEL.IMAGE_SIZE
-                input = ops.crop_warp(input, meta["trans"].numpy(), (int(size[0]), int(size[1])), device=dev)
+                input = ops.crop_warp(input, meta["trans"].numpy(), (int(size[0]), int(size[1])), device=dev,
+                                      roi=meta["roi"].numpy() if "roi" in meta else None,
+                                      frame_hw=meta["frame_hw"].numpy() if "frame_hw" in meta else None)
             else:
                 input = input.to(dev, non_blocking=True)
             c = meta["center"].float()
@@ -107,7 +109,7 @@ def _run(config, val_loader, val_dataset, models, criterion, output_dir, pred_fi
                 out_f = _last(model(input.flip(2) if input.dtype == torch.uint8 else input.flip(3)))   # x axis: NHWC crops / NCHW tensors
                 # flip_back + SHIFT_HEATMAP + average (:354-366) in one device kernel, no D2H round trip
                 output = ops.flip_merge(output, out_f, val_dataset.flip_pairs, config.TEST.SHIFT_HEATMAP)
-            num_images = input.size(0)
+            num_images = int(input.shape[0])
             if fast:
                 pass
             elif log_metrics and criterion is not None and tuple(target.shape) != tuple(output.shape):

@@ -30,6 +30,16 @@ extern "C" int32_t scpose_crop_warp(const uint8_t* frames, const int64_t* offset
                           static_cast<hipStream_t>(stream));
 }
 
+extern "C" int32_t scpose_crop_warp_roi(const uint8_t* windows, const int64_t* offsets, const int32_t* frame_hw, const int32_t* roi_xywh,
+                                        const double* minv, int32_t n, int32_t out_h, int32_t out_w, int32_t swap_rb,
+                                        uint8_t* crops, void* stream) {
+  if (n == 0) return SCPOSE_OK;
+  SCP_REQUIRE(windows && offsets && frame_hw && roi_xywh && minv && crops, "crop_warp_roi: null argument");
+  SCP_REQUIRE(out_h > 0 && out_w > 0, "crop_warp_roi: bad output size %dx%d", out_h, out_w);
+  return crop_warp_launch(windows, offsets, frame_hw, minv, n, out_h, out_w, swap_rb, crops,
+                          static_cast<hipStream_t>(stream), roi_xywh);
+}
+
 extern "C" int32_t scpose_flip_merge(const float* a, const float* b, const int32_t* perm, int32_t n, int32_t j,
                                      int32_t h, int32_t w, int32_t shift, float* out, void* stream) {
   if (n == 0) return SCPOSE_OK;

@@ -235,7 +235,7 @@ int32_t fuse_down_launch(const FuseDownPacked& fd, const void* x0, int N, int H,
 int32_t fuse_sum_launch(const void* const* terms, const int32_t* shifts, int nterms, int N, int C,
                         int H, int W, int dtype, void* out, hipStream_t stream);
 int32_t crop_warp_launch(const uint8_t* frames, const int64_t* offsets, const int32_t* hw, const double* minv,
-                         int N, int oh, int ow, int swap_rb, uint8_t* out, hipStream_t stream);
+                         int N, int oh, int ow, int swap_rb, uint8_t* out, hipStream_t stream, const int32_t* roi = nullptr);
 int32_t head_gather_launch(const void* taps, const float* bias, const float* prev, int N, int J, int H, int W,
                            int K, int S, int dtype, float* out, hipStream_t stream);
 int32_t heatmap_accumulate_launch(float* acc, const float* x, float div, size_t count, hipStream_t stream);

@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void crop_warp_kernel(const uint8_t* __restric
                                                         const int64_t* __restrict__ offsets,
                                                         const int32_t* __restrict__ hw,
                                                         const double* __restrict__ minv, int N, int oh,
-                                                        int ow, int swap_rb, uint8_t* __restrict__ out) {
+                                                        int ow, int swap_rb, uint8_t* __restrict__ out,
+                                                        const int32_t* __restrict__ roi) {
   const size_t total = (size_t)N * oh * ow;
   for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (size_t)gridDim.x * 256) {
     const int x = (int)(gid % ow);
@@ -32,6 +33,9 @@ __global__ __launch_bounds__(256) void crop_warp_kernel(const uint8_t* __restric
     const double* m = minv + (size_t)n * 6;
     const int sh = hw[2 * n], sw = hw[2 * n + 1];
     const uint8_t* src = frames + offsets[n];
+    // roi != null: only the window [ry, ry + rh) x [rx, rx + rw) of frame n is stored (the loader ships the part of the frame the
+    // warp can touch instead of 1920 x 1200 x 3 bytes per frame); coordinates, weights and the frame border stay those of the whole frame
+    const int rx = roi ? roi[4 * n] : 0, ry = roi ? roi[4 * n + 1] : 0, rw = roi ? roi[4 * n + 2] : sw, rh = roi ? roi[4 * n + 3] : sh;
     const double xs = (double)x, ys = (double)y;
     auto sat_int = [](double v) -> long long {      // cv::saturate_cast<int>(double): cvRound + clamp to int32
       v = rint(v);
@@ -48,8 +52,8 @@ __global__ __launch_bounds__(256) void crop_warp_kernel(const uint8_t* __restric
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       auto tap = [&](long long yy, long long xx) -> int {
-        const bool ok = yy >= 0 && yy < sh && xx >= 0 && xx < sw;
-        return ok ? (int)src[((size_t)yy * sw + (size_t)xx) * 3 + c] : 0;
+        const bool ok = yy >= 0 && yy < sh && xx >= 0 && xx < sw && yy >= ry && yy < ry + rh && xx >= rx && xx < rx + rw;
+        return ok ? (int)src[((size_t)(yy - ry) * rw + (size_t)(xx - rx)) * 3 + c] : 0;
       };
       const int v = (tap(y0, x0) * w00 + tap(y0, x0 + 1) * w01 + tap(y0 + 1, x0) * w10 + tap(y0 + 1, x0 + 1) * w11 + 16384) >> 15;
       res[c] = (uint8_t)(v > 255 ? 255 : v);
@@ -62,13 +66,13 @@ __global__ __launch_bounds__(256) void crop_warp_kernel(const uint8_t* __restric
 }
 
 int32_t crop_warp_launch(const uint8_t* frames, const int64_t* offsets, const int32_t* hw, const double* minv,
-                         int N, int oh, int ow, int swap_rb, uint8_t* out, hipStream_t stream) {
+                         int N, int oh, int ow, int swap_rb, uint8_t* out, hipStream_t stream, const int32_t* roi) {
   const size_t total = (size_t)N * oh * ow;
   if (total == 0) return SCPOSE_OK;
   size_t blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(crop_warp_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, frames, offsets, hw, minv, N, oh,
-                     ow, swap_rb, out);
+                     ow, swap_rb, out, roi);
   SCP_CHECK_HIP(hipGetLastError());
   return SCPOSE_OK;
 }

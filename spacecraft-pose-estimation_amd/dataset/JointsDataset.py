@@ -88,7 +88,11 @@ class JointsDataset(Dataset):
             data_numpy = self.numpy_transform(data_numpy)
         trans = get_affine_transform(c, s, r, self.image_size)
         if self.device_crop:
-            input = torch.from_numpy(np.ascontiguousarray(data_numpy))   # H x W x 3 uint8, final channel order
+            # only the window of the frame the warp can read travels (worker -> main process -> device): [x0, y0, w, h] in meta["roi"]
+            from ..ops import warp_window
+            fh, fw = int(data_numpy.shape[0]), int(data_numpy.shape[1])
+            roi = warp_window(trans, (int(self.image_size[0]), int(self.image_size[1])), (fh, fw))
+            input = torch.from_numpy(np.ascontiguousarray(data_numpy[roi[1]:roi[1] + roi[3], roi[0]:roi[0] + roi[2]]))   # uint8, final channel order
         else:
             input = warp_affine_bilinear(np.ascontiguousarray(data_numpy), trans, (int(self.image_size[0]), int(self.image_size[1])))
             if self.transform:
@@ -105,13 +109,17 @@ class JointsDataset(Dataset):
                 "joints": joints, "joints_vis": joints_vis, "center": c, "scale": s, "rotation": r, "score": score}
         if self.device_crop:
             meta["trans"] = np.asarray(trans, dtype=np.float64)
+            meta["roi"] = np.asarray(roi, dtype=np.int32)
+            meta["frame_hw"] = np.asarray([fh, fw], dtype=np.int32)
         return input, torch.from_numpy(target), torch.from_numpy(target_weight), meta
 
     @staticmethod
     def collate_device_crop(batch):
-        """DataLoader collate_fn for device_crop: frames stay a list (sizes differ), the rest is default-collated."""
+        """DataLoader collate_fn for device_crop: the frame windows (sizes differ) are packed into one flat tensor + offsets + sizes
+        (ops.pack_frames: one object through the worker -> main-process queue instead of one per frame), the rest is default-collated."""
         from torch.utils.data import default_collate
-        frames = [b[0] for b in batch]
+        from ..ops import pack_frames
+        frames = pack_frames([b[0] for b in batch])
         rest = default_collate([(b[1], b[2], b[3]) for b in batch])
         return frames, rest[0], rest[1], rest[2]
 

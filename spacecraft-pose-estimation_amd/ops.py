@@ -131,34 +131,75 @@ def max_preds(heatmaps):
     return coords, maxvals
 
 
-def crop_warp(frames, trans, out_wh, swap_rb=False, device=None):
+def crop_warp(frames, trans, out_wh, swap_rb=False, device=None, roi=None, frame_hw=None):
     """Batched cv2.warpAffine(frame_i, trans_i, (W, H), INTER_LINEAR) on the device.
     frames: list of HxWx3 uint8 arrays/tensors (any sizes); trans: (N,2,3) forward affines as returned by
-    get_affine_transform (frame -> crop).  Returns uint8 (N, H, W, 3) device crops."""
+    get_affine_transform (frame -> crop).  Returns uint8 (N, H, W, 3) device crops.
+    roi (N,4) [x0, y0, w, h] + frame_hw (N,2): frames[i] is only that WINDOW of a frame of size frame_hw[i] (warp_window below
+    computes one that contains every tap); same crops bit for bit (scpose_crop_warp_roi)."""
     import numpy as np
     dev = device or torch.device("cuda", torch.cuda.current_device())
-    n = len(frames)
+    packed = isinstance(frames, dict)      # pack_frames(): one flat uint8 tensor + offsets + sizes (what the data-loader workers send)
+    if not packed:
+        frames = pack_frames(frames)
+    n = int(frames["hw"].shape[0])
     w, h = int(out_wh[0]), int(out_wh[1])
     out = torch.empty((n, h, w, 3), dtype=torch.uint8, device=dev)
     if n == 0:
         return out
+    offs = frames["offsets"].tolist(); hw = [tuple(v) for v in frames["hw"].tolist()]
+    buf = frames["flat"].to(dev, non_blocking=True)
+    from .utils.transforms import invert_affine_cv
+    minv = np.zeros((n, 6), dtype=np.float64)
+    for i in range(n):
+        minv[i] = invert_affine_cv(trans[i])            # the inverse map exactly as cv::warpAffine derives it
+    offs_d = torch.tensor(offs, dtype=torch.int64, device=dev)
+    minv_d = torch.from_numpy(minv).to(dev)
+    if roi is not None:
+        roi = np.asarray(roi, dtype=np.int32).reshape(n, 4); fhw = np.asarray(frame_hw, dtype=np.int32).reshape(n, 2)
+        for i in range(n):
+            if (int(roi[i, 3]), int(roi[i, 2])) != hw[i]:
+                raise ValueError("crop_warp: window %d is %s but roi says %dx%d" % (i, hw[i], roi[i, 3], roi[i, 2]))
+        fhw_d = torch.from_numpy(fhw).to(dev); roi_d = torch.from_numpy(roi).to(dev)      # (named: both must outlive the launch call)
+        nat.check(nat.lib().scpose_crop_warp_roi(_ptr(buf), _ptr(offs_d), _ptr(fhw_d), _ptr(roi_d),
+                                                 _ptr(minv_d), n, h, w, int(bool(swap_rb)), _ptr(out), _stream()), "crop_warp_roi")
+        return out
+    hw_d = torch.tensor(hw, dtype=torch.int32, device=dev)
+    nat.check(nat.lib().scpose_crop_warp(_ptr(buf), _ptr(offs_d), _ptr(hw_d), _ptr(minv_d), n, h, w, int(bool(swap_rb)),
+                                         _ptr(out), _stream()), "crop_warp")
+    return out
+
+
+def pack_frames(frames):
+    """list of HxWx3 uint8 arrays / tensors (any sizes) -> {"flat": all bytes back to back, "offsets": int64 (n,), "hw": int32 (n, 2)}:
+    the form scpose_crop_warp[_roi] takes.  The data-loader workers call it (dataset.collate_device_crop), so a batch crosses the
+    process boundary as one tensor instead of one per frame."""
+    import numpy as np
     flat, offs, hw, o = [], [], [], 0
     for f in frames:
         t = f if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(f))
         if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
             raise ValueError("crop_warp: frames must be HxWx3 uint8")
         flat.append(t.reshape(-1)); offs.append(o); hw.append((t.shape[0], t.shape[1])); o += t.numel()
-    buf = torch.cat(flat).to(dev, non_blocking=True)
+    return {"flat": torch.cat(flat) if flat else torch.zeros(0, dtype=torch.uint8), "offsets": torch.tensor(offs, dtype=torch.int64),
+            "hw": torch.tensor(hw, dtype=torch.int32).reshape(-1, 2)}
+
+
+def warp_window(trans, out_wh, frame_hw):
+    """[x0, y0, w, h]: a window of the frame that contains every pixel crop_warp reads for this affine (host side, NumPy).  The
+    corners of the output grid go through the inverse map exactly as the kernel derives it; the fixed-point coordinates deviate
+    from the real ones by < 1 px and a bilinear tap reads (x, x + 1): two pixels of margin, three on the far side; clipped to the frame
+    (w or h may be 0: nothing of the frame is read)."""
+    import numpy as np
     from .utils.transforms import invert_affine_cv
-    minv = np.zeros((n, 6), dtype=np.float64)
-    for i in range(n):
-        minv[i] = invert_affine_cv(trans[i])            # the inverse map exactly as cv::warpAffine derives it
-    offs_d = torch.tensor(offs, dtype=torch.int64, device=dev)
-    hw_d = torch.tensor(hw, dtype=torch.int32, device=dev)
-    minv_d = torch.from_numpy(minv).to(dev)
-    nat.check(nat.lib().scpose_crop_warp(_ptr(buf), _ptr(offs_d), _ptr(hw_d), _ptr(minv_d), n, h, w, int(bool(swap_rb)),
-                                         _ptr(out), _stream()), "crop_warp")
-    return out
+    m = np.asarray(invert_affine_cv(trans), dtype=np.float64).reshape(2, 3)
+    w, h = int(out_wh[0]), int(out_wh[1])
+    cx = np.array([0.0, w - 1.0, 0.0, w - 1.0]); cy = np.array([0.0, 0.0, h - 1.0, h - 1.0])
+    sx = m[0, 0] * cx + m[0, 1] * cy + m[0, 2]; sy = m[1, 0] * cx + m[1, 1] * cy + m[1, 2]
+    fh, fw = int(frame_hw[0]), int(frame_hw[1])
+    x0 = min(max(int(np.floor(sx.min())) - 2, 0), fw); x1 = min(max(int(np.ceil(sx.max())) + 3, 0), fw)
+    y0 = min(max(int(np.floor(sy.min())) - 2, 0), fh); y1 = min(max(int(np.ceil(sy.max())) + 3, 0), fh)
+    return [x0, y0, max(x1 - x0, 0), max(y1 - y0, 0)]
 
 
 def basic_block(conv1, conv2, xb):

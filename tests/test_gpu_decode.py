@@ -153,3 +153,30 @@ def test_crop_warp_matches_numpy_restatement(gpu_ops):
     got_sw = gpu_ops.crop_warp(frames, np.stack(trans), (48, 64), swap_rb=True).cpu().numpy()
     assert np.array_equal(got_sw, np.stack(refs)[..., ::-1])
     assert gpu_ops.crop_warp([], np.zeros((0, 2, 3)), (48, 64)).shape == (0, 64, 48, 3)
+
+
+def test_crop_warp_from_windows_equals_crop_warp_from_whole_frames(gpu_ops):
+    """scpose_crop_warp_roi (ABI 7): the loader ships only the window of each frame the warp can read (ops.warp_window) -- the crops must
+    be the ones the whole frames give, bit for bit: boxes inside the frame, overhanging every border, larger than the frame,
+    entirely outside it (empty window), up- and down-sampling; and the window must be a small part of a full-size frame."""
+    import numpy as np
+    from importlib import import_module
+    T = import_module("spacecraft-pose-estimation_amd.utils.transforms")
+    rng = np.random.default_rng(17)
+    cases = [(1200, 1920, (960.0, 600.0), (1.2, 1.2)), (1200, 1920, (30.0, 20.0), (1.0, 1.0)), (1200, 1920, (1900.0, 1190.0), (2.0, 2.0)),
+             (120, 200, (100.0, 60.0), (3.0, 3.0)), (96, 96, (-300.0, -300.0), (0.4, 0.4)), (240, 320, (160.0, 120.0), (0.15, 0.15)),
+             (64, 80, (79.0, 0.0), (0.3, 0.3))]
+    frames, wins, rois, fhw, trans = [], [], [], [], []
+    for (h, w, c, s) in cases:
+        f = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        t = T.get_affine_transform(np.array(c, np.float32), np.array(s, np.float32), 0, np.array([96, 128]))
+        r = gpu_ops.warp_window(t, (96, 128), (h, w))
+        frames.append(f); trans.append(t); rois.append(r); fhw.append((h, w))
+        wins.append(np.ascontiguousarray(f[r[1]:r[1] + r[3], r[0]:r[0] + r[2]]))
+    whole = gpu_ops.crop_warp(frames, np.stack(trans), (96, 128)).cpu().numpy()
+    part = gpu_ops.crop_warp(wins, np.stack(trans), (96, 128), roi=np.array(rois), frame_hw=np.array(fhw)).cpu().numpy()
+    assert np.array_equal(part, whole)
+    assert whole[0].any() and not whole[4].any() and rois[4][2] * rois[4][3] == 0          # a crop with content; a box outside the frame
+    assert rois[0][2] * rois[0][3] < 0.1 * 1920 * 1200                                      # 240 px box in a SPEED+ frame: < 10 % of its bytes
+    part_sw = gpu_ops.crop_warp(wins, np.stack(trans), (96, 128), swap_rb=True, roi=np.array(rois), frame_hw=np.array(fhw)).cpu().numpy()
+    assert np.array_equal(part_sw, whole[..., ::-1])

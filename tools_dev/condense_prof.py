@@ -30,7 +30,12 @@ def op_classes():
     eng.forward(x, profile=True)
     recs = [r for r in eng.profile_read() if not (r["kind"] == 2 and r["bytes_per_frame"] == 0)]   # the fuse row the fused tail absorbs launches nothing
     names = eng.kernel_classes(recs)
-    return names, {c: (r["flops_per_frame"] * batch, r["bytes_per_frame"] * batch) for c, r in zip(names, recs)}
+    # algorithmic work per launch of a class = the MEAN over its launches (a class mixes launches with and without a residual:
+    # 96 -> 96 moves 339.7 MB with one and 226.5 MB without; bench.py's roofline line divides by the same mean -- VERDICT r4)
+    acc = collections.defaultdict(lambda: [0.0, 0.0, 0])
+    for c, r in zip(names, recs):
+        a = acc[c]; a[0] += r["flops_per_frame"] * batch; a[1] += r["bytes_per_frame"] * batch; a[2] += 1
+    return names, {c: (a[0] / a[2], a[1] / a[2]) for c, a in acc.items()}
 
 
 def find(sub, pat):
