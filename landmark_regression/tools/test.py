@@ -89,8 +89,8 @@ def main():
     valid_dataset.want_target = bool(args.log_metrics)     # gaussian targets feed the logged loss / PCK only
     valid_loader = torch.utils.data.DataLoader(subset, batch_size=cfg.TEST.BATCH_SIZE_PER_GPU * len(cfg.GPUS),
                                                shuffle=False, num_workers=cfg.WORKERS, pin_memory=not args.device_crop,
-                                               # workers are started fresh (forkserver), never forked from this process: it has initialised HIP
-                                               multiprocessing_context="forkserver" if cfg.WORKERS > 0 else None,
+                                               # workers come from a clean fork server, never from this process: it has initialised HIP
+                                               multiprocessing_context=parallel.loader_worker_context(cfg.WORKERS),
                                                collate_fn=valid_dataset.collate_device_crop if args.device_crop else None)
     validate(cfg, valid_loader, valid_dataset, model, criterion, final_output_dir, tb_log_dir, pred_file_name="pred_test",
              log_metrics=bool(args.log_metrics))

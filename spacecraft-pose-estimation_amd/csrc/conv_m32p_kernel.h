@@ -169,9 +169,21 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
         hs[i] = -1; hy[i] = hx[i] = 0;
       }
     }
+    // Retire-buffer traffic is split over the producer waves by pixel slot: slots [0, 256) belong to thread ptid.  The NX 64-slot
+    // chunks past 256 (PXCAP = 320: one, 384: two) used to belong to waves 0 .. NX - 1 for EVERY plane, which gave those waves twice the
+    // stores and residual loads of the others -- and their SIMDs' consumer waves a busier partner, at whose pace all eight waves then
+    // met the stage barrier (round 5).  They now go round the waves by plane: NX = 2: waves 0, 1 on even planes, 2, 3 on odd ones;
+    // NX = 1: wave pl & 3.  A thread still owns at most two slots (ptid, and 256 + 64 (wave & 1) + lane).
+    constexpr int NX = (PXCAP > 256 && PXCAP < 512) ? (PXCAP - 256) / 64 : 0;
+    auto slot_of = [&](int k) -> int { return (k == 0 || NX == 0) ? k * 256 + ptid : 256 + (NX == 2 ? (wave & 1) : 0) * 64 + lane; };
+    auto wslot_of = [&](int k) -> int { return (k == 0 || NX == 0) ? k * 256 + wave * 64 : 256 + (NX == 2 ? (wave & 1) : 0) * 64; };   // the wave's first slot
+    auto moves = [&](int k, int pl) -> bool {   // wave-uniform: does this wave move pixel group k of plane pl?
+      if (k == 0 || NX == 0) return k * 256 + wave * 64 < PXCAP;
+      return NX == 2 ? ((pl & 1) == (wave >> 1)) : ((pl & 3) == wave);
+    };
     int qs[NQ], qy[NQ], qx[NQ];   // retire-buffer pixels of this thread
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) pixel_of(k * 256 + ptid < PXCAP ? k * 256 + ptid : P, qs[k], qy[k], qx[k]);
+    for (int k = 0; k < NQ; ++k) pixel_of(slot_of(k) < PXCAP ? slot_of(k) : P, qs[k], qy[k], qx[k]);
 
     // Tensors below 4 GiB are addressed through buffer descriptors (conv_pipe_kernel.h: dma16_buf): per-item 32-bit
     // lane offsets, chunk / plane displacement in an SGPR, padding lanes out of range.  Larger ones keep 64-bit pointers.
@@ -280,19 +292,19 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
         for (int pl = pl0; pl < pl1; ++pl)
 #pragma unroll
           for (int k = 0; k < NQ; ++k)
-            if (k * 256 + ptid < PXCAP)
+            if (moves(k, pl))
               dma16_buf(rs_res, plane0 + pl < cout_planes ? (uint32_t)qb[k] : BUF_OOB, (uint32_t)((plane0 + pl) * HoWo) * 16u,
-                        ro + ((pl * PXCAP) + k * 256 + wave * 64) * 16);
+                        ro + ((pl * PXCAP) + wslot_of(k)) * 16);
         return;
       }
       for (int pl = pl0; pl < pl1; ++pl)
 #pragma unroll
         for (int k = 0; k < NQ; ++k)
-          if (k * 256 + ptid < PXCAP) {
+          if (moves(k, pl)) {
             const bool ok = qb[k] != ~(size_t)0 && plane0 + pl < cout_planes;
             const char* src = ok ? static_cast<const char*>(p.res) + qb[k] + (size_t)(plane0 + pl) * HoWo * 16
                                  : static_cast<const char*>(p.zero16);
-            dma16(src, ro + ((pl * PXCAP) + k * 256 + wave * 64) * 16);
+            dma16(src, ro + ((pl * PXCAP) + wslot_of(k)) * 16);
           }
     };
     // planes [pl0, pl1) of the retire buffer: results of tile `it` -> global
@@ -302,21 +314,25 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
         for (int pl = pl0; pl < pl1 && plane0 + pl < cout_planes; ++pl)
 #pragma unroll
           for (int k = 0; k < NQ; ++k)
-            if (k * 256 + ptid < PXCAP)     // pixels outside the map carry BUF_OOB: the store is dropped by the hardware
+            if (moves(k, pl))     // pixels outside the map carry BUF_OOB: the store is dropped by the hardware
               store16_buf(rs_out, (uint32_t)qb[k], (uint32_t)((plane0 + pl) * HoWo) * 16u,
-                          *reinterpret_cast<const u32x4*>(ro + ((pl * PXCAP) + k * 256 + ptid) * 16));
+                          *reinterpret_cast<const u32x4*>(ro + ((pl * PXCAP) + slot_of(k)) * 16));
         return;
       }
       for (int pl = pl0; pl < pl1; ++pl)
 #pragma unroll
         for (int k = 0; k < NQ; ++k)
-          if (k * 256 + ptid < PXCAP && qb[k] != ~(size_t)0 && plane0 + pl < cout_planes) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(ro + ((pl * PXCAP) + k * 256 + ptid) * 16);
+          if (moves(k, pl) && qb[k] != ~(size_t)0 && plane0 + pl < cout_planes) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(ro + ((pl * PXCAP) + slot_of(k)) * 16);
             *reinterpret_cast<u32x4*>(static_cast<char*>(p.out) + qb[k] + (size_t)(plane0 + pl) * HoWo * 16) = v;
           }
     };
 
-    if (!SCP_DBG(p, 128)) __builtin_amdgcn_s_setprio(3);   // memory instructions ahead of the consumers' MFMA stream
+    // memory instructions ahead of the consumers' MFMA stream -- for the 32x32x16 consumers (a 32-cycle MFMA leaves the issue port free
+    // three quarters of the time; stride 2: 130 against 146 us without it).  Beside the 16x16x32 consumers, which issue twice as often,
+    // the producers' address arithmetic at priority 3 delays MFMA issue: without it 96 -> 96 97.2 against 99.3 us, 192 -> 192 80.9 / 81.7,
+    // 384 -> 384 88.8 / 88.5 inside the forward (round 5, development build, profiles/round5_priority_ab.txt)
+    if (!SCP_DBG(p, 128) && !(C16 != 0 && M16 == 0)) __builtin_amdgcn_s_setprio(3);
     size_t qb_cur[NQ], qb_prev[NQ];
 #pragma unroll
     for (int k = 0; k < NQ; ++k) qb_cur[k] = qb_prev[k] = buf ? (size_t)BUF_OOB : ~(size_t)0;
@@ -408,6 +424,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
     acc_t acc[MB][NB];
     frag_t a0[MB], a1[MB], bR[RING];
     const bool wave_idle = wave * NB * 16 >= P;   // wave-uniform
+    if (SCP_DBG(p, 512)) __builtin_amdgcn_s_setprio(3);   // (development: consumers at the producers' priority -- arbitration by age)
     const int npp = p.cp >> 1;                    // plane pairs per stage: 1 (the halves of a pair are two stages), 2 or 4
     int wc = 0, xb = 0;
     __syncthreads();   // matches the producers' prologue barrier

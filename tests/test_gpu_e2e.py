@@ -217,9 +217,9 @@ def test_cli_tools_test_and_pose_export(pk, tmp_path):
     # last kernel (no heat-map).  The reference's data flow -- crops warped and normalised in the loader, heat-maps written, loss /
     # PCK logged, get_final_preds on the heat-maps -- is --host_crop --log_metrics.  Every combination must give the same pred .mat,
     # bit for bit; so must a batch size of 2, whose second and third batch replay the captured forward (models/pose_hrnet.py).
-    def run(tag, flags, batch="4"):
+    def run(tag, flags, batch="4", workers="0"):
         o = tmp_path / ("out_" + tag)
-        c2 = cmd[:2] + flags + cmd[2:]
+        c2 = cmd[:2] + flags + cmd[2:] + ["WORKERS", workers]
         c2[c2.index("OUTPUT_DIR") + 1] = str(o)
         c2[c2.index("TEST.BATCH_SIZE_PER_GPU") + 1] = batch
         r2 = subprocess.run(c2, cwd=os.path.join(ROOT, "landmark_regression"), capture_output=True, text=True, timeout=600)
@@ -233,6 +233,11 @@ def test_cli_tools_test_and_pose_export(pk, tmp_path):
         assert ("fused forward -> key-point path" in log) == ("--log_metrics" not in flags), tag
         if "--log_metrics" in flags:
             assert "Accuracy" in log and "Loss" in log
+    # loader workers (cfg.WORKERS > 0) come from a pre-loaded fork server, never forked from the process that holds the HIP context
+    preds_w, _ = run("workers2", [], "4", workers="2")
+    assert np.array_equal(preds_w, preds)
+    preds_w, _ = run("workers2_host_crop", ["--host_crop"], "4", workers="2")
+    assert np.array_equal(preds_w, preds)
 
     # stage 3 on known-answer keypoints written in the same .mat format
     kp, Rs, ts = P.synth_keypoints(6, np.random.default_rng(4), 0.5, 0.0)
