@@ -326,3 +326,51 @@ def w48_chain_checkpoint(seed=0, eps=W48_CHAIN_EPS):
         w[j, j, 0, 0] += 1.0
     sd["final_layer.bias"].zero_()
     return sd
+
+
+def landmark_scene(n, rng, image=384, blob_sigma=W48_CHAIN_BLOB_SIGMA, landmarks=TANGO_LANDMARKS, K=SPEEDPLUS_K, dist=SPEEDPLUS_DIST,
+                   width=1920, height=1200):
+    """landmark_frames at the FILE boundary: n whole 1920 x 1200 frames showing the projected landmarks as coloured blobs, with the COCO
+    bounding box a detector would hand to `EventsDataset` -- so that the crop JointsDataset.py:134-198 cuts (centre / scale by
+    events.py:94-113's _xywh2cs, float32) is the crop landmark_frames draws directly: every landmark sits at the frame position whose
+    heat-map coordinate has the fractional part .25 / .75 nearest to its projection, with sigma = blob_sigma crop pixels after the warp.
+    Returns dict: frames [n] uint8 (height, width, 3) RGB; bbox (n, 4) [x, y, w, h]; kp (n, J, 2) drawn positions in frame pixels; R, t."""
+    j = len(landmarks)
+    hs = image // 4
+    frames, bbox = [], np.zeros((n, 4))
+    kp = np.zeros((n, j, 2)); rs = np.zeros((n, 3, 3)); ts = np.zeros((n, 3))
+    for i in range(n):
+        while True:
+            r = random_rotation(rng)
+            z = rng.uniform(3.0, 10.0)
+            t = np.array([rng.uniform(-0.25, 0.25) * z, rng.uniform(-0.15, 0.15) * z, z])
+            uv = project(r, t, landmarks, K, dist)
+            if not ((uv[:, 0] > 0).all() and (uv[:, 0] < width).all() and (uv[:, 1] > 0).all() and (uv[:, 1] < height).all()):
+                continue
+            lo, hi = uv.min(0), uv.max(0)
+            w = max(1.3 * (hi - lo).max(), 48.0) / 1.5                # the detector's box: EventsDataset enlarges it 1.5 x
+            x, y = (lo[0] + hi[0]) / 2 - w / 2, (lo[1] + hi[1]) / 2 - w / 2
+            c32 = np.array([x + 0.5 * w, y + 0.5 * w], dtype=np.float32)                 # _xywh2cs, events.py:94-113
+            s32 = (np.array([w, w], dtype=np.float64) / 200).astype(np.float32) * 1.5
+            side = float(s32[0]) * 200.0
+            h = ((uv - c32.astype(np.float64)) * (image / side) + image / 2) / 4.0
+            fl = np.floor(h)
+            h = fl + np.where(h - fl < 0.5, 0.25, 0.75)
+            if h.min() < 2.0 or h.max() > hs - 3.0:
+                continue
+            d = np.linalg.norm(h[:, None, :] - h[None, :, :], axis=2) + 1e9 * np.eye(j)
+            if d.min() < 4.0:          # blobs of sigma 1.9 heat-map pixels must not merge
+                continue
+            break
+        pos = (4.0 * h - image / 2) * (side / image) + c32.astype(np.float64)
+        sig = blob_sigma * side / image
+        img = 20.0 + rng.uniform(-4.0, 4.0, (height, width, 1)) * np.ones((1, 1, 3))
+        for k in range(j):
+            x0, x1 = int(max(pos[k, 0] - 4 * sig, 0)), int(min(pos[k, 0] + 4 * sig + 1, width))
+            y0, y1 = int(max(pos[k, 1] - 4 * sig, 0)), int(min(pos[k, 1] + 4 * sig + 1, height))
+            yy, xx = np.mgrid[y0:y1, x0:x1].astype(np.float64)
+            g = np.exp(-((xx - pos[k, 0]) ** 2 + (yy - pos[k, 1]) ** 2) / (2.0 * sig ** 2))
+            img[y0:y1, x0:x1] += 200.0 * g[:, :, None] * LANDMARK_COLOURS[k % len(LANDMARK_COLOURS)]
+        frames.append(np.clip(img, 0.0, 255.0).astype(np.uint8))
+        bbox[i] = (x, y, w, w); kp[i] = pos; rs[i], ts[i] = r, t
+    return {"frames": frames, "bbox": bbox, "kp": kp, "R": rs, "t": ts}
