@@ -23,6 +23,9 @@ container (it never ships; /root/reference does not exist on the GPU box):
     intrinsics with and without distortion, the direction-cosine matrices, and the masks.  cv2.solvePnPRansac itself stays
     unpinned (no OpenCV here).
 
+  * lib/utils/transforms.py (get_affine_transform, affine_transform :57-95) -- the crop's affine and the joints mapped through it
+    (affine_reference_outputs.npz).
+
 Only data is written (npz): no reference source text.  Re-run: python tests/golden/make_golden.py
 """
 import importlib
@@ -221,6 +224,26 @@ def host_vectors():
     print("host vectors: acc", acc, "cnt", cnt, "loss", out["loss_use0"], out["loss_use1"])
 
 
+def affine_vectors():
+    """get_affine_transform / affine_transform of lib/utils/transforms.py:57-95 (imported under the cv2.getAffineTransform stub): the affine
+    the crop is cut with (inv = 0: JointsDataset.py:179, what scpose_crop_warp applies) and its inverse (inv = 1: transform_preds),
+    for seeded centres / scales / output sizes, and joints mapped through it (JointsDataset.py:186-188).  Pins the GEOMETRY of the crop;
+    cv2.warpAffine's pixel interpolation stays unpinned (oracle/warp_ref.py)."""
+    install_cv2_stub()
+    tr = importlib.import_module("utils.transforms")
+    rng = np.random.default_rng(11)
+    n = 40
+    c = (rng.random((n, 2)) * np.array([1920, 1200]) * 1.2 - 100).astype(np.float32)
+    s = (rng.random((n, 2)) * 4.0 + 0.1).astype(np.float32)
+    sizes = np.array([(384, 384), (256, 256), (768, 768), (96, 128), (64, 48)])[rng.integers(0, 5, n)]
+    pts = (rng.random((n, 11, 2)) * np.array([1920, 1200])).astype(np.float64)
+    fwd = np.stack([tr.get_affine_transform(c[i], s[i], 0, sizes[i]) for i in range(n)])
+    inv = np.stack([tr.get_affine_transform(c[i], s[i], 0, sizes[i], inv=1) for i in range(n)])
+    mapped = np.stack([np.stack([tr.affine_transform(pts[i, j], fwd[i]) for j in range(11)]) for i in range(n)])
+    np.savez_compressed(os.path.join(HERE, "affine_reference_outputs.npz"), center=c, scale=s, sizes=sizes, points=pts, forward=fwd, inverse=inv, mapped=mapped)
+    print("affine vectors", fwd.shape, float(np.abs(fwd).max()))
+
+
 def camera_vectors():
     """Camera model + confidence filter through the reference's own code (SURVEY.md section 8 a11, 8d, section 9 "PnP")."""
     import inspect
@@ -306,4 +329,5 @@ if __name__ == "__main__":
     cms_vectors()
     decode_vectors()
     host_vectors()
+    affine_vectors()
     camera_vectors()
