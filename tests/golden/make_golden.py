@@ -26,6 +26,11 @@ container (it never ships; /root/reference does not exist on the GPU box):
   * lib/utils/transforms.py (get_affine_transform, affine_transform :57-95) -- the crop's affine and the joints mapped through it
     (affine_reference_outputs.npz).
 
+  * lib/dataset/events.py (_xywh2cs :94-113) and lib/dataset/JointsDataset.py (generate_target :264-332), called unbound
+    (dataset_reference_outputs.npz).
+
+  * lib/utils/utils.py (create_logger :22-57): the output-directory naming (naming_reference_outputs.npz).
+
 Only data is written (npz): no reference source text.  Re-run: python tests/golden/make_golden.py
 """
 import importlib
@@ -244,6 +249,70 @@ def affine_vectors():
     print("affine vectors", fwd.shape, float(np.abs(fwd).max()))
 
 
+def dataset_vectors():
+    """The two pieces of dataset code on the path through the reference's own classes, imported under stubs for cv2 and
+    json_tricks: EventsDataset._xywh2cs (lib/dataset/events.py:94-113: COCO box -> float32 centre / scale) and
+    JointsDataset.generate_target (lib/dataset/JointsDataset.py:264-332: the gaussian targets the logged loss / PCK are computed
+    against), called unbound on a namespace that carries the attributes they read."""
+    install_cv2_stub()
+    if "json_tricks" not in sys.modules:
+        sys.modules["json_tricks"] = types.ModuleType("json_tricks")
+    ev = importlib.import_module("dataset.events")
+    jd = importlib.import_module("dataset.JointsDataset")
+    rng = np.random.default_rng(13)
+    boxes = np.concatenate([rng.random((30, 4)) * np.array([1800, 1100, 900, 700]), np.array([[-1.0, 5.0, 0.0, 7.0], [10.5, 20.25, 1.0, 1.0], [0, 0, 1920, 1200]])])
+    ns = types.SimpleNamespace(pixel_std=200, aspect_ratio=1920 / 1200)
+    cs = [ev.EventsDataset._xywh2cs(ns, *b) for b in boxes]
+    out = {"boxes": boxes, "center": np.stack([c for c, _ in cs]), "scale": np.stack([s for _, s in cs])}
+    for name, (img, hm, sigma) in {"w48": ((384, 384), (96, 96), 2), "rect": ((192, 256), (48, 64), 3), "cms768": ((768, 768), (768, 768), 12)}.items():
+        n, j = 6, 11
+        g = types.SimpleNamespace(num_joints=j, target_type="gaussian", image_size=np.array(img), heatmap_size=np.array(hm), sigma=sigma,
+                                  sigma2=sigma, sigma3=sigma, sigma4=sigma, use_different_joints_weight=False, joints_weight=1)
+        joints = np.zeros((n, j, 3)); vis = np.ones((n, j, 3))
+        joints[:, :, 0] = rng.uniform(-0.2, 1.2, (n, j)) * img[0]; joints[:, :, 1] = rng.uniform(-0.2, 1.2, (n, j)) * img[1]
+        joints[0, 0, :2] = (0.0, 0.0); joints[0, 1, :2] = (img[0] - 1, img[1] - 1); joints[0, 2, :2] = (-3 * sigma * img[0] / hm[0] - 1, 10)   # corners; just outside
+        vis[1, 3] = 0.0                                                                                                                          # an invisible joint
+        res = [jd.JointsDataset.generate_target(g, joints[i].copy(), vis[i].copy()) for i in range(n)]
+        out[name + "/joints"] = joints; out[name + "/vis"] = vis
+        out[name + "/meta"] = np.array([img[0], img[1], hm[0], hm[1], sigma])
+        tg = np.stack([t for t, _ in res])
+        out[name + "/weight"] = np.stack([w for _, w in res])
+        if name == "cms768":      # 6 x 11 x 768 x 768 floats would be 156 MB: store where each map is non-zero and its values
+            nz = [np.nonzero(tg[i, k]) for i in range(n) for k in range(j)]
+            out[name + "/nz_count"] = np.array([len(a[0]) for a in nz])
+            out[name + "/nz_index"] = np.concatenate([a[0] * hm[0] + a[1] for a in nz]).astype(np.int32)
+            out[name + "/nz_value"] = np.concatenate([tg[i, k][nz[i * j + k]] for i in range(n) for k in range(j)])
+        else:
+            out[name + "/target"] = tg
+    np.savez_compressed(os.path.join(HERE, "dataset_reference_outputs.npz"), **out)
+    print("dataset vectors:", {k: v.shape for k, v in out.items() if k.endswith("target") or k.endswith("nz_value")})
+
+
+def naming_vectors():
+    """create_logger of lib/utils/utils.py:22-57 (imports only torch): the output tree <OUTPUT_DIR>/<DATASET>[_<HYBRID>]/<MODEL.NAME>/<cfg basename>
+    that evaluate_pipeline.py:88 reads pred.mat from, for a few cfg shapes; stored relative to OUTPUT_DIR / LOG_DIR."""
+    import logging
+    import tempfile
+    spec = importlib.util.spec_from_file_location("ref_utils_utils", os.path.join(REF, "lib/utils/utils.py"))
+    u = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(u)
+    cases = [("EventsDataset", "", "pose_hrnet", "experiments/events/events-config.yaml", "valid"),
+             ("PEdataset", "", "hrnet_cms", "experiments/lit_hpc_001.yaml", "valid"),
+             ("coco", "hybrid:v2", "pose_hrnet", "/abs/path/w48_384x384.adam.yaml", "train"),
+             ("light:box", "", "hrnet_cms_384", "sun_hpc_003.yaml", "valid")]
+    rel_out, rel_log = [], []
+    for ds, hy, model, cfg_name, phase in cases:
+        with tempfile.TemporaryDirectory() as d:
+            cfg = types.SimpleNamespace(OUTPUT_DIR=os.path.join(d, "out"), LOG_DIR=os.path.join(d, "log"),
+                                        DATASET=types.SimpleNamespace(DATASET=ds, HYBRID_JOINTS_TYPE=hy), MODEL=types.SimpleNamespace(NAME=model))
+            _, fo, tb = u.create_logger(cfg, cfg_name, phase)
+            rel_out.append(os.path.relpath(fo, cfg.OUTPUT_DIR)); rel_log.append(os.path.relpath(os.path.dirname(tb), cfg.LOG_DIR) + "|" + os.path.basename(tb)[:-17])
+            for h in list(logging.getLogger().handlers):
+                logging.getLogger().removeHandler(h); h.close()
+    np.savez_compressed(os.path.join(HERE, "naming_reference_outputs.npz"), cases=np.array(cases), rel_out=np.array(rel_out), rel_log=np.array(rel_log))
+    print("naming vectors", rel_out, rel_log)
+
+
 def camera_vectors():
     """Camera model + confidence filter through the reference's own code (SURVEY.md section 8 a11, 8d, section 9 "PnP")."""
     import inspect
@@ -330,4 +399,6 @@ if __name__ == "__main__":
     decode_vectors()
     host_vectors()
     affine_vectors()
+    dataset_vectors()
+    naming_vectors()
     camera_vectors()
