@@ -31,6 +31,12 @@ container (it never ships; /root/reference does not exist on the GPU box):
 
   * lib/utils/utils.py (create_logger :22-57): the output-directory naming (naming_reference_outputs.npz).
 
+  * evaluate_pipeline.py (:9-94), run with subprocess.run replaced by a recorder: the command lines of the three stages
+    (driver_reference_commands.npz).
+
+  * the argparse surfaces of tools/test.py (parse_args() cut out with ast) and export_predicted_poses_real.py, and how they parse the
+    driver's command lines (cli_reference_surfaces.npz).
+
 Only data is written (npz): no reference source text.  Re-run: python tests/golden/make_golden.py
 """
 import importlib
@@ -313,6 +319,110 @@ def naming_vectors():
     print("naming vectors", rel_out, rel_log)
 
 
+def driver_vectors():
+    """The command lines the reference's driver issues (evaluate_pipeline.py:9-94, imported as a module and run with subprocess.run
+    replaced by a recorder, inside a scratch tree with two scene directories): per stage the working directory (relative to the
+    tree) and the argv -- the CLI contract tools/test.py and export_predicted_poses_real.py have to honour."""
+    import json
+    import subprocess
+    import tempfile
+    spec = importlib.util.spec_from_file_location("ref_evaluate_pipeline", os.path.join(os.path.dirname(REF), "evaluate_pipeline.py"))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    calls = []
+    cwd0 = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        d = os.path.join(os.path.realpath(d), "root")
+        for sub in ("object_detection", "landmark_regression", "pose_estimation", "data/scene_a/event-frames", "data/scene_b/event-frames",
+                    "../pose_estimation"):      # the driver leaves landmark_regression/ with chdir("../../pose_estimation") (:81): one level above the tree
+            os.makedirs(os.path.join(d, sub))
+        # the driver looks for the scenes at ../../<data_dir> from landmark_regression/ (:66): one level above the tree; give it that view too
+        real_listdir, real_isdir = os.listdir, os.path.isdir
+
+        def listdir(p):
+            return sorted(real_listdir(os.path.join(d, "data"))) if os.path.basename(os.path.normpath(p)) == "data" else real_listdir(p)
+
+        def isdir(p):
+            q = os.path.normpath(p)
+            return True if os.path.basename(os.path.dirname(q)) == "data" and os.path.basename(q).startswith("scene_") else real_isdir(p)
+        rec = lambda argv, **kw: calls.append((os.path.relpath(os.getcwd(), d), list(argv)))
+        argv = ["evaluate_pipeline.py", "--data_dir", "data", "--detection_model_file", "det.pth", "--regression_model_file", "models/reg.pth",
+                "--detection_annotations_base", "det_out", "--regression_annotations_base", "reg_out", "--pose_estimation_base", "pose_out",
+                "--validation_annotations", "val.json", "--landmarks_file", "landmarks.csv", "--calibration_file_path", "calib/calibration.json",
+                "--image_width", "1920", "--image_height", "1200", "--joints_count", "11"]
+        old = (sys.argv, subprocess.run, os.listdir, os.path.isdir)
+        try:
+            sys.argv = argv; drv.subprocess.run = rec; os.listdir = listdir; os.path.isdir = isdir
+            os.chdir(d)
+            drv.main()
+        finally:
+            sys.argv, drv.subprocess.run, os.listdir, os.path.isdir = old[0], old[1], old[2], old[3]
+            os.chdir(cwd0)
+    np.savez_compressed(os.path.join(HERE, "driver_reference_commands.npz"), argv=np.array(json.dumps(argv[1:])), calls=np.array(json.dumps(calls)))
+    for c in calls:
+        print(c[0], " ".join(c[1])[:200])
+
+
+def cli_vectors():
+    """The argparse surface of the two CLIs on the path -- landmark_regression/tools/test.py:35-66 (its parse_args() alone: the module
+    itself needs yacs / torchvision, so the function's source is cut out with `ast` and executed) and
+    pose_estimation/export_predicted_poses_real.py:127-148 (main() run up to parse_args) -- and how each parses the command line
+    the reference's driver issues (driver_reference_commands.npz)."""
+    import argparse
+    import ast
+    import json
+    surfaces, parsed = {}, {}
+
+    class Done(Exception):
+        pass
+
+    def surface(parser):
+        return [[list(a.option_strings) or [a.dest], bool(a.required), getattr(a.type, "__name__", None), a.nargs if a.nargs is None else str(a.nargs),
+                 a.default if isinstance(a.default, (str, int, float, type(None))) else None] for a in parser._actions if a.dest != "help"]
+    calls = json.loads(str(np.load(os.path.join(HERE, "driver_reference_commands.npz"))["calls"]))
+    real_parse = argparse.ArgumentParser.parse_args
+
+    def recorder(name, argv):
+        def parse(self, args=None, namespace=None):
+            surfaces[name] = surface(self)
+            parsed[name] = {k: v for k, v in vars(real_parse(self, argv)).items()}
+            raise Done()
+        return parse
+    # tools/test.py: parse_args() only
+    src = open(os.path.join(REF, "tools/test.py")).read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "parse_args")
+    ns = {"argparse": argparse}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "<tools/test.py: parse_args>", "exec"), ns)
+    argv1 = next(c[1] for c in calls if c[1][1] == "tools/test.py")[2:]
+    try:
+        argparse.ArgumentParser.parse_args = recorder("tools/test.py", argv1)
+        ns["parse_args"]()
+    except Done:
+        pass
+    finally:
+        argparse.ArgumentParser.parse_args = real_parse
+    # export_predicted_poses_real.py: main() up to parse_args
+    install_cv2_stub()
+    for name in ("kornia", "kornia.geometry", "kornia.geometry.conversions"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["kornia.geometry.conversions"].angle_axis_to_quaternion = None
+    sys.modules["kornia.geometry.conversions"].QuaternionCoeffOrder = None
+    spec = importlib.util.spec_from_file_location("ref_export_poses_cli", os.path.join(os.path.dirname(REF), "pose_estimation/export_predicted_poses_real.py"))
+    exp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(exp)
+    argv2 = next(c[1] for c in calls if c[1][1] == "export_predicted_poses_real.py")[2:]
+    try:
+        argparse.ArgumentParser.parse_args = recorder("export_predicted_poses_real.py", argv2)
+        exp.main()
+    except Done:
+        pass
+    finally:
+        argparse.ArgumentParser.parse_args = real_parse
+    np.savez_compressed(os.path.join(HERE, "cli_reference_surfaces.npz"), surfaces=np.array(json.dumps(surfaces)), parsed=np.array(json.dumps(parsed)),
+                        argv=np.array(json.dumps({"tools/test.py": argv1, "export_predicted_poses_real.py": argv2})))
+    print("cli surfaces", {k: len(v) for k, v in surfaces.items()}, parsed["tools/test.py"]["opts"][:4])
+
+
 def camera_vectors():
     """Camera model + confidence filter through the reference's own code (SURVEY.md section 8 a11, 8d, section 9 "PnP")."""
     import inspect
@@ -401,4 +511,6 @@ if __name__ == "__main__":
     affine_vectors()
     dataset_vectors()
     naming_vectors()
+    driver_vectors()
+    cli_vectors()
     camera_vectors()

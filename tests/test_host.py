@@ -383,3 +383,84 @@ def test_output_tree_naming_equals_the_reference_create_logger(tmp_path):
     for h in list(logging.getLogger().handlers):
         if h not in before:
             logging.getLogger().removeHandler(h); h.close()
+
+
+def test_driver_command_lines_follow_the_reference_driver(tmp_path, monkeypatch):
+    """evaluate_pipeline.py against the command lines the REFERENCE's driver issues (tests/golden/driver_reference_commands.npz: the
+    reference's evaluate_pipeline.py:62-91 run with subprocess.run replaced by a recorder): per scene the same script, the same
+    flags / yacs keys in the same order, equal literal values, and every path value naming the same file (the reference's value,
+    stripped of the leading '..' components its working-directory convention needs, is a suffix of the absolute path used here)."""
+    import importlib.util
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "driver_reference_commands.npz"))
+    ref_calls = [c for c in json.loads(str(g["calls"])) if "export_object_detection" not in c[1][1]]      # stage 1 is out of scope
+    spec = importlib.util.spec_from_file_location("our_evaluate_pipeline", os.path.join(ROOT, "evaluate_pipeline.py"))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    for sub in ("data/scene_a/event-frames", "data/scene_b/event-frames", "object_detection/det_out/scene_a", "object_detection/det_out/scene_b"):
+        os.makedirs(tmp_path / sub)
+    for sc in ("scene_a", "scene_b"):
+        (tmp_path / "object_detection" / "det_out" / sc / "test.json").write_text("{}")
+    calls = []
+    monkeypatch.setattr(drv, "run", lambda cmd, cwd: calls.append((os.path.basename(cwd), list(cmd))))
+    drv.main(["--data_dir", str(tmp_path / "data"), "--detection_model_file", "det.pth", "--regression_model_file", "models/reg.pth",
+              "--detection_annotations_base", str(tmp_path / "object_detection" / "det_out"),
+              "--regression_annotations_base", str(tmp_path / "landmark_regression" / "reg_out"),
+              "--pose_estimation_base", str(tmp_path / "pose_estimation" / "pose_out"), "--validation_annotations", "val.json",
+              "--landmarks_file", "landmarks.csv", "--calibration_file_path", "calib/calibration.json",
+              "--image_width", "1920", "--image_height", "1200", "--joints_count", "11"])
+    assert len(calls) == len(ref_calls) == 4
+    literal = {"DATASET.TEST_SET", "DATASET.TRAIN_SET", "DATASET.IMAGE_WIDTH", "DATASET.IMAGE_HEIGHT", "MODEL.NUM_JOINTS"}
+
+    def strip(p):
+        parts = [q for q in p.split("/") if q not in ("..", ".")]
+        return "/".join(parts)
+    for (cwd, cmd), (rcwd, rcmd) in zip(calls, ref_calls):
+        assert cwd == os.path.basename(rcwd)                                  # landmark_regression / pose_estimation
+        ours, ref = cmd[1:], rcmd[1:]                                         # [script, flag, value, ...] behind the interpreter
+        assert ours[0] == ref[0] and len(ours) == len(ref)
+        assert ours[1::2] == ref[1::2], (ours[1::2], ref[1::2])              # flags and yacs keys, in order
+        for key, a, b in zip(ref[1::2], ours[2::2], ref[2::2]):
+            if key in literal:
+                assert a == b, (key, a, b)
+            else:
+                assert os.path.isabs(a) and a.endswith("/" + strip(b)), (key, a, b)
+
+
+def test_cli_argparse_surfaces_cover_the_reference_clis(monkeypatch):
+    """landmark_regression/tools/test.py and pose_estimation/export_predicted_poses_real.py against the argparse surfaces of the
+    reference's scripts (tests/golden/cli_reference_surfaces.npz: tools/test.py:35-66, export_predicted_poses_real.py:127-148): every
+    reference option exists here with the same flags, required-ness, type, nargs and default (extensions are extra, optional flags),
+    and the command lines the reference's driver issues parse to the same values."""
+    import argparse
+    import importlib.util
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cli_reference_surfaces.npz"))
+    surfaces, parsed, argv = (json.loads(str(g[k])) for k in ("surfaces", "parsed", "argv"))
+
+    class Done(Exception):
+        pass
+    got = {}
+    real_parse = argparse.ArgumentParser.parse_args
+
+    def surface(parser):
+        return [[list(a.option_strings) or [a.dest], bool(a.required), getattr(a.type, "__name__", None), a.nargs if a.nargs is None else str(a.nargs),
+                 a.default if isinstance(a.default, (str, int, float, type(None))) else None] for a in parser._actions if a.dest != "help"]
+    for name, path in (("tools/test.py", "landmark_regression/tools/test.py"), ("export_predicted_poses_real.py", "pose_estimation/export_predicted_poses_real.py")):
+        def parse(self, args=None, namespace=None, _n=name):
+            got[_n] = (surface(self), vars(real_parse(self, argv[_n])))
+            raise Done()
+        monkeypatch.setattr(argparse.ArgumentParser, "parse_args", parse)
+        spec = importlib.util.spec_from_file_location("cli_" + name.replace("/", "_").replace(".", "_"), os.path.join(ROOT, path))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        with pytest.raises(Done):
+            (mod.parse_args if hasattr(mod, "parse_args") else mod.main)()
+        monkeypatch.setattr(argparse.ArgumentParser, "parse_args", real_parse)
+        ours, vals = got[name]
+        for opt in surfaces[name]:
+            assert opt in ours, "%s: reference option %s is missing or differs (have %s)" % (name, opt, ours)
+        for extra in (o for o in ours if o not in surfaces[name]):
+            assert extra[1] is False, "%s: an extension option must not be required: %s" % (name, extra)
+        for k, v in parsed[name].items():
+            assert vals[k] == v, (name, k, vals[k], v)
