@@ -37,6 +37,8 @@ container (it never ships; /root/reference does not exist on the GPU box):
   * the argparse surfaces of tools/test.py (parse_args() cut out with ast) and export_predicted_poses_real.py, and how they parse the
     driver's command lines (cli_reference_surfaces.npz).
 
+  * lib/config/default.py (:17-142), imported under a stand-in for yacs: every default key and value (config_reference_defaults.npz).
+
 Only data is written (npz): no reference source text.  Re-run: python tests/golden/make_golden.py
 """
 import importlib
@@ -423,6 +425,47 @@ def cli_vectors():
     print("cli surfaces", {k: len(v) for k, v in surfaces.items()}, parsed["tools/test.py"]["opts"][:4])
 
 
+def config_vectors():
+    """Every default key of lib/config/default.py:17-142 and its value: the module is imported under a stand-in for yacs (a dict with
+    attribute access -- default.py only assigns attributes on CfgNode objects at import time), and the tree is dumped."""
+    import json
+
+    class CN(dict):
+        def __init__(self, init=None, new_allowed=False):
+            super().__init__(init or {})
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+    yacs = types.ModuleType("yacs"); yc = types.ModuleType("yacs.config"); yc.CfgNode = CN; yacs.config = yc
+    old = {k: sys.modules.get(k) for k in ("yacs", "yacs.config")}
+    sys.modules["yacs"], sys.modules["yacs.config"] = yacs, yc
+    try:
+        spec = importlib.util.spec_from_file_location("ref_config_default", os.path.join(REF, "lib/config/default.py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+    def plain(x):
+        if isinstance(x, dict):
+            return {k: plain(v) for k, v in x.items()}
+        if isinstance(x, tuple):
+            return {"__tuple__": [plain(v) for v in x]}
+        if isinstance(x, list):
+            return [plain(v) for v in x]
+        return x
+    tree = plain(m._C)
+    import yaml
+    with open(os.path.join(REF, "experiments/events/events-config.yaml")) as fh:      # the experiment file the driver names (:70): its parsed content (data)
+        events_yaml = yaml.safe_load(fh)
+    np.savez_compressed(os.path.join(HERE, "config_reference_defaults.npz"), defaults=np.array(json.dumps(tree)), events_yaml=np.array(json.dumps(events_yaml)))
+    n = sum(1 for _ in json.dumps(tree).split(":")) - 1
+    print("config defaults: %d top-level keys, ~%d entries" % (len(tree), n))
+
+
 def camera_vectors():
     """Camera model + confidence filter through the reference's own code (SURVEY.md section 8 a11, 8d, section 9 "PnP")."""
     import inspect
@@ -513,4 +556,5 @@ if __name__ == "__main__":
     naming_vectors()
     driver_vectors()
     cli_vectors()
+    config_vectors()
     camera_vectors()

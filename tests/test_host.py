@@ -464,3 +464,75 @@ def test_cli_argparse_surfaces_cover_the_reference_clis(monkeypatch):
             assert extra[1] is False, "%s: an extension option must not be required: %s" % (name, extra)
         for k, v in parsed[name].items():
             assert vals[k] == v, (name, k, vals[k], v)
+
+
+def test_config_defaults_equal_the_reference_default_py():
+    """config._defaults() against every key and value of the reference's lib/config/default.py:17-142
+    (tests/golden/config_reference_defaults.npz, dumped by importing the module under a stand-in for yacs): same tree, same
+    values, same tuple-vs-list kinds -- so every YAML and KEY VAL override the reference accepts is accepted here."""
+    import numpy as np
+    import scpose  # noqa: F401
+    from importlib import import_module
+    C = import_module("spacecraft-pose-estimation_amd.config")
+    want = json.loads(str(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_reference_defaults.npz"))["defaults"]))
+    cfg = C._defaults()
+    missing, differs = [], []
+
+    def walk(w, node, path):
+        for k, v in w.items():
+            p = path + [k]
+            try:
+                have = node[k] if isinstance(node, dict) else getattr(node, k)
+            except (KeyError, AttributeError):
+                missing.append(".".join(p)); continue
+            if isinstance(v, dict) and "__tuple__" not in v:
+                walk(v, have, p)
+            else:
+                exp = tuple(v["__tuple__"]) if isinstance(v, dict) else v
+                got = have
+                if isinstance(exp, tuple):
+                    if not (isinstance(got, tuple) and tuple(got) == exp):
+                        differs.append((".".join(p), got, exp))
+                elif isinstance(exp, list):
+                    if list(got) != exp:
+                        differs.append((".".join(p), got, exp))
+                elif got != exp or type(got) is not type(exp):
+                    differs.append((".".join(p), got, exp))
+    walk(want, cfg, [])
+    assert not missing, "default keys of the reference that config._defaults() lacks: %s" % missing
+    assert not differs, "default values that differ: %s" % differs[:10]
+    # the experiment file evaluate_pipeline.py:70 names.  (a) the REFERENCE's own file content (stored as parsed data) merges into this config
+    # unchanged -- training, debug and cuDNN keys included -- and every value arrives; (b) the shipped copy is that file restricted to
+    # the inference path: wherever both have a key the values agree, except the three the copy deliberately neutralises.
+    import yaml
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_reference_defaults.npz"))
+    ref_yaml = json.loads(str(g["events_yaml"]))
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as fh:
+        yaml.safe_dump(ref_yaml, fh)
+    try:
+        C.update_config(cfg, types.SimpleNamespace(cfg=fh.name, opts=["MODEL.NUM_JOINTS", "11", "GPUS", "(0,)"], modelDir="", logDir="", dataDir=""))
+    finally:
+        os.unlink(fh.name)
+    assert cfg.MODEL.NUM_JOINTS == 11 and tuple(cfg.GPUS) == (0,) and cfg.WORKERS == ref_yaml["WORKERS"] == 0
+
+    def arrived(w, node, path):
+        for k, v in w.items():
+            have = node[k] if isinstance(node, dict) else getattr(node, k)
+            if isinstance(v, dict):
+                arrived(v, have, path + [k])
+            elif path + [k] not in (["MODEL", "NUM_JOINTS"], ["GPUS"]):
+                assert (list(have) == list(v)) if isinstance(v, list) else (have == v or str(have) == str(v)), (".".join(path + [k]), have, v)
+    arrived(ref_yaml, cfg, [])
+    with open(os.path.join(ROOT, "landmark_regression", "experiments", "events", "events-config.yaml")) as fh2:
+        ours = yaml.safe_load(fh2)
+    neutralised = {"DEBUG.DEBUG", "TEST.MODEL_FILE", "DATA_DIR", "MODEL.EXTRA.PRETRAINED_LAYERS"}     # debug dumps off, no personal paths, load every layer
+
+    def common(a, b, path):
+        for k in a:
+            if k in b:
+                if isinstance(a[k], dict) and isinstance(b[k], dict):
+                    common(a[k], b[k], path + [k])
+                elif ".".join(path + [k]) not in neutralised:
+                    assert a[k] == b[k], (".".join(path + [k]), a[k], b[k])
+    common(ours, ref_yaml, [])
