@@ -98,5 +98,4 @@ def test_validate_equals_the_reference_validate(scpose, gpu_ops, mode):
             assert ma and mb and ma.group(1, 2, 5, 6) == mb.group(1, 2, 5, 6), (a, b)       # batch index / count and both accuracies
             assert abs(float(ma.group(3)) - float(mb.group(3))) <= 1e-4 and abs(float(ma.group(4)) - float(mb.group(4))) <= 1e-4   # losses as printed (.4f)
     else:
-        assert "validate: fused forward -> key-point path" in " ".join(l for l in [r.getMessage() if hasattr(r, "getMessage") else r for r in lines] + ["validate: fused forward -> key-point path"])
         assert lines[-3:] == ref_lines[-3:]
