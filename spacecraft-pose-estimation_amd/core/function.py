@@ -129,7 +129,7 @@ def _run(config, val_loader, val_dataset, models, criterion, output_dir, pred_fi
             local_preds.append(xyc)
             boxes = torch.zeros((num_images, 6), dtype=torch.float64)
             boxes[:, 0:2] = c[:, 0:2].double(); boxes[:, 2:4] = s[:, 0:2].double()
-            boxes[:, 4] = torch.prod(s.double() * 200, 1); boxes[:, 5] = score
+            boxes[:, 4] = torch.prod(s * 200, 1).double(); boxes[:, 5] = score     # np.prod(s * 200, 1) on the float32 scales (:397): float32 arithmetic
             local_boxes.append(boxes)
             image_path.extend(meta["image"])
             batch_time.update(time.time() - end)
