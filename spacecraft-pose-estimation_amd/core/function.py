@@ -61,15 +61,16 @@ def validate_cv(config, val_loader, val_dataset, models, criterion, output_dir, 
                 writer_dict=None, log_metrics=True):
     if not models:
         raise ValueError("validate_cv: no model given (none of TEST.MODEL_FILE .. MODEL_FILE6 exists?)")
+    # (:500-592 logs every fifth batch whatever PRINT_FREQ says, and does not print the name_values table)
     return _run(config, val_loader, val_dataset, list(models), criterion, output_dir, pred_file_name, log_metrics,
-                flip_test=False)
+                flip_test=False, print_freq=5, print_table=False)
 
 
 def _last(outputs):
     return outputs[-1] if isinstance(outputs, (list, tuple)) else outputs
 
 
-def _run(config, val_loader, val_dataset, models, criterion, output_dir, pred_file_name, log_metrics, flip_test):
+def _run(config, val_loader, val_dataset, models, criterion, output_dir, pred_file_name, log_metrics, flip_test, print_freq=None, print_table=True):
     batch_time, losses, acc = AverageMeter(), AverageMeter(), AverageMeter()
     for m in models:
         m.eval()
@@ -134,7 +135,7 @@ def _run(config, val_loader, val_dataset, models, criterion, output_dir, pred_fi
             image_path.extend(meta["image"])
             batch_time.update(time.time() - end)
             end = time.time()
-            if i % config.PRINT_FREQ == 0:
+            if i % (print_freq or config.PRINT_FREQ) == 0:
                 logger.info("Test: [{0}/{1}]\tTime {bt.val:.3f} ({bt.avg:.3f})\tLoss {loss.val:.4f} ({loss.avg:.4f})\t"
                             "Accuracy {acc.val:.3f} ({acc.avg:.3f})".format(i, len(val_loader), bt=batch_time, loss=losses, acc=acc))
         preds_d = torch.cat(local_preds, 0) if local_preds else torch.zeros((0, config.MODEL.NUM_JOINTS, 3), device=dev)
@@ -151,6 +152,6 @@ def _run(config, val_loader, val_dataset, models, criterion, output_dir, pred_fi
             name_values, perf_indicator = val_dataset.evaluate(config, all_preds, output_dir, pred_file_name, all_boxes,
                                                                image_path, [], [])
             model_name = config.MODEL.NAME
-            for nv in (name_values if isinstance(name_values, list) else [name_values]):
+            for nv in (name_values if isinstance(name_values, list) else [name_values]) if print_table else []:
                 _print_name_value(nv, model_name)
     return perf_indicator

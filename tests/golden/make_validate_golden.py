@@ -10,7 +10,8 @@ fitted chain checkpoint tests/golden/chain_checkpoint.npz, strict load), its Joi
 all_preds / all_boxes assembly, its log lines.  Inputs: the 64 decisive frames of the chain fixture as normalised float32 crops in
 batches of 12 (the last one ragged), gaussian targets at the drawn positions, scores 0.5 .. 1, TEST.FLIP_TEST off.
 
-Stored: all_preds (N, J, 3), all_boxes (N, 6), image_path, the averaged loss / accuracy, the log lines.  Only data is written.
+Stored: all_preds (N, J, 3), all_boxes (N, 6), image_path, the averaged loss / accuracy, the log lines -- and the same for `validate_cv()`
+(:500-592, the ensemble loop of tools/test_cv_ensemble.py) over three members (the checkpoint with its final layer scaled by 0.8 / 1.0 / 1.3).  Only data is written.
 Re-run: python tests/golden/make_validate_golden.py"""
 import importlib
 import logging
@@ -31,6 +32,7 @@ import make_golden as MG  # noqa: E402
 
 syn = importlib.import_module("spacecraft-pose-estimation_amd.synthetic")
 BATCH = 12
+CV_SCALES = (0.8, 1.0, 1.3)
 MEAN = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
 STD = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
 
@@ -95,18 +97,32 @@ def main():
         def __init__(self):
             super().__init__(); meters.append(self)
     fn.AverageMeter = Meter
+    import re
     cuda = torch.Tensor.cuda
     torch.Tensor.cuda = lambda self, *a, **k: self
+    out = {}
     try:
         perf = fn.validate(config, batches, DS(), net, loss_mod.JointsMSELoss(use_target_weight=True), "/tmp", "/tmp", pred_file_name="pred_test")
+        out.update(preds=got["preds"], boxes=got["boxes"], image_path=np.array(got["image_path"]), pred_file_name=np.array(got["pred_file_name"]),
+                   perf=np.array(perf), loss_avg=np.array(meters[1].avg), acc_avg=np.array(meters[2].avg),
+                   log=np.array([re.sub(r"Time \S+ \(\S+\)", "Time T (T)", l) for l in lines]), batch=np.array(BATCH))
+        print("validate(): %d frames, loss %.6f, accuracy %.4f; %d log lines, e.g. %r" % (n, meters[1].avg, meters[2].avg, len(lines), lines[0]))
+        # ---- validate_cv (:500-592, tools/test_cv_ensemble.py): three members = the checkpoint with its final layer scaled by 0.8 / 1.0 / 1.3 ----
+        nets = []
+        for f in CV_SCALES:
+            m = MG.ref_pose_hrnet().get_pose_net(cfg, False)
+            sd = syn.load_chain_checkpoint(os.path.join(HERE, "chain_checkpoint.npz"))
+            sd["final_layer.weight"] = sd["final_layer.weight"] * f; sd["final_layer.bias"] = sd["final_layer.bias"] * f
+            m.load_state_dict(sd, strict=True)
+            nets.append(m)
+        del lines[:]; del meters[:]; got.clear()
+        perf = fn.validate_cv(config, batches, DS(), nets, loss_mod.JointsMSELoss(use_target_weight=True), "/tmp", "/tmp", "pred_real")
+        out.update(cv_preds=got["preds"], cv_boxes=got["boxes"], cv_pred_file_name=np.array(got["pred_file_name"]), cv_perf=np.array(perf),
+                   cv_log=np.array([re.sub(r"Time \S+ \(\S+\)", "Time T (T)", l) for l in lines]), cv_scales=np.array(CV_SCALES))
+        print("validate_cv(): loss %.6f, accuracy %.4f; log lines %r" % (meters[1].avg, meters[2].avg, lines))
     finally:
         torch.Tensor.cuda = cuda; fn.AverageMeter = real_meter; fn.logger.removeHandler(h)
-    import re
-    lines = [re.sub(r"Time \S+ \(\S+\)", "Time T (T)", l) for l in lines]
-    np.savez_compressed(os.path.join(HERE, "validate_reference_outputs.npz"), preds=got["preds"], boxes=got["boxes"], image_path=np.array(got["image_path"]),
-                        pred_file_name=np.array(got["pred_file_name"]), perf=np.array(perf), loss_avg=np.array(meters[1].avg), acc_avg=np.array(meters[2].avg),
-                        log=np.array(lines), batch=np.array(BATCH))
-    print("validate(): %d frames, loss %.6f, accuracy %.4f; %d log lines, e.g. %r" % (n, meters[1].avg, meters[2].avg, len(lines), lines[0]))
+    np.savez_compressed(os.path.join(HERE, "validate_reference_outputs.npz"), **out)
 
 
 if __name__ == "__main__":
