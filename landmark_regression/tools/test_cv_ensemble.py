@@ -50,6 +50,9 @@ def parse_args():
                         help="(extension, the default) warp the crops on the GPU (scpose_crop_warp): the loader only decodes the frames")
     parser.add_argument("--host_crop", dest="device_crop", action="store_false",
                         help="(extension) warp and normalise the crops in the data loader, as the reference does")
+    parser.add_argument("--loader_threads", type=int, default=0,
+                        help="(extension) decode the frames with N threads of this process (parallel.ThreadedLoader) instead of cfg.WORKERS "
+                             "DataLoader worker processes: no start-up, no inter-process copies")
     parser.add_argument("--log_metrics", action="store_true",
                         help="(extension) compute the loss / PCK the reference logs per batch; they need the heat-maps, so the forward "
                              "then writes them instead of handing key points out of its last kernel (same pred .mat, bit for bit)")
@@ -93,6 +96,10 @@ def main():
                                                # workers come from a clean fork server, never from this process: it has initialised HIP
                                                multiprocessing_context=parallel.loader_worker_context(cfg.WORKERS),
                                                collate_fn=valid_dataset.collate_device_crop if args.device_crop else None)
+    if args.loader_threads > 0:
+        valid_loader = parallel.ThreadedLoader(valid_dataset, cfg.TEST.BATCH_SIZE_PER_GPU * len(cfg.GPUS), args.loader_threads,
+                                               collate_fn=valid_dataset.collate_device_crop if args.device_crop else None,
+                                               indices=range(lo, hi) if ws > 1 else None)
     validate_cv(cfg, valid_loader, valid_dataset, cv_models, criterion, final_output_dir, tb_log_dir, "pred_real",
                 log_metrics=bool(args.log_metrics))
 

@@ -163,3 +163,37 @@ def spawn_local_ranks(argv, nprocs, env=None, timeout=None):
         import shutil
         shutil.rmtree(rdzv_dir, ignore_errors=True)
     return worst
+
+
+class ThreadedLoader:
+    """A batch iterator over a map-style dataset that decodes with THREADS of this process instead of DataLoader worker processes.
+
+    Why: with GPU crop warp the loader's work per frame is image decoding (PIL releases the GIL while it decodes and converts) plus a
+    slice; worker processes pay for it twice more -- every batch is pickled through shared memory into the main process, and the
+    workers must never be forked from a process that holds a HIP context (loader_worker_context).  Threads share the address space: no
+    copies, no start-up, and the pool scales to the host's cores.  Order is the dataset's (`shuffle=False` semantics), batches are
+    collated with `collate_fn` (default: torch's default_collate), `prefetch` batches are decoded ahead of the consumer."""
+
+    def __init__(self, dataset, batch_size, threads, collate_fn=None, prefetch=4, indices=None):
+        self.dataset, self.batch_size, self.threads, self.prefetch = dataset, int(batch_size), max(1, int(threads)), max(1, int(prefetch))
+        self.indices = list(range(len(dataset))) if indices is None else list(indices)
+        if collate_fn is None:
+            from torch.utils.data import default_collate
+            collate_fn = default_collate
+        self.collate_fn = collate_fn
+
+    def __len__(self):
+        return (len(self.indices) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        batches = [self.indices[i:i + self.batch_size] for i in range(0, len(self.indices), self.batch_size)]
+        with ThreadPoolExecutor(self.threads) as pool:
+            pending = deque()
+            nxt = 0
+            while nxt < len(batches) or pending:
+                while nxt < len(batches) and len(pending) < self.prefetch:
+                    pending.append([pool.submit(self.dataset.__getitem__, k) for k in batches[nxt]])
+                    nxt += 1
+                yield self.collate_fn([f.result() for f in pending.popleft()])

@@ -238,6 +238,11 @@ def test_cli_tools_test_and_pose_export(pk, tmp_path):
     assert np.array_equal(preds_w, preds)
     preds_w, _ = run("workers2_host_crop", ["--host_crop"], "4", workers="2")
     assert np.array_equal(preds_w, preds)
+    # ... or the frames are decoded by threads of the CLI's own process (parallel.ThreadedLoader)
+    preds_w, _ = run("threads3", ["--loader_threads", "3"], "4")
+    assert np.array_equal(preds_w, preds)
+    preds_w, _ = run("threads2_ref_flow", ["--loader_threads", "2", "--host_crop", "--log_metrics"], "4")
+    assert np.array_equal(preds_w, preds)
 
     # stage 3 on known-answer keypoints written in the same .mat format
     kp, Rs, ts = P.synth_keypoints(6, np.random.default_rng(4), 0.5, 0.0)
