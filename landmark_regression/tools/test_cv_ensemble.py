@@ -92,7 +92,7 @@ def main():
     valid_dataset.device_crop = bool(args.device_crop)
     valid_dataset.want_target = bool(args.log_metrics)     # gaussian targets feed the logged loss / PCK only
     valid_loader = torch.utils.data.DataLoader(subset, batch_size=cfg.TEST.BATCH_SIZE_PER_GPU * len(cfg.GPUS),
-                                               shuffle=False, num_workers=cfg.WORKERS, pin_memory=not args.device_crop,
+                                               shuffle=False, num_workers=cfg.WORKERS, pin_memory=True,   # (the packed frame windows too: a background thread pins them, the copy to the device is then asynchronous)
                                                # workers come from a clean fork server, never from this process: it has initialised HIP
                                                multiprocessing_context=parallel.loader_worker_context(cfg.WORKERS),
                                                collate_fn=valid_dataset.collate_device_crop if args.device_crop else None)

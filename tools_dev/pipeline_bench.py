@@ -102,12 +102,12 @@ def run(frames=2048, workers=8, batch=64, model="w48", keep=None, mp_ctx="forkse
     net = net.cuda().eval()
     tf = transforms.Compose([transforms.ToTensor(), transforms.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])])
 
-    def loader(device_crop, nworkers, want_target, threads=0):
+    def loader(device_crop, nworkers, want_target, threads=0, pin=True):
         ds = getattr(dataset, cfg.DATASET.DATASET)(cfg, cfg.DATASET.ROOT, cfg.DATA_DIR, cfg.DATASET.TEST_SET, False, tf)
         ds.device_crop = device_crop; ds.want_target = want_target
         if threads > 0:      # tools/test.py --loader_threads N: decoding threads of this process instead of worker processes
             return ds, parallel.ThreadedLoader(ds, batch, threads, collate_fn=ds.collate_device_crop if device_crop else None)
-        return ds, torch.utils.data.DataLoader(ds, batch_size=batch, shuffle=False, num_workers=nworkers, pin_memory=not device_crop,
+        return ds, torch.utils.data.DataLoader(ds, batch_size=batch, shuffle=False, num_workers=nworkers, pin_memory=pin,
                                                # as tools/test.py: workers from a clean, pre-loaded fork server, never forked from this (HIP) process
                                                multiprocessing_context=(parallel.loader_worker_context(nworkers) if mp_ctx == "forkserver" else mp_ctx) if nworkers > 0 else None,
                                                collate_fn=ds.collate_device_crop if device_crop else None)
@@ -157,9 +157,9 @@ def run(frames=2048, workers=8, batch=64, model="w48", keep=None, mp_ctx="forkse
     out["one_off_engine_build_and_capture_s"] = round(time.perf_counter() - t0, 2)
     more = [workers] + ([4 * workers] if (os.cpu_count() or 1) >= 8 * workers else [])
     thr = [t for t in (16, 64) if (os.cpu_count() or 1) >= t] or [os.cpu_count() or 1]
-    for tag, dc, nw, nt in [("product_device_crop_workers%d" % w, True, w, 0) for w in more] + [("product_device_crop_workers0", True, 0, 0)] + \
-                           [("product_device_crop_threads%d" % t, True, 0, t) for t in thr]:
-        ds, ld = loader(dc, nw, False, nt)
+    for tag, dc, nw, nt, pin in [("product_device_crop_workers%d" % w, True, w, 0, True) for w in more] + [("product_device_crop_workers0", True, 0, 0, True)] + \
+                                [("product_device_crop_threads%d" % t, True, 0, t, True) for t in thr] + [("product_device_crop_workers%d_unpinned" % workers, True, workers, 0, False)]:
+        ds, ld = loader(dc, nw, False, nt, pin)
         ts = time.perf_counter()
         started = _Started(ld)        # workers up and the first batch decoded: start-up is reported separately, the clock starts behind it
         t_start = time.perf_counter() - ts
