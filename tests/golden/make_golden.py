@@ -39,6 +39,9 @@ container (it never ships; /root/reference does not exist on the GPU box):
 
   * lib/config/default.py (:17-142), imported under a stand-in for yacs: every default key and value (config_reference_defaults.npz).
 
+  * pose_estimation/export_predicted_poses_real.py main() (:126-236) run with cv2 replaced by a recorder that answers with this
+    repository's C oracle: the call contract of solvePnPRansac, the JSON it writes, the overlay names (export_reference_outputs.npz).
+
 Only data is written (npz): no reference source text.  Re-run: python tests/golden/make_golden.py
 """
 import importlib
@@ -466,6 +469,81 @@ def config_vectors():
     print("config defaults: %d top-level keys, ~%d entries" % (len(tree), n))
 
 
+def export_vectors():
+    """The host loop of pose_estimation/export_predicted_poses_real.py:126-236 -- main() ITSELF, run on a scratch scene with `cv2` replaced by a
+    recorder: solvePnPRansac records its arguments (what the reference hands to OpenCV per frame: which landmarks, dtypes, flags) and
+    answers with this repository's C oracle on exactly those arguments, Rodrigues is the oracle's, imread / rectangle / circle /
+    imwrite do nothing but note the file names.  Stored: the scene's inputs, every recorded call, the opencv_poses.json text the
+    reference wrote and the overlay names.  (cv2.solvePnPRansac's internals stay unpinned; its call contract and everything around it
+    are the reference's own code.)"""
+    import json
+    import tempfile
+    from scipy.io import savemat
+    from oracle import pnp_ref as P
+    for name in ("kornia", "kornia.geometry", "kornia.geometry.conversions"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["kornia.geometry.conversions"].angle_axis_to_quaternion = None
+    sys.modules["kornia.geometry.conversions"].QuaternionCoeffOrder = None
+    calls, written = [], []
+    cv2 = types.ModuleType("cv2")
+    cv2.SOLVEPNP_EPNP = 1
+
+    def solvePnPRansac(obj, img, K, distCoeffs=None, flags=None, iterationsCount=None, reprojectionError=None, **kw):
+        calls.append({"obj": np.array(obj), "img": np.array(img), "img_dtype": str(np.asarray(img).dtype), "obj_dtype": str(np.asarray(obj).dtype),
+                      "K": np.array(K), "dist": np.array(distCoeffs), "flags": flags, "iters": iterationsCount, "err": reprojectionError, "extra": sorted(kw)})
+        kp = np.concatenate([np.asarray(img, np.float32), np.ones((len(img), 1), np.float32)], 1)[None]
+        o = P.solve_batch(kp, landmarks=np.asarray(obj, np.float64), K=np.asarray(K), dist=np.asarray(distCoeffs), min_pts=0,
+                          max_iters=iterationsCount, reproj_err=reprojectionError)
+        return o["status"][0] > 0, o["rvec"][0].reshape(3, 1), o["t"][0].reshape(3, 1), None
+    cv2.solvePnPRansac = solvePnPRansac
+    cv2.Rodrigues = lambda rv: (P.rodrigues(np.asarray(rv, np.float64).reshape(3)), None)
+    cv2.imread = lambda path: np.zeros((4, 4, 3), np.uint8)
+    cv2.rectangle = lambda img, a, b, c, t: img
+    cv2.circle = lambda img, c, radius=0, color=0, thickness=0: img
+    cv2.imwrite = lambda path, img: written.append(os.path.basename(path)) or True
+    old_cv2 = sys.modules.get("cv2")
+    sys.modules["cv2"] = cv2
+    try:
+        spec = importlib.util.spec_from_file_location("ref_export_loop", os.path.join(os.path.dirname(REF), "pose_estimation/export_predicted_poses_real.py"))
+        exp = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(exp)
+        rng = np.random.default_rng(31)
+        n = 7
+        kp, Rs, ts = P.synth_keypoints(n, rng, 0.7, 0.0)
+        kp[:, :, 2] = rng.uniform(0.3, 1.0, (n, 11)).astype(np.float32)
+        kp[2, 5:, 2] = 1e-12                                  # a frame with five usable landmarks
+        names = ["scene/img_%03d.png" % (10 - i) for i in range(n)]        # ids not in order, names with a directory part and a dot
+        ids = [50 - 3 * i for i in range(n)]
+        with tempfile.TemporaryDirectory() as d:
+            det = {"images": [{"id": ids[i], "file_name": names[i], "width": 1920, "height": 1200} for i in range(n)],
+                   "annotations": [{"image_id": ids[i], "bbox": [100.5 + i, 200.25, 300.75, 250.0], "keypoints": [0] * 33, "id": i, "category_id": 1} for i in range(n)]}
+            json.dump(det, open(os.path.join(d, "det.json"), "w"))
+            savemat(os.path.join(d, "pred.mat"), {"preds": kp})
+            open(os.path.join(d, "landmarks.csv"), "w").write("x,y,z\n" + "\n".join(",".join(repr(float(v)) for v in r) for r in P.LANDMARKS))
+            json.dump({"intrinsics": {"camera_matrix": P.CAMERA_K.tolist(), "distortion_coefficients": P.CAMERA_DIST.tolist()}}, open(os.path.join(d, "calib.json"), "w"))
+            argv = sys.argv
+            sys.argv = ["export_predicted_poses_real.py", "--frames_dir", os.path.join(d, "frames"), "--detection_annotations", os.path.join(d, "det.json"),
+                        "--pose_annotations", os.path.join(d, "pred.mat"), "--landmarks_file", os.path.join(d, "landmarks.csv"),
+                        "--calibration_file_path", os.path.join(d, "calib.json"), "--output_dir", os.path.join(d, "out")]
+            try:
+                exp.main()
+            finally:
+                sys.argv = argv
+            text = open(os.path.join(d, "out", "opencv_poses.json")).read()
+    finally:
+        if old_cv2 is None:
+            sys.modules.pop("cv2", None)
+        else:
+            sys.modules["cv2"] = old_cv2
+    out = {"preds": kp, "det": np.array(json.dumps(det)), "json_text": np.array(text), "overlays": np.array(written), "ncalls": np.array(len(calls)),
+           "flags": np.array([c["flags"] for c in calls]), "iters": np.array([c["iters"] for c in calls]), "err": np.array([c["err"] for c in calls]),
+           "img_dtype": np.array([c["img_dtype"] for c in calls]), "obj_dtype": np.array([c["obj_dtype"] for c in calls]), "extra": np.array(json.dumps([c["extra"] for c in calls])),
+           "K": calls[0]["K"], "dist": calls[0]["dist"], "npts": np.array([len(c["img"]) for c in calls]),
+           "img_points": np.concatenate([c["img"] for c in calls]), "obj_points": np.concatenate([c["obj"] for c in calls])}
+    np.savez_compressed(os.path.join(HERE, "export_reference_outputs.npz"), **out)
+    print("export loop: %d solvePnPRansac calls, points per call %s, %d overlays, json %d bytes" % (len(calls), out["npts"].tolist(), len(written), len(text)))
+
+
 def camera_vectors():
     """Camera model + confidence filter through the reference's own code (SURVEY.md section 8 a11, 8d, section 9 "PnP")."""
     import inspect
@@ -558,3 +636,4 @@ if __name__ == "__main__":
     cli_vectors()
     config_vectors()
     camera_vectors()
+    export_vectors()

@@ -420,3 +420,21 @@ def test_cli_files_to_poses_recovers_the_rendered_poses_w48(pk, tmp_path):
     ang = P.rot_angle(Rg, sc["R"]); terr = np.linalg.norm(tg - sc["t"], axis=1) / np.linalg.norm(sc["t"], axis=1)
     print("files -> poses vs the rendered poses: rotation max %.2e rad, translation max %.2e" % (ang.max(), terr.max()))
     assert ang.max() < 5e-2 and terr.max() < 2e-2
+
+
+def test_pose_export_on_the_gpu_equals_the_reference_main_output(pk, tmp_path):
+    """The same scene as tests/test_host.py::test_pose_export_writes_what_the_reference_main_writes, with the real kernel: the poses in
+    opencv_poses.json are those the reference's main() wrote (its cv2 answered by the C oracle) to 1e-4 rad / 1e-4, record for record."""
+    from test_host import _export_scene
+    g = np.load(os.path.join(ROOT, "tests", "golden", "export_reference_outputs.npz"))
+    _export_scene(tmp_path, g, with_frames=False)
+    cmd = [sys.executable, "export_predicted_poses_real.py", "--frames_dir", str(tmp_path / "frames"), "--detection_annotations", str(tmp_path / "det.json"),
+           "--pose_annotations", str(tmp_path / "pred.mat"), "--landmarks_file", str(tmp_path / "landmarks.csv"),
+           "--calibration_file_path", str(tmp_path / "calib.json"), "--output_dir", str(tmp_path / "out")]
+    r = subprocess.run(cmd, cwd=os.path.join(ROOT, "pose_estimation"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = json.load(open(tmp_path / "out" / "opencv_poses.json")); ref = json.loads(str(g["json_text"]))
+    assert [q["image_name"] for q in got] == [q["image_name"] for q in ref] and all(list(a) == list(b) for a, b in zip(got, ref))
+    Rg = np.array([q["rotation_matrix"] for q in got]); Rr = np.array([q["rotation_matrix"] for q in ref])
+    tg = np.array([q["T"] for q in got]).reshape(-1, 3); tr_ = np.array([q["T"] for q in ref]).reshape(-1, 3)
+    assert P.rot_angle(Rg, Rr).max() <= 1e-4 and (np.linalg.norm(tg - tr_, axis=1) / np.linalg.norm(tr_, axis=1)).max() <= 1e-4

@@ -536,3 +536,60 @@ def test_config_defaults_equal_the_reference_default_py():
                 elif ".".join(path + [k]) not in neutralised:
                     assert a[k] == b[k], (".".join(path + [k]), a[k], b[k])
     common(ours, ref_yaml, [])
+
+
+def _export_scene(tmp_path, g, with_frames):
+    from PIL import Image
+    from scipy.io import savemat
+    from oracle import pnp_ref as P
+    det = json.loads(str(g["det"]))
+    (tmp_path / "det.json").write_text(json.dumps(det))
+    savemat(tmp_path / "pred.mat", {"preds": g["preds"]})
+    (tmp_path / "landmarks.csv").write_text("x,y,z\n" + "\n".join(",".join(repr(float(v)) for v in r) for r in P.LANDMARKS))
+    (tmp_path / "calib.json").write_text(json.dumps({"intrinsics": {"camera_matrix": P.CAMERA_K.tolist(), "distortion_coefficients": P.CAMERA_DIST.tolist()}}))
+    if with_frames:
+        for im in det["images"]:
+            f = tmp_path / "frames" / im["file_name"]
+            f.parent.mkdir(parents=True, exist_ok=True)
+            Image.fromarray(np.zeros((24, 32, 3), np.uint8)).save(f)
+    return det
+
+
+def test_pose_export_writes_what_the_reference_main_writes(tmp_path, monkeypatch):
+    """pose_export.export against the reference's own export_predicted_poses_real.py main() (:126-236), run on a scratch scene with cv2
+    replaced by a recorder (tests/golden/export_reference_outputs.npz): given the poses, opencv_poses.json is the reference's file
+    BYTE FOR BYTE (record order = images[] order through the id -> file_name map, "T" 3 x 1, "rotation_matrix" 3 x 3, indent 2), the
+    overlay files carry the reference's names, and what the reference hands to solvePnPRansac per frame -- float32 image points and
+    float64 landmarks of exactly the landmarks its threshold loop admits, SOLVEPNP_EPNP, 10 000 iterations, 15 px -- is what the
+    oracle's filter selects and what the kernel's defaults are."""
+    import numpy as np
+    import scpose  # noqa: F401
+    from importlib import import_module
+    from oracle import pnp_ref as P
+    pe = import_module("spacecraft-pose-estimation_amd.pose_export")
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "export_reference_outputs.npz"))
+    det = _export_scene(tmp_path, g, with_frames=True)
+    ref_text = str(g["json_text"])
+    ref = json.loads(ref_text)
+    R = np.array([r["rotation_matrix"] for r in ref]); T = np.array([r["T"] for r in ref]).reshape(-1, 3)
+    monkeypatch.setattr(pe, "solve_poses", lambda preds, lm, K, dist, **kw: (R, T, np.full(len(R), 11, np.int32)))
+    pe.export(str(tmp_path / "frames"), str(tmp_path / "det.json"), str(tmp_path / "pred.mat"), str(tmp_path / "landmarks.csv"),
+              str(tmp_path / "calib.json"), str(tmp_path / "out"), overlay=True)
+    assert (tmp_path / "out" / "opencv_poses.json").read_text() == ref_text
+    assert sorted(f for f in os.listdir(tmp_path / "out") if f.endswith(".jpg")) == sorted(str(v) for v in g["overlays"])
+    # the call contract
+    n = int(g["ncalls"])
+    assert n == len(det["images"]) and set(g["flags"].tolist()) == {1} and set(g["iters"].tolist()) == {10000} and set(g["err"].tolist()) == {15.0}
+    assert set(g["img_dtype"].tolist()) == {"float32"} and set(g["obj_dtype"].tolist()) == {"float64"} and json.loads(str(g["extra"])) == [[]] * n
+    assert np.array_equal(g["K"], P.CAMERA_K) and np.array_equal(g["dist"], P.CAMERA_DIST)
+    pos = 0
+    for i in range(n):
+        m = P.conf_mask(g["preds"][i, :, 2])
+        k = int(g["npts"][i])
+        assert m.sum() == k and np.array_equal(g["img_points"][pos:pos + k], g["preds"][i, m, :2])
+        # (landmarks as pd.read_csv parses them: one float64 ulp off the literals in places, identical as the float32 values OpenCV computes with)
+        assert np.array_equal(g["obj_points"][pos:pos + k].astype(np.float32), P.LANDMARKS[m].astype(np.float32))
+        pos += k
+    import inspect
+    sig = inspect.signature(import_module("spacecraft-pose-estimation_amd.ops").pnp_epnp_ransac).parameters
+    assert sig["max_iters"].default == 10000 and sig["reproj_err"].default == 15.0 and sig["conf_thr0"].default == 0.95 and sig["min_pts"].default == 15
