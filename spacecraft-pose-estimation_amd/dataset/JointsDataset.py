@@ -94,7 +94,8 @@ class JointsDataset(Dataset):
             from ..ops import warp_window
             fh, fw = int(data_numpy.shape[0]), int(data_numpy.shape[1])
             roi = warp_window(trans, (int(self.image_size[0]), int(self.image_size[1])), (fh, fw))
-            input = torch.from_numpy(np.ascontiguousarray(data_numpy[roi[1]:roi[1] + roi[3], roi[0]:roi[0] + roi[2]]))   # uint8, final channel order
+            win = np.ascontiguousarray(data_numpy[roi[1]:roi[1] + roi[3], roi[0]:roi[0] + roi[2]])
+            input = torch.from_numpy(win if win.flags.writeable else win.copy())   # uint8, final channel order (the decoder's array is read-only)
         else:
             input = warp_affine_bilinear(np.ascontiguousarray(data_numpy), trans, (int(self.image_size[0]), int(self.image_size[1])))
             if self.transform:

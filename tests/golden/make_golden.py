@@ -42,6 +42,9 @@ container (it never ships; /root/reference does not exist on the GPU box):
   * pose_estimation/export_predicted_poses_real.py main() (:126-236) run with cv2 replaced by a recorder that answers with this
     repository's C oracle: the call contract of solvePnPRansac, the JSON it writes, the overlay names (export_reference_outputs.npz).
 
+  * lib/dataset/events.py + JointsDataset.py as whole classes (__init__, _get_db, __getitem__ in eval mode) on a scratch scene, with
+    cv2.warpAffine answered by this repository's restatement (dataset_item_reference_outputs.npz).
+
 Only data is written (npz): no reference source text.  Re-run: python tests/golden/make_golden.py
 """
 import importlib
@@ -544,6 +547,94 @@ def export_vectors():
     print("export loop: %d solvePnPRansac calls, points per call %s, %d overlays, json %d bytes" % (len(calls), out["npts"].tolist(), len(written), len(text)))
 
 
+def scratch_coco_scene(root, rng):
+    """Three seeded frames + a COCO dict with real key points and mixed visibility flags (shared with tests/test_host.py)."""
+    import json
+    from PIL import Image
+    os.makedirs(os.path.join(root, "frames", "sub"), exist_ok=True)
+    os.makedirs(os.path.join(root, "ann"), exist_ok=True)
+    images, anns = [], []
+    for i, (h, w) in enumerate([(120, 160), (96, 96), (200, 150)]):
+        name = ("sub/f%d.png" if i == 1 else "f%d.png") % i
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(os.path.join(root, "frames", name))
+        images.append({"id": 7 + 2 * i, "file_name": name, "width": w, "height": h})
+    order = [2, 0, 1, 0]                                           # annotations[] order differs from images[] order; one image twice
+    for k, i in enumerate(order):
+        w, h = images[i]["width"], images[i]["height"]
+        bbox = [float(rng.uniform(-5, w * 0.4)), float(rng.uniform(-5, h * 0.4)), float(rng.uniform(20, w)), float(rng.uniform(20, h))]
+        kps = []
+        for j in range(11):
+            kps += [float(rng.uniform(0, w)), float(rng.uniform(0, h)), int(rng.integers(0, 3))]      # COCO visibility 0 / 1 / 2
+        anns.append({"image_id": images[i]["id"], "bbox": bbox, "keypoints": kps, "id": k, "category_id": 1})
+    with open(os.path.join(root, "ann", "test.json"), "w") as f:
+        json.dump({"images": images, "annotations": anns}, f)
+    return len(anns)
+
+
+def dataset_item_vectors():
+    """EventsDataset as a whole (lib/dataset/events.py:24-92 __init__ / _get_db, lib/dataset/JointsDataset.py:120-229 __getitem__ in eval
+    mode) through the reference's own classes on a scratch scene.  Stand-ins: json_tricks = json; np.float = float (removed from NumPy);
+    cv2.imread = PIL decoding reversed to BGR, cv2.cvtColor(BGR2RGB) = channel reversal, and cv2.warpAffine = this repository's NumPy
+    restatement (utils.transforms.warp_affine_bilinear) -- the one piece that stays unpinned; everything around it is the reference's
+    code: db records, centre / scale, the affine, joints mapped into the crop, targets, weights, the meta dict."""
+    import json
+    import tempfile
+    import scpose  # noqa: F401
+    T = importlib.import_module("spacecraft-pose-estimation_amd.utils.transforms")
+    from PIL import Image
+    cv2 = types.ModuleType("cv2")
+    cv2.IMREAD_COLOR, cv2.IMREAD_IGNORE_ORIENTATION, cv2.COLOR_BGR2RGB, cv2.INTER_LINEAR = 1, 128, 4, 1
+    cv2.imread = lambda path, flags=None: (np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1].copy() if os.path.exists(path) else None)
+    cv2.cvtColor = lambda img, code: img[:, :, ::-1]
+    cv2.warpAffine = lambda img, trans, size, flags=None: T.warp_affine_bilinear(np.ascontiguousarray(img), trans, size)
+    cv2.getAffineTransform = lambda src, dst: T.affine_from_3pts(np.asarray(src, np.float32), np.asarray(dst, np.float32))
+    saved = {k: sys.modules.get(k) for k in ("cv2", "json_tricks")}
+    for k in [m for m in sys.modules if m == "utils.transforms" or m.startswith("dataset")]:
+        sys.modules.pop(k)
+    sys.modules["cv2"] = cv2; sys.modules["json_tricks"] = json
+    had_float = hasattr(np, "float")
+    if not had_float:
+        np.float = float
+    if os.path.join(REF, "lib") not in sys.path:
+        sys.path.insert(0, os.path.join(REF, "lib"))
+    try:
+        ev = importlib.import_module("dataset.events")
+        N = types.SimpleNamespace
+        out = {}
+        with tempfile.TemporaryDirectory() as d:
+            n = scratch_coco_scene(d, np.random.default_rng(17))
+            for rgb in (True, False):
+                cfg = N(OUTPUT_DIR="", DATASET=N(DATA_FORMAT="png", SCALE_FACTOR=0.25, ROT_FACTOR=30, FLIP=False, NUM_JOINTS_HALF_BODY=8, PROB_HALF_BODY=-1.0,
+                                                 COLOR_RGB=rgb, IMAGE_WIDTH=160, IMAGE_HEIGHT=120),
+                        MODEL=N(TARGET_TYPE="gaussian", IMAGE_SIZE=[64, 48], HEATMAP_SIZE=[16, 12], SIGMA=2, NUM_JOINTS=11), LOSS=N(USE_DIFFERENT_JOINTS_WEIGHT=False))
+                ds = ev.EventsDataset(cfg, os.path.join(d, "ann"), os.path.join(d, "frames"), "test", False, None)
+                tag = "rgb%d/" % rgb
+                out[tag + "len"] = np.array(len(ds))
+                for i in range(n):
+                    rec = ds.db[i]
+                    out[tag + "%d/db_image" % i] = np.array(os.path.relpath(rec["image"], d))
+                    for k in ("center", "scale", "joints_3d", "joints_3d_vis"):
+                        out[tag + "%d/db_%s" % (i, k)] = np.asarray(rec[k])
+                    out[tag + "%d/db_box" % i] = np.array([rec["box_w"], rec["box_h"]])
+                    inp, target, weight, meta = ds[i]
+                    out[tag + "%d/input" % i] = np.asarray(inp); out[tag + "%d/target" % i] = target.numpy(); out[tag + "%d/weight" % i] = weight.numpy()
+                    for k in ("joints", "joints_vis", "center", "scale"):
+                        out[tag + "%d/meta_%s" % (i, k)] = np.asarray(meta[k])
+                    out[tag + "%d/meta_misc" % i] = np.array(json.dumps([os.path.relpath(meta["image"], d), meta["filename"], meta["imgnum"], meta["rotation"], meta["score"]]))
+        np.savez_compressed(os.path.join(HERE, "dataset_item_reference_outputs.npz"), **out)
+        print("dataset items: %d records x 2 colour orders; input %s %s" % (n, out["rgb1/0/input"].shape, out["rgb1/0/input"].dtype))
+    finally:
+        if not had_float:
+            del np.float
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        for k in [m for m in sys.modules if m == "utils.transforms" or m.startswith("dataset")]:
+            sys.modules.pop(k)
+
+
 def camera_vectors():
     """Camera model + confidence filter through the reference's own code (SURVEY.md section 8 a11, 8d, section 9 "PnP")."""
     import inspect
@@ -637,3 +728,4 @@ if __name__ == "__main__":
     config_vectors()
     camera_vectors()
     export_vectors()
+    dataset_item_vectors()

@@ -593,3 +593,56 @@ def test_pose_export_writes_what_the_reference_main_writes(tmp_path, monkeypatch
     import inspect
     sig = inspect.signature(import_module("spacecraft-pose-estimation_amd.ops").pnp_epnp_ransac).parameters
     assert sig["max_iters"].default == 10000 and sig["reproj_err"].default == 15.0 and sig["conf_thr0"].default == 0.95 and sig["min_pts"].default == 15
+
+
+@pytest.mark.parametrize("rgb", [True, False])
+def test_events_dataset_equals_the_reference_classes_item_for_item(tmp_path, rgb):
+    """EventsDataset (db construction, __getitem__ in eval mode) against the reference's own classes run on the same scratch scene
+    (tests/golden/dataset_item_reference_outputs.npz, make_golden.py: dataset_item_vectors -- lib/dataset/events.py:24-92,
+    lib/dataset/JointsDataset.py:120-229; cv2.warpAffine answered by utils.transforms.warp_affine_bilinear, the one unpinned piece):
+    db records in annotations[] order (non-monotonic ids, an image used twice, file names with a directory part), centre / scale,
+    joints and visibility, the crop, the joints mapped into it (only the visible ones), targets, weights and the meta dict -- bit for bit,
+    for COLOR_RGB on and off; and the device-crop path returns the window of the same frame with the same meta."""
+    import importlib.util
+    import numpy as np
+    import scpose  # noqa: F401
+    from importlib import import_module
+    spec = importlib.util.spec_from_file_location("mg_for_scene", os.path.join(ROOT, "tests", "golden", "make_golden.py"))
+    src = open(os.path.join(ROOT, "tests", "golden", "make_golden.py")).read()
+    ns = {"os": os, "np": np}
+    start = src.index("def scratch_coco_scene("); end = src.index("def dataset_item_vectors(")
+    exec(compile(src[start:end], "scratch_coco_scene", "exec"), ns)            # the scene builder of the generator (this repository's code)
+    n = ns["scratch_coco_scene"](str(tmp_path), np.random.default_rng(17))
+    g = np.load(os.path.join(ROOT, "tests", "golden", "dataset_item_reference_outputs.npz"))
+    C = import_module("spacecraft-pose-estimation_amd.config"); D = import_module("spacecraft-pose-estimation_amd.dataset")
+    cfg = C._defaults()
+    cfg.defrost() if hasattr(cfg, "defrost") else None
+    cfg.DATASET.DATA_FORMAT = "png"; cfg.DATASET.COLOR_RGB = rgb; cfg.DATASET.IMAGE_WIDTH = 160; cfg.DATASET.IMAGE_HEIGHT = 120
+    cfg.MODEL.IMAGE_SIZE = [64, 48]; cfg.MODEL.HEATMAP_SIZE = [16, 12]; cfg.MODEL.SIGMA = 2; cfg.MODEL.NUM_JOINTS = 11; cfg.MODEL.TARGET_TYPE = "gaussian"
+    ds = D.EventsDataset(cfg, str(tmp_path / "ann"), str(tmp_path / "frames"), "test", False, None)
+    tag = "rgb%d/" % rgb
+    assert len(ds) == int(g[tag + "len"]) == n
+    for i in range(n):
+        rec = ds.db[i]
+        assert os.path.relpath(rec["image"], tmp_path) == str(g[tag + "%d/db_image" % i])
+        for k in ("center", "scale", "joints_3d", "joints_3d_vis"):
+            want = g[tag + "%d/db_%s" % (i, k)]
+            assert np.asarray(rec[k]).dtype == want.dtype and np.array_equal(rec[k], want), (i, k)
+        assert np.array_equal(np.array([rec["box_w"], rec["box_h"]]), g[tag + "%d/db_box" % i])
+        inp, target, weight, meta = ds[i]
+        assert np.array_equal(np.asarray(inp), g[tag + "%d/input" % i])
+        assert np.array_equal(target.numpy(), g[tag + "%d/target" % i]) and np.array_equal(weight.numpy(), g[tag + "%d/weight" % i])
+        for k in ("joints", "joints_vis", "center", "scale"):
+            assert np.array_equal(np.asarray(meta[k]), g[tag + "%d/meta_%s" % (i, k)]), (i, k)
+        misc = json.loads(str(g[tag + "%d/meta_misc" % i]))
+        assert [os.path.relpath(meta["image"], tmp_path), meta["filename"], meta["imgnum"], meta["rotation"], meta["score"]] == misc
+    # device-crop path: the window of the frame, same meta, and the affine the crop above was cut with
+    ds.device_crop = True
+    T = import_module("spacecraft-pose-estimation_amd.utils.transforms")
+    for i in range(n):
+        win, target, weight, meta = ds[i]
+        rx, ry, rw, rh = [int(v) for v in meta["roi"]]
+        assert tuple(win.shape) == (rh, rw, 3) and np.array_equal(np.asarray(meta["center"]), g[tag + "%d/meta_center" % i])
+        full = np.zeros((int(meta["frame_hw"][0]), int(meta["frame_hw"][1]), 3), np.uint8)
+        full[ry:ry + rh, rx:rx + rw] = win.numpy()
+        assert np.array_equal(T.warp_affine_bilinear(full, meta["trans"], (64, 48)), g[tag + "%d/input" % i])      # every tap of the crop lies in the window
