@@ -244,6 +244,19 @@ def test_cli_tools_test_and_pose_export(pk, tmp_path):
     preds_w, _ = run("threads2_ref_flow", ["--loader_threads", "2", "--host_crop", "--log_metrics"], "4")
     assert np.array_equal(preds_w, preds)
 
+    # a data set of 512+ frames is decoded by worker processes even though the YAML says WORKERS: 0 (as the reference's events-config.yaml does);
+    # rows follow annotations[] order whatever the workers' completion order
+    big = {"images": images, "annotations": [dict(anns[k % 6], id=k) for k in range(520)]}
+    (tmp_path / "data_big").mkdir()
+    (tmp_path / "data_big" / "real_test.json").write_text(json.dumps(big))
+    cb = list(cmd); cb[cb.index("DATASET.ROOT") + 1] = str(tmp_path / "data_big"); cb[cb.index("OUTPUT_DIR") + 1] = str(tmp_path / "out_big")
+    cb[cb.index("TEST.BATCH_SIZE_PER_GPU") + 1] = "64"
+    rb = subprocess.run(cb, cwd=os.path.join(ROOT, "landmark_regression"), capture_output=True, text=True, timeout=900)
+    assert rb.returncode == 0, rb.stdout[-2000:] + rb.stderr[-2000:]
+    assert "decoding with" in rb.stdout + rb.stderr
+    pb_ = loadmat(tmp_path / "out_big" / "EventsDataset" / "pose_hrnet" / "w32_256" / "pred_test.mat")["preds"]
+    assert pb_.shape == (520, 11, 3) and all(np.array_equal(pb_[k], preds[k % 6]) for k in range(520))
+
     # stage 3 on known-answer keypoints written in the same .mat format
     kp, Rs, ts = P.synth_keypoints(6, np.random.default_rng(4), 0.5, 0.0)
     from scipy.io import savemat
