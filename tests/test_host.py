@@ -607,12 +607,10 @@ def test_events_dataset_equals_the_reference_classes_item_for_item(tmp_path, rgb
     import numpy as np
     import scpose  # noqa: F401
     from importlib import import_module
-    spec = importlib.util.spec_from_file_location("mg_for_scene", os.path.join(ROOT, "tests", "golden", "make_golden.py"))
-    src = open(os.path.join(ROOT, "tests", "golden", "make_golden.py")).read()
-    ns = {"os": os, "np": np}
-    start = src.index("def scratch_coco_scene("); end = src.index("def dataset_item_vectors(")
-    exec(compile(src[start:end], "scratch_coco_scene", "exec"), ns)            # the scene builder of the generator (this repository's code)
-    n = ns["scratch_coco_scene"](str(tmp_path), np.random.default_rng(17))
+    spec = importlib.util.spec_from_file_location("make_golden_for_scene", os.path.join(ROOT, "tests", "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)            # only its scene builder is used (this repository's code; nothing of /root/reference is touched on import)
+    n = mg.scratch_coco_scene(str(tmp_path), np.random.default_rng(17))
     g = np.load(os.path.join(ROOT, "tests", "golden", "dataset_item_reference_outputs.npz"))
     C = import_module("spacecraft-pose-estimation_amd.config"); D = import_module("spacecraft-pose-estimation_amd.dataset")
     cfg = C._defaults()
