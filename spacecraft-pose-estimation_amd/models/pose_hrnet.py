@@ -145,7 +145,8 @@ class PoseHighResolutionNet(nn.Module):
         ver = self._param_version()
         if self._engine is None or self._engine_version != ver or self._engine.device != device:
             if self._engine is not None:
-                self._engine.close()
+                self._engine.close()             # (closes the graphs captured from it)
+            self._fast_graph = self._fast_seen = None      # forward_decode's captured forward belonged to the old engine
             cfg = {"MODEL": self._cfg_model}
             self._engine = ops.HrnetEngine(cfg, self.state_dict(), dtype=self.dtype_name, device=device)
             self._engine_version = ver
