@@ -26,29 +26,25 @@ from .inference import get_final_preds_device
 logger = logging.getLogger(__name__)
 
 
-class AverageMeter(object):
-    def __init__(self):
-        self.reset()
+class AverageMeter:
+    """Running mean weighted by sample count; `.val` is the last value, `.avg` the mean so far (what the log lines print)."""
 
-    def reset(self):
-        self.val = self.avg = self.sum = self.count = 0
+    def __init__(self):
+        self.val = self.sum = self.count = self.avg = 0
+
+    reset = __init__
 
     def update(self, val, n=1):
-        self.val = val
-        self.sum += val * n
-        self.count += n
-        self.avg = self.sum / self.count if self.count != 0 else 0
+        self.val, self.sum, self.count = val, self.sum + val * n, self.count + n
+        self.avg = self.sum / self.count if self.count else 0
 
 
 def _print_name_value(name_value, full_arch_name):
-    names = name_value.keys()
-    values = name_value.values()
-    num_values = len(name_value)
-    logger.info("| Arch " + " ".join(["| {}".format(name) for name in names]) + " |")
-    logger.info("|---" * (num_values + 1) + "|")
-    if len(full_arch_name) > 15:
-        full_arch_name = full_arch_name[:8] + "..."
-    logger.info("| " + full_arch_name + " " + " ".join(["| {:.3f}".format(value) for value in values]) + " |")
+    """The three-line markdown table lib/core/function.py:462-479 logs for a dict of metrics (arch names over 15 characters are cut to 8 + '...')."""
+    arch = full_arch_name if len(full_arch_name) <= 15 else full_arch_name[:8] + "..."
+    logger.info("| Arch " + " ".join("| %s" % k for k in name_value) + " |")
+    logger.info("|---" * (len(name_value) + 1) + "|")
+    logger.info("| " + arch + " " + " ".join("| %.3f" % v for v in name_value.values()) + " |")
 
 
 def validate(config, val_loader, val_dataset, model, criterion, output_dir, tb_log_dir, pred_file_name="pred",
