@@ -104,7 +104,9 @@ def parse():
                          "validate() -> pred.mat -> export -> opencv_poses.json), frames/s per stage beside the reference-style host loader "
                          "(tools_dev/pipeline_bench.py)")
     ap.add_argument("--pipeline-frames", type=int, default=2048)
-    ap.add_argument("--pipeline-workers", type=int, default=min(8, os.cpu_count() or 1))
+    ap.add_argument("--pipeline-workers", type=int, default=max(1, min(32, (os.cpu_count() or 1) // 4)), help="loader workers (default: what the CLI picks, parallel.auto_workers)")
+    ap.add_argument("--no-chain-check", action="store_true",
+                    help="skip the post-run key-point / pose check on the 64 W48 fixture frames (about 15 s: the constructed checkpoint is rebuilt from its seed)")
     ap.add_argument("--cpu-stub", action="store_true",
                     help="(tests only) run the multi-rank step loop on CPU tensors over gloo with a stand-in engine: exercises the sharding, "
                          "gather, timing and printing code, measures nothing")
@@ -147,6 +149,92 @@ def cpu_baseline(cfg, sd, image, nframes, kp_sample):
                       "serial C EPnP+RANSAC), %.1f s" % (nframes, "W48" if cfg["MODEL"]["EXTRA"]["STAGE2"]["NUM_CHANNELS"][0] == 48 else "W32",
                                                          image, image, bs, total),
             "stage_s_per_frame": {"hrnet": t_net / nframes, "decode": t_dec / nframes, "pnp": t_pnp / nframes}}
+
+
+class DeviceSampler:
+    """Shader clock and board power of one GPU while the timed region runs, read from sysfs (what rocm-smi reads) by a thread of this
+    process every 25 ms: lets a reader of the line tell a slow BOX (low clock / power cap) from a slow BUILD.  None when the
+    files are not readable; the figures are a report, nothing is computed from them."""
+
+    def __init__(self, index):
+        import threading
+        self.sclk, self.power, self._stop, self._thread = [], [], threading.Event(), None
+        cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(d, "pp_dpm_sclk")))
+        self.dev = cards[index] if index < len(cards) else None
+        hw = glob.glob(os.path.join(self.dev, "hwmon", "hwmon*")) if self.dev else []
+        self.pfile = next((os.path.join(h, f) for h in hw for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, f))), None)
+        self._threading = threading
+
+    def _sample(self):
+        try:
+            for ln in open(os.path.join(self.dev, "pp_dpm_sclk")).read().splitlines():
+                if ln.rstrip().endswith("*"):
+                    self.sclk.append(int("".join(ch for ch in ln.split(":")[1] if ch.isdigit())))
+            if self.pfile:
+                self.power.append(int(open(self.pfile).read().strip()) / 1e6)
+        except (OSError, ValueError, IndexError):
+            pass
+
+    def start(self):
+        if self.dev is None:
+            return
+        def run():
+            while not self._stop.is_set():
+                self._sample()
+                self._stop.wait(0.025)
+        self._thread = self._threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if self._thread is None:
+            return None
+        self._stop.set(); self._thread.join()
+        if not self.sclk:
+            return None
+        return {"sclk_mhz_median": float(np.median(self.sclk)), "sclk_mhz_min": int(min(self.sclk)), "sclk_mhz_max": int(max(self.sclk)),
+                "power_w_mean": round(float(np.mean(self.power)), 1) if self.power else None,
+                "power_w_max": round(float(max(self.power)), 1) if self.power else None, "samples": len(self.sclk),
+                "source": "sysfs pp_dpm_sclk / hwmon power1_average, sampled every 25 ms during the timed region"}
+
+
+def chain_check(ops, syn, dev, dtype):
+    """The metric's second half ("keypoint/pose err vs ref", BASELINE.json) in the driver-run line: after the timed region, the
+    64 fixture frames of tests/golden/chain_w48_reference.npz go image -> key points -> pose through the SAME kernels at the headline
+    geometry (HRNet-W48, 384 x 384, the constructed checkpoint synthetic.w48_chain_checkpoint: random-init weights carry no pose).
+    Key points are compared with the ones the REFERENCE module + the reference's get_final_preds produced on the same weights and frames
+    (stored in the fixture, made by tests/golden/make_w48_chain.py), poses with the ones the frames were rendered from.
+    What this can and cannot show: DESIGN.md section 0.1 -- the checkpoint's residual and cross-branch paths are scaled by 0.02, so it
+    proves the chain end to end, not that 16-bit noise never moves an arg-max of a trained network (the heat-map tests carry that)."""
+    path = os.path.join(ROOT, "tests", "golden", "chain_w48_reference.npz")
+    if not os.path.exists(path):
+        return {"skipped": "fixture %s not found" % os.path.relpath(path, ROOT)}
+    z = np.load(path)
+    image, n_cand, seed, wseed = [int(v) for v in z["meta"]]
+    cand = syn.landmark_frames(n_cand, np.random.default_rng(seed), image, blob_sigma=syn.W48_CHAIN_BLOB_SIGMA)
+    fr = {k: v[z["test_index"]] for k, v in cand.items()}
+    eng = ops.HrnetEngine(syn.w48_chain_cfg(image), syn.w48_chain_checkpoint(wseed), dtype=dtype, device=dev)
+    try:
+        x = torch.from_numpy(fr["crops"]).to(dev)
+        c = torch.from_numpy(fr["center"]).to(dev); s = torch.from_numpy(fr["scale"]).to(dev)
+        kp = eng.forward_decode(x, c, s, True)
+        rows = torch.empty((kp.shape[0], 13), dtype=torch.float64, device=dev)
+        ops.pnp_epnp_ransac(kp, torch.from_numpy(syn.TANGO_LANDMARKS).to(dev), torch.from_numpy(syn.SPEEDPLUS_K).to(dev),
+                            torch.from_numpy(syn.SPEEDPLUS_DIST).to(dev), rows=rows)
+        got, hb = kp.cpu().numpy(), rows.cpu().numpy()
+    finally:
+        eng.close()
+    err = np.linalg.norm(got[:, :, :2] - z["ref_preds"], axis=2)
+    Rg = hb[:, 0:9].reshape(-1, 3, 3)
+    ang = np.arccos(np.clip((np.einsum("nij,nij->n", Rg, fr["R"]) - 1.0) / 2.0, -1.0, 1.0))
+    terr = np.linalg.norm(hb[:, 9:12] - fr["t"], axis=1) / np.linalg.norm(fr["t"], axis=1)
+    return {"frames": int(got.shape[0]), "joints": int(err.size), "kp_px_max": float(err.max()), "kp_px_mean": float(err.mean()),
+            "maxval_abs_diff_max": float(np.abs(got[:, :, 2:3] - z["ref_maxvals"]).max()),
+            "rot_err_rad_median": float(np.median(ang)), "rot_err_rad_max": float(ang.max()),
+            "t_err_rel_median": float(np.median(terr)), "t_err_rel_max": float(terr.max()), "inliers_min": int(hb[:, 12].min()),
+            "kp_reference": "reference pose_hrnet module (fp32) + reference get_final_preds on the same weights / frames (tests/golden/chain_w48_reference.npz)",
+            "pose_reference": "the poses the frames were rendered from (landmarks drawn up to one crop pixel from their projection)",
+            "workload": "HRNet-W48 384x384 constructed checkpoint (synthetic.w48_chain_checkpoint), %d fixture frames, %s, after the timed region" % (got.shape[0], dtype),
+            "tolerances": "north_star: key points <= 0.5 px; rotation / translation <= 1e-4 hold against the oracle chain on identical key points (tests/test_gpu_chain.py), not against the rendered pose"}
 
 
 # ---- --cpu-stub: the multi-rank step loop of THIS file on CPU tensors over gloo (tests/test_parallel_gloo.py) ----------------------
@@ -226,7 +314,7 @@ def main():
     if args.pipeline:
         sys.path.insert(0, os.path.join(ROOT, "tools_dev"))
         import pipeline_bench
-        res = pipeline_bench.run(args.pipeline_frames, args.pipeline_workers, 64 if args.batch == BATCH_PER_GPU else args.batch, args.model)
+        res = pipeline_bench.run(args.pipeline_frames, args.pipeline_workers, 16 if args.batch == BATCH_PER_GPU else args.batch, args.model)   # 16: the reference's shipped TEST.BATCH_SIZE_PER_GPU
         print(json.dumps({"metric": "frames/sec files -> poses (product CLI path)", "unit": "frames/s", **res}))
         return
     if args.events:
@@ -335,6 +423,7 @@ def main():
 
     prof_ms = {}
     fwd_events = []     # (start, end) events around the forward of every timed step (two records per step, no per-launch events)
+    step_end_events = []   # the event that closes every timed step on the side stream: consecutive differences = per-step period
 
     def step(profile, timed=False):
         k = counter[0] & 1
@@ -374,8 +463,10 @@ def main():
                 out = block[k]
             if rank == 0:
                 host_buf[k].copy_(out, non_blocking=True)   # (R, t, status) of every frame on rank 0's host
-            done[k] = cuda.Event()
+            done[k] = cuda.Event(enable_timing=timed)
             done[k].record(side)
+            if timed:
+                step_end_events.append(done[k])
         if profile:   # per-launch HIP events of this forward (blocks the host until the forward has finished)
             recs = eng.profile_read()
             for rec, cls in zip(recs, eng.kernel_classes(recs)):
@@ -392,16 +483,37 @@ def main():
     for _ in range(args.warmup):
         step(False)
     barrier()
+    sampler = DeviceSampler(local_rank) if (rank == 0 and not stub) else None
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     host = None
     for i in range(args.steps):     # the timed region: exactly K steps, none of them instrumented per launch
         host = step(False, timed=True)
     barrier()
     elapsed = time.perf_counter() - t0
+    device_state = sampler.stop() if sampler else None
+    elapsed_own = elapsed
+    rccl = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+        # who took part: every rank reports its device, so that the line itself shows N ranks on N distinct devices
+        props = None if stub else torch.cuda.get_device_properties(local_rank)
+        me = {"rank": rank, "local_rank": local_rank, "device": "cpu (stub)" if stub else props.name,
+              "pci_bus_id": None if stub else "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1) & 0xff, getattr(props, "pci_device_id", 0)),
+              "uuid": None if stub else str(getattr(props, "uuid", "")), "ms_per_step": round(elapsed_own / args.steps * 1e3, 3), "pid": os.getpid()}
+        reports = [None] * world
+        dist.all_gather_object(reports, me)
+        nccl_version = None
+        if not stub:
+            try:
+                nccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                nccl_version = None
+        rccl = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "nccl_version": nccl_version,
+                "ranks_reporting": sorted(reports, key=lambda r: r["rank"])}
     fwd_unprofiled_ms = sum(a.elapsed_time(b) for a, b in fwd_events) / max(len(fwd_events), 1)
     # Roofline pass, AFTER the timed region: per-launch HIP events cost ~2.5 ms per forward (~280 records
     # that break back-to-back dispatch), so the steps that carry them are not part of `value`; the same pipelined step
@@ -495,6 +607,18 @@ def main():
         if world == 1 and args.cpu_frames > 0 and not stub:
             cpu = cpu_baseline(cfg, sd, image, args.cpu_frames, kp_np)
         st = eng.stats(image, image)
+        periods = [] if stub else [a.elapsed_time(b) for a, b in zip(step_end_events[:-1], step_end_events[1:])]
+        step_ms = ({"min": round(min(periods), 3), "median": round(float(np.median(periods)), 3), "max": round(max(periods), 3), "n": len(periods),
+                    "what": "time between the ends of consecutive timed steps (HIP events on the side stream, rank 0)"} if periods else None)
+        if rccl is not None:      # every rank's block must be its own: key points are seeded per rank, so equal blocks mean a rank's rows were not gathered
+            hb_all = host.numpy()
+            blocks = [hb_all[r * B:(r + 1) * B] for r in range(world)]
+            distinct = all(not np.array_equal(blocks[a], blocks[b]) for a in range(world) for b in range(a + 1, world))
+            ids = [r["uuid"] or r["pci_bus_id"] for r in rccl["ranks_reporting"]]
+            rccl["rank_blocks_distinct"] = bool(distinct)
+            rccl["devices_distinct"] = None if stub else len(set(ids)) == world
+            if not distinct or len(rccl["ranks_reporting"]) != world or [r["rank"] for r in rccl["ranks_reporting"]] != list(range(world)):
+                raise SystemExit("bench.py: the gathered (R, t, status) blocks of %d ranks are not %d distinct blocks: %s" % (world, world, json.dumps(rccl)))
         chain_report = None
         if chain is not None:   # rank 0's own frames: pose of the last step against the pose each frame was rendered from
             hb = host[:B].numpy()
@@ -506,6 +630,8 @@ def main():
                             "t_err_rel_median": float(np.median(terr)), "t_err_rel_max": float(terr.max()),
                             "inliers_min": int(hb[:, 12].min()),
                             "note": "landmarks are drawn up to one crop pixel (side / 128 frame px) from their projection (synthetic.landmark_frames)"}
+        if chain_report is None and not stub and not args.events and args.model == "w48" and args.dtype in ("bf16", "f16") and not args.no_chain_check:
+            chain_report = chain_check(ops, syn, dev, args.dtype)
         line = {
             "metric": "STUB: multi-rank step loop on CPU tensors over gloo, nothing is computed or measured (--cpu-stub)" if stub else
                       "poses/sec end-to-end (HRNet+PnP) at batch 256; keypoint/pose err vs ref",
@@ -533,6 +659,9 @@ def main():
             "hrnet_forward_ms_sum_of_profiled_launches": round(fwd_ms, 3),
             "hrnet_tflops": round(st["flops_per_frame"] * B / (fwd_unprofiled_ms / 1e3) / 1e12, 2),
             "poses_ok": ok, "poses_total": world * B,
+            "step_ms": step_ms,
+            "device_state": device_state,
+            "rccl": rccl,
             "chain": chain_report,
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -270,7 +270,8 @@ int32_t scpose_heatmap_accumulate(float* acc, const float* x, float div, int64_t
  *   tvec       device f64 N x 3
  *   rvec       device f64 N x 3 (may be NULL)
  *   status     device i32 N: >=0 number of RANSAC inliers; <0 failure code
- *              (-1: fewer than 4 usable points [the reference raises], -2: RANSAC found no model).
+ *              (-1: fewer than 4 usable points [the reference raises], -2: RANSAC found no model, -4: the final solve is not
+ *              finite [cv2 would return NaN]); every failure writes the identity rotation and a zero translation.
  *              Exactly four usable points: as in OpenCV 3.4, no RANSAC -- the P3P kernel on the first three points, the
  *              fourth picks among its up to four poses (status 4, or -2 when P3P finds none); exactly five: one EPnP.
  * ---------------------------------------------------------------------------------------- */

@@ -50,13 +50,14 @@ def parse_args():
                         help="(extension, the default) warp the crops on the GPU (scpose_crop_warp): the loader only decodes the frames")
     parser.add_argument("--host_crop", dest="device_crop", action="store_false",
                         help="(extension) warp and normalise the crops in the data loader, as the reference does")
-    parser.add_argument("--loader_threads", type=int, default=0,
-                        help="(extension) decode the frames with N threads of this process (parallel.ThreadedLoader) instead of cfg.WORKERS "
-                             "DataLoader worker processes: no start-up, no inter-process copies")
     parser.add_argument("--no_auto_workers", action="store_true",
                         help="(extension) keep cfg.WORKERS = 0 as 'decode in this process'.  By default a data set of 512 frames or more is decoded by "
-                             "up to 8 worker processes even when the YAML says WORKERS: 0 (the reference's events-config.yaml does): same output, "
-                             "~10x the frames/s; smaller sets are not worth the workers' start-up")
+                             "min(32, cores / 4) worker processes even when the YAML says WORKERS: 0 (the reference's events-config.yaml does): same "
+                             "output, 10-35x the frames/s; smaller sets are not worth the workers' start-up")
+    parser.add_argument("--engine_batch", type=int, default=256,
+                        help="(extension) frames per engine launch: the loop coalesces the loader's batches (TEST.BATCH_SIZE_PER_GPU, 16 in the "
+                             "reference's YAML) into engine batches of this size -- a frame's result does not depend on its batch, bit for bit, so "
+                             "the pred .mat is the same; 0 = one launch per loader batch.  Ignored with --log_metrics (loss / PCK are per loader batch)")
     parser.add_argument("--log_metrics", action="store_true",
                         help="(extension) compute the loss / PCK the reference logs per batch; they need the heat-maps, so the forward "
                              "then writes them instead of handing key points out of its last kernel (same pred .mat, bit for bit)")
@@ -91,24 +92,15 @@ def main():
         cfg, cfg.DATASET.ROOT, cfg.DATA_DIR, cfg.DATASET.TEST_SET, False,
         transforms.Compose([transforms.ToTensor(), normalize]))
     lo, hi = parallel.shard_range(len(valid_dataset), rank, ws)
-    subset = torch.utils.data.Subset(valid_dataset, range(lo, hi)) if ws > 1 else valid_dataset
     valid_dataset.device_crop = bool(args.device_crop)
     valid_dataset.want_target = bool(args.log_metrics)     # gaussian targets feed the logged loss / PCK only
-    workers = int(cfg.WORKERS)
-    if workers == 0 and not args.no_auto_workers and args.loader_threads == 0 and hi - lo >= 512:
-        workers = max(1, min(8, (os.cpu_count() or 1) // 2))
+    workers = parallel.auto_workers(hi - lo, cfg.WORKERS, keep=args.no_auto_workers)
+    if workers != int(cfg.WORKERS):
         logger.info("=> WORKERS: 0 and %d frames: decoding with %d worker processes (--no_auto_workers keeps it in this process)" % (hi - lo, workers))
-    valid_loader = torch.utils.data.DataLoader(subset, batch_size=cfg.TEST.BATCH_SIZE_PER_GPU * len(cfg.GPUS),
-                                               shuffle=False, num_workers=workers, pin_memory=True,   # (the packed frame windows too: a background thread pins them, the copy to the device is then asynchronous)
-                                               # workers come from a clean fork server, never from this process: it has initialised HIP
-                                               multiprocessing_context=parallel.loader_worker_context(workers),
-                                               collate_fn=valid_dataset.collate_device_crop if args.device_crop else None)
-    if args.loader_threads > 0:
-        valid_loader = parallel.ThreadedLoader(valid_dataset, cfg.TEST.BATCH_SIZE_PER_GPU * len(cfg.GPUS), args.loader_threads,
-                                               collate_fn=valid_dataset.collate_device_crop if args.device_crop else None,
-                                               indices=range(lo, hi) if ws > 1 else None)
+    # (workers come from a clean fork server, never from this process: it has initialised HIP)
+    valid_loader = parallel.valid_loader(valid_dataset, lo, hi, ws, cfg.TEST.BATCH_SIZE_PER_GPU * len(cfg.GPUS), workers, args.device_crop)
     validate(cfg, valid_loader, valid_dataset, model, criterion, final_output_dir, tb_log_dir, pred_file_name="pred_test",
-             log_metrics=bool(args.log_metrics))
+             log_metrics=bool(args.log_metrics), engine_batch=args.engine_batch)
 
 
 if __name__ == "__main__":

@@ -9,8 +9,8 @@ namespace scpose {
 
 int32_t conv_m32_dispatch_bf16(int mr, int wm, int nr, int occ, const ConvLaunch& L, size_t lds, hipStream_t st);
 int32_t conv_m32_dispatch_f16(int mr, int wm, int nr, int occ, const ConvLaunch& L, size_t lds, hipStream_t st);
-int32_t conv_m32p_dispatch_bf16(int stride, int mr, int nr, int c16, const ConvLaunch& L, size_t lds, hipStream_t st);
-int32_t conv_m32p_dispatch_f16(int stride, int mr, int nr, int c16, const ConvLaunch& L, size_t lds, hipStream_t st);
+int32_t conv_m32p_dispatch_bf16(int stride, int mr, int nr, int c16, int cw2, const ConvLaunch& L, size_t lds, hipStream_t st);
+int32_t conv_m32p_dispatch_f16(int stride, int mr, int nr, int c16, int cw2, const ConvLaunch& L, size_t lds, hipStream_t st);
 
 // kernel variants built (keep in step with m32_dispatch / m32p_dispatch): occ = resident workgroups
 // per CU of the single-role kernel (1, 2), or 3 = the producer/consumer kernel (512 threads, one per CU);
@@ -18,6 +18,7 @@ int32_t conv_m32p_dispatch_f16(int stride, int mr, int nr, int c16, const ConvLa
 // (conv_m32p_kernel.h, C16) -- the ONLY family of the layers conv_m16_eligible() names, whatever the batch, so that a
 // frame's sums are formed in one order; nr then only sizes the tile (nb16 * 16 = nr * 32 pixels)
 struct M32Variant { int mr, wm, nr, occ, nb16; };
+constexpr int kM16Cw2Default = 0;   // product default of SCPOSE_M16_CW2 (see m32p_two_consumer_waves)
 static const M32Variant kVariants[] = {
   {3, 1, 3, 1, 0}, {3, 1, 2, 2, 0}, {3, 1, 1, 3, 0}, {3, 1, 2, 3, 0}, {3, 1, 3, 3, 0},
   {2, 1, 2, 1, 0}, {2, 1, 4, 1, 0}, {2, 1, 3, 2, 0}, {2, 1, 1, 3, 0}, {2, 1, 2, 3, 0}, {2, 1, 3, 3, 0},
@@ -32,6 +33,16 @@ static bool conv_m16_eligible(const PackedConv& pc) {
   static const char* e = dev_env("SCPOSE_M16");
   if (pc.mrep == kMrep48) return true;   // (conv_m32_choose checked the layer; this family has no 32x32x16 form)
   return pc.ks == 3 && pc.stride == 1 && pc.mrep == 3 && pc.wm == 1 && pc.cp == 2 && (pc.cin / 16) % 2 == 0 && pc.cin / 16 >= 3 && !(e && atoi(e) == 0);
+}
+
+// Two consumer waves per SIMD (768-thread workgroups): built for 6 and 4 columns per tile group (3 / 2 per consumer wave).
+// SCPOSE_M16_CW2 (development): 0 = never, 1 = every eligible layer, 2 = only layers with more than one Cout block (192 / 384 channels)
+static int m32p_two_consumer_waves(const PackedConv& pc, int nb16, int cp) {
+  static const char* e = dev_env("SCPOSE_M16_CW2");
+  const int mode = e ? atoi(e) : kM16Cw2Default;
+  if (mode == 0 || pc.mrep != 3 || pc.stride != 1 || !(nb16 == 6 || nb16 == 4)) return 0;
+  (void)cp;
+  return mode == 1 || pc.n_mblk > 1;
 }
 
 bool conv_m32_choose(int cin, int cout, int ks, int stride, int* mr, int* wm, int* cp) {
@@ -275,10 +286,13 @@ int32_t conv_launch_m32(const PackedConv& pc, ConvLaunch& L, hipStream_t stream)
   if (b_occ == 3) {
     // L.groups doubles as "K-chunks of weights held in producer registers" for the producer/consumer kernel
     static const char* wr_env = dev_env("SCPOSE_M32_WREG");
-    L.groups = (pc.n_mblk == 1 && ck.nchunks == 6 && ck.cp == 2 && pc.stride == 1 && pc.mrep == 3 && (b_nb16 > 0 ? b_nb16 == 6 : b_nr == 3) && !(wr_env && atoi(wr_env) == 0)) ? 6 : 1;
+    // two consumer waves per SIMD (conv_m32p_kernel.h, CW2; round 6): a property of the LAYER (its Cout-block count), not of the batch, so
+    // that a frame's sums are formed in one order whatever the batch -- the consumers' MFMA order per pixel is the same in both forms anyway
+    const int cw2 = m32p_two_consumer_waves(pc, b_nb16, ck.cp);
+    L.groups = (!cw2 && pc.n_mblk == 1 && ck.nchunks == 6 && ck.cp == 2 && pc.stride == 1 && pc.mrep == 3 && (b_nb16 > 0 ? b_nb16 == 6 : b_nr == 3) && !(wr_env && atoi(wr_env) == 0)) ? 6 : 1;
     // b_nb16 > 0: 16x16x32 consumers (conv_m32p_kernel.h, C16; round 4) -- see conv_m16_eligible
-    if (pc.dtype == SCPOSE_DT_BF16) return conv_m32p_dispatch_bf16(pc.stride, pc.mrep, b_nr, b_nb16, L, lds, stream);
-    return conv_m32p_dispatch_f16(pc.stride, pc.mrep, b_nr, b_nb16, L, lds, stream);
+    if (pc.dtype == SCPOSE_DT_BF16) return conv_m32p_dispatch_bf16(pc.stride, pc.mrep, b_nr, b_nb16, cw2, L, lds, stream);
+    return conv_m32p_dispatch_f16(pc.stride, pc.mrep, b_nr, b_nb16, cw2, L, lds, stream);
   }
   if (pc.dtype == SCPOSE_DT_BF16) return conv_m32_dispatch_bf16(pc.mrep, pc.wm, b_nr, b_occ, L, lds, stream);
   return conv_m32_dispatch_f16(pc.mrep, pc.wm, b_nr, b_occ, L, lds, stream);

@@ -30,10 +30,10 @@ constexpr bool m16_rowpair(int S) { return S == 3 || S == 8; }
 // of k-step S + 1 goes to the slot column N - 1 released one column earlier (never to a register an MFMA in flight still reads)
 constexpr int m16_ring(int N, int S, int RING) { return ((N - S) % RING + 4 * RING) % RING; }
 // behind column n a prefetching k-step requests m16_na(NB, n) of the next k-step's six A fragments, then its B fragment of column n
-constexpr int m16_na(int NB, int n) { return NB == 2 ? 3 : (n < 2 ? 2 : n < 4 ? 1 : 0); }   // NB 6: 2 2 1 1 0 0, 5: 2 2 1 1 0, 4: 2 2 1 1, 2: 3 3
+constexpr int m16_na(int NB, int n) { return NB == 2 ? 3 : NB == 3 ? (n < 2 ? 3 : 0) : (n < 2 ? 2 : n < 4 ? 1 : 0); }   // NB 6: 2 2 1 1 0 0, 5: 2 2 1 1 0, 4: 2 2 1 1, 3: 3 3 0, 2: 3 3
 constexpr int m16_afirst(int NB, int n) { int a = 0; for (int k = 0; k < n; ++k) a += m16_na(NB, k); return a; }
 constexpr int m16_issued(int NB, int n) { return m16_afirst(NB, n) + n; }   // requests of a prefetching k-step in front of its column n
-constexpr int m16_ja(int NB) { return NB == 2 ? 1 : 3; }                    // the column that requests the last A fragment
+constexpr int m16_ja(int NB) { return NB <= 3 ? 1 : 3; }                    // the column that requests the last A fragment
 // LDS returns in order: lgkmcnt value to wait for in front of column n (-1: what it needs is older than something already waited for).
 // first: the k-step's fragments were requested in one burst, A0..5 B0..NB-1; more: the k-step itself prefetches.
 constexpr int m16_wait(int NB, int n, bool first, bool more) {
@@ -45,6 +45,7 @@ constexpr int m16_wait(int NB, int n, bool first, bool more) {
 static_assert(m16_wait(6, 0, true, true) == 5 && m16_wait(6, 1, true, true) == 7 && m16_wait(6, 3, true, true) == 10 && m16_wait(6, 5, true, true) == 11, "");
 static_assert(m16_wait(6, 0, false, true) == 3 && m16_wait(6, 2, false, true) == -1 && m16_wait(6, 3, false, true) == 10 && m16_wait(6, 4, false, true) == 11, "");
 static_assert(m16_wait(6, 0, false, false) == 3 && m16_wait(6, 3, false, false) == 2 && m16_wait(6, 5, false, false) == 0, "");
+static_assert(m16_wait(3, 0, false, true) == 2 && m16_wait(3, 1, false, true) == 5 && m16_wait(3, 2, false, true) == 8 && m16_wait(3, 2, false, false) == 0 && m16_wait(3, 0, true, true) == 2, "");
 static_assert(m16_wait(2, 0, false, true) == 1 && m16_wait(2, 1, false, true) == 4 && m16_wait(5, 4, false, true) == 10 && m16_wait(4, 3, false, true) == 8, "");
 
 // 48-row Cout blocks (three 16-row blocks, NB = 8 columns per consumer wave: 3 x 8 accumulators).  A prefetching k-step requests the
@@ -91,8 +92,15 @@ static_assert(m48_wait(8, 0, true, true) == 7 && m48_wait(8, 7, true, true) == 1
 // ADDR: 0 = every tensor of the launch is buffer-addressed (< 4 GiB), 1 = 64-bit pointers, 2 = decided at run time (p.in_bytes).  The
 // 16x16x32-consumer variants are built for 0 and 1 separately: with both paths in one kernel the producers' stage loop is twice the
 // code and spills 70 SGPRs (round 5).
-template <int DT, int KS, int STRIDE, int MR, int NR, int WREG = 0, int C16 = 0, int M16 = 0, int ADDR = 2>
-__global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
+// CW2 = 1 (round 6): TWO consumer waves per SIMD -- a 768-thread workgroup, waves 0-7 consumers (each C16 / 2 columns of the same
+// C16 x 64-pixel tile group: 6 x 3 accumulators, 72 registers), waves 8-11 producers; three waves per SIMD leave 168 registers per
+// wave, so the producers cannot hold the layer's weights (WREG = 0 only).  Why: with one consumer wave per SIMD the matrix pipe
+// idles whenever that wave waits for fragments, runs its epilogue or sits at the stage barrier (busy 0.43-0.53);
+// with two, one wave's waits sit under its partner's MFMAs.  Costs 1.5x the LDS fragment reads (9 per 18 MFMAs instead of 12 per 36).
+template <int DT, int KS, int STRIDE, int MR, int NR, int WREG = 0, int C16 = 0, int M16 = 0, int ADDR = 2, int CW2 = 0>
+__global__ __launch_bounds__(CW2 ? 768 : 512, CW2 ? 3 : 2) void conv_m32p_kernel(const ConvLaunch p) {
+  static_assert(!CW2 || (C16 > 0 && C16 % 2 == 0 && WREG == 0 && M16 == 0), "two consumer waves per SIMD: 16x16x32 consumers, even column count, weights by LDS-DMA");
+  constexpr int NCW = CW2 ? 8 : 4;             // consumer waves
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename DtOf<DT>::type T;
   typedef typename FragOf<T>::type frag_t;
@@ -112,7 +120,8 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: role branch, LDS-DMA bases and M0 values stay scalar
-  const bool producer = wave_all >= 4;
+  const bool producer = wave_all >= NCW;
+  const int cw = wave_all;                     // consumer wave index, 0 .. NCW - 1 (16x16x32 consumers)
   const int wave = wave_all & 3, ptid = tid & 255;
   const int half = lane >> 5, r = lane & 31;
   const int HW = p.H * p.W;
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
   const int tiles_per_img = p.tiles_x * p.tiles_y;
   const size_t chunk_wbytes = (size_t)ksteps_full * (2 * MT * 16);
 
-  for (int i = tid; i < p.n_mblk * MT; i += 512) bias_l[i] = p.bias[i];
+  for (int i = tid; i < p.n_mblk * MT; i += (CW2 ? 768 : 512)) bias_l[i] = p.bias[i];
 
   const int wg = xcd_remap(blockIdx.x, p.grid);
   const int it_begin = wg * p.items_per_wg;
@@ -175,6 +184,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
     // met the stage barrier (round 5).  They now go round the waves by plane: NX = 2: waves 0, 1 on even planes, 2, 3 on odd ones;
     // NX = 1: wave pl & 3.  A thread still owns at most two slots (ptid, and 256 + 64 (wave & 1) + lane).
     constexpr int NX = (PXCAP > 256 && PXCAP < 512) ? (PXCAP - 256) / 64 : 0;
+    static_assert(NX <= 2, "the retire-buffer slot rotation is written for one or two extra 64-slot chunks (PXCAP 320 / 384)");
     auto slot_of = [&](int k) -> int { return (k == 0 || NX == 0) ? k * 256 + ptid : 256 + (NX == 2 ? (wave & 1) : 0) * 64 + lane; };
     auto wslot_of = [&](int k) -> int { return (k == 0 || NX == 0) ? k * 256 + wave * 64 : 256 + (NX == 2 ? (wave & 1) : 0) * 64; };   // the wave's first slot
     auto moves = [&](int k, int pl) -> bool {   // wave-uniform: does this wave move pixel group k of plane pl?
@@ -390,17 +400,17 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
     }
     if (it_begin < it_end && !SCP_DBG(p, 2)) store_results(it_end - 1, qb_prev, 0, ROPL);   // drain the last tile
     if (SCP_DBG(p, 8) && SCP_DBG_BUF(p) && lane == 0)
-      for (int k = 0; k < 6; ++k) SCP_DBG_BUF(p)[((size_t)blockIdx.x * 8 + wave_all) * 6 + k] = tph[k];
+      for (int k = 0; k < 6; ++k) SCP_DBG_BUF(p)[((size_t)blockIdx.x * 8 + 4 + wave) * 6 + k] = tph[k];   // slots 4-7: the producer waves
   } else if constexpr (C16 != 0) {
     // =====================================================================================
     // consumers, 16x16x32 form (see the header comment): LDS reads, MFMAs, epilogue into the retire buffer
     // =====================================================================================
     static_assert(KS == 3 && (MT == 96 || MT == 48), "16x16x32 consumers: 3x3 layers, 96- or 48-row Cout blocks");
     constexpr int MB = MT / 16;          // 16-row blocks of the Cout block
-    constexpr int NB = C16;              // 16-pixel columns of a consumer wave (PXCAP = 64 NB pixel slots per tile group)
+    constexpr int NB = CW2 ? C16 / 2 : C16;   // 16-pixel columns of a consumer wave (PXCAP = 16 NB NCW pixel slots per tile group)
     constexpr int RING = NB + 1;
     constexpr int TAPB = 2 * MT * 16;    // bytes of one tap (both planes) in the packed weight image
-    static_assert(MB == 6 ? (NB == 2 || NB == 4 || NB == 5 || NB == 6) : (MB == 3 && NB == 8), "16x16x32 consumers: column counts with a prefetch schedule");
+    static_assert(MB == 6 ? (NB == 2 || NB == 3 || NB == 4 || NB == 5 || NB == 6) : (MB == 3 && NB == 8), "16x16x32 consumers: column counts with a prefetch schedule");
     typedef f32x4 acc_t;
     // Lane (q = lane >> 4, l15 = lane & 15): plane q & 1 of a plane pair; class q >> 1 picks the tap of a k-step's pair.
     // Pairs are chosen so that the two classes' fragment addresses differ by a constant: one pixel (taps kx, kx + 1 of a row) or
@@ -416,14 +426,14 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
       int ps, py, px;
-      pixel_of((wave * NB + n) * 16 + (lane & 15), ps, py, px);
+      pixel_of((cw * NB + n) * 16 + (lane & 15), ps, py, px);
       pixoffq[n] = (ps >= 0 ? (ps * HP + (py * STRIDE) * p.halo_w + px * STRIDE) * 16 : 0) + ((lane >> 4) & 1) * p.plane_stride;
     }
     const uint32_t hw16 = (uint32_t)p.halo_w * 16u;
     const uint32_t sh_px = (uint32_t)(lane >> 5) * 16u, sh_row = (uint32_t)(lane >> 5) * hw16;   // class shifts of the B address
     acc_t acc[MB][NB];
     frag_t a0[MB], a1[MB], bR[RING];
-    const bool wave_idle = wave * NB * 16 >= P;   // wave-uniform
+    const bool wave_idle = cw * NB * 16 >= P;   // wave-uniform
     if (SCP_DBG(p, 512)) __builtin_amdgcn_s_setprio(3);   // (development: consumers at the producers' priority -- arbitration by age)
     const int npp = p.cp >> 1;                    // plane pairs per stage: 1 (the halves of a pair are two stages), 2 or 4
     int wc = 0, xb = 0;
@@ -676,6 +686,25 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
                   : [wm] "v"(wa0), [x0] "v"(xa[0]), [x1] "v"(xa[1]), [x2] "v"(xa[2]), [x3] "v"(xa[3]),
                     [o0] "n"(2 * TAPB + 0), [o1] "n"(2 * TAPB + 256), [o2] "n"(2 * TAPB + 512), [o3] "n"(2 * TAPB + 768), [o4] "n"(2 * TAPB + 1024), [o5] "n"(2 * TAPB + 1280)
                   : "memory");
+              } else if constexpr (NB == 3) {
+                asm volatile(
+                  "s_mov_b64 %[keep], exec\n\t"
+                  "s_mov_b32 exec_lo, 0\n\t"
+                  "ds_read_b128 %[a0], %[wm] offset:%[o0]\n\t"
+                  "ds_read_b128 %[a1], %[wm] offset:%[o1]\n\t"
+                  "ds_read_b128 %[a2], %[wm] offset:%[o2]\n\t"
+                  "ds_read_b128 %[a3], %[wm] offset:%[o3]\n\t"
+                  "ds_read_b128 %[a4], %[wm] offset:%[o4]\n\t"
+                  "ds_read_b128 %[a5], %[wm] offset:%[o5]\n\t"
+                  "ds_read_b128 %[b0], %[x0]\n\t"
+                  "ds_read_b128 %[b1], %[x1]\n\t"
+                  "ds_read_b128 %[b2], %[x2]\n\t"
+                  "s_mov_b64 exec, %[keep]"
+                  : [keep] "=&s"(keep), [a0] "+v"(a0[0]), [a1] "+v"(a0[1]), [a2] "+v"(a0[2]), [a3] "+v"(a0[3]), [a4] "+v"(a0[4]), [a5] "+v"(a0[5]),
+                    [b0] "+v"(bR[m16_ring(0, 4, RING)]), [b1] "+v"(bR[m16_ring(1, 4, RING)]), [b2] "+v"(bR[m16_ring(NB == 3 ? 2 : 0, 4, RING)])
+                  : [wm] "v"(wa0), [x0] "v"(xa[0]), [x1] "v"(xa[1]), [x2] "v"(xa[NB == 3 ? 2 : 0]),
+                    [o0] "n"(2 * TAPB + 0), [o1] "n"(2 * TAPB + 256), [o2] "n"(2 * TAPB + 512), [o3] "n"(2 * TAPB + 768), [o4] "n"(2 * TAPB + 1024), [o5] "n"(2 * TAPB + 1280)
+                  : "memory");
               } else if constexpr (NB == 2) {
                 asm volatile(
                   "s_mov_b64 %[keep], exec\n\t"
@@ -722,7 +751,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
           // live across the k-steps, which have no register to spare)
           uint32_t lane_e = (uint32_t)lane;
           asm volatile("" : "+v"(lane_e));
-          char* const slot0 = ro + ((((lane_e >> 5) & 1) * PXCAP) + wave * NB * 16 + (lane_e & 15)) * 16 + 8 * ((lane_e >> 4) & 1);
+          char* const slot0 = ro + ((((lane_e >> 5) & 1) * PXCAP) + cw * NB * 16 + (lane_e & 15)) * 16 + 8 * ((lane_e >> 4) & 1);
           auto slot = [&](int m, int n) -> char* { return slot0 + ((2 * m) * PXCAP + n * 16) * 16; };
           if (!p.res) {
 #pragma unroll
@@ -791,7 +820,7 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
       }
     }
 #undef M16_BASES
-    if (SCP_DBG(p, 8) && SCP_DBG_BUF(p) && lane == 0)
+    if (SCP_DBG(p, 8) && SCP_DBG_BUF(p) && lane == 0 && wave_all < 4)   // slots 0-3 (two consumer waves per SIMD: the first four)
       for (int k = 0; k < 6; ++k) SCP_DBG_BUF(p)[((size_t)blockIdx.x * 8 + wave_all) * 6 + k] = tph[k];
   } else {
     // =====================================================================================
@@ -992,28 +1021,34 @@ __global__ __launch_bounds__(512, 2) void conv_m32p_kernel(const ConvLaunch p) {
   }
 }
 
-template <int DT, int STRIDE, int MR, int NR, int WREG = 0, int C16 = 0, int M16 = 0, int ADDR = 2>
+template <int DT, int STRIDE, int MR, int NR, int WREG = 0, int C16 = 0, int M16 = 0, int ADDR = 2, int CW2 = 0>
 int32_t m32p_launch_addr(const ConvLaunch& L, size_t lds, hipStream_t st) {
-  auto kern = conv_m32p_kernel<DT, 3, STRIDE, MR, NR, WREG, C16, M16, ADDR>;
+  auto kern = conv_m32p_kernel<DT, 3, STRIDE, MR, NR, WREG, C16, M16, ADDR, CW2>;
   static LdsOptIn big_lds;   // per device (common.h)
   { const int32_t rc = lds_opt_in(reinterpret_cast<const void*>(kern), 160 * 1024, &big_lds); if (rc != SCPOSE_OK) return rc; }
-  hipLaunchKernelGGL(kern, dim3(L.grid), dim3(512), lds, st, L);
+  hipLaunchKernelGGL(kern, dim3(L.grid), dim3(CW2 ? 768 : 512), lds, st, L);
   SCP_CHECK_HIP(hipGetLastError());
   return SCPOSE_OK;
 }
 
-template <int DT, int STRIDE, int MR, int NR, int WREG = 0, int C16 = 0, int M16 = 0>
+template <int DT, int STRIDE, int MR, int NR, int WREG = 0, int C16 = 0, int M16 = 0, int CW2 = 0>
 int32_t m32p_launch_one(const ConvLaunch& L, size_t lds, hipStream_t st) {
   if constexpr (C16 != 0) {   // one addressing mode per kernel (see ADDR)
-    return L.in_bytes != 0 ? m32p_launch_addr<DT, STRIDE, MR, NR, WREG, C16, M16, 0>(L, lds, st)
-                           : m32p_launch_addr<DT, STRIDE, MR, NR, WREG, C16, M16, 1>(L, lds, st);
+    return L.in_bytes != 0 ? m32p_launch_addr<DT, STRIDE, MR, NR, WREG, C16, M16, 0, CW2>(L, lds, st)
+                           : m32p_launch_addr<DT, STRIDE, MR, NR, WREG, C16, M16, 1, CW2>(L, lds, st);
   } else {
     return m32p_launch_addr<DT, STRIDE, MR, NR, WREG, C16, M16, 2>(L, lds, st);
   }
 }
 
 template <int DT>
-int32_t m32p_dispatch(int stride, int mr, int nr, int c16, const ConvLaunch& L, size_t lds, hipStream_t st) {
+int32_t m32p_dispatch(int stride, int mr, int nr, int c16, int cw2, const ConvLaunch& L, size_t lds, hipStream_t st) {
+  if (c16 && cw2) {   // two consumer waves per SIMD (768 threads)
+    if (stride == 1 && mr == 3 && c16 == 6) return m32p_launch_one<DT, 1, 3, 3, 0, 6, 0, 1>(L, lds, st);
+    if (stride == 1 && mr == 3 && c16 == 4) return m32p_launch_one<DT, 1, 3, 2, 0, 4, 0, 1>(L, lds, st);
+    set_error("conv m32p: two-consumer-wave variant stride=%d mr=%d columns=%d not built", stride, mr, c16);
+    return SCPOSE_E_INVALID;
+  }
   if (c16) {   // 16x16x32 consumers, c16 = 16-pixel columns per consumer wave (conv_launch_m32 routes only stride 1 and 96-row blocks here)
     if (stride == 1 && mr == 3) {
       if (c16 == 6) return L.groups == 6 ? m32p_launch_one<DT, 1, 3, 3, 6, 6>(L, lds, st) : m32p_launch_one<DT, 1, 3, 3, 0, 6>(L, lds, st);

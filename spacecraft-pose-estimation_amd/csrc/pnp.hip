@@ -1104,6 +1104,9 @@ __global__ __launch_bounds__(256) void pnp_kernel(const PnpArgs a) {
 
   if (lane == 0) {
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    // a degenerate final solve (non-finite rvec / tvec) is reported, not written: status -4, identity / zero pose like the other
+    // failures -- one such frame must not put NaN into opencv_poses.json
+    if (status > 0 && !(isfinite(rvec[0]) && isfinite(rvec[1]) && isfinite(rvec[2]) && isfinite(tvec[0]) && isfinite(tvec[1]) && isfinite(tvec[2]))) status = -4;
     if (status > 0) rodrigues_vec2mat(rvec, R);
     else { rvec[0] = rvec[1] = rvec[2] = 0; tvec[0] = tvec[1] = tvec[2] = 0; }
     if (a.rows) {   // the block a rank all-gathers / copies to the host: one row per frame, no assembly launches

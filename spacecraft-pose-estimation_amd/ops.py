@@ -266,6 +266,8 @@ def pnp_epnp_ransac(kp_xyc, landmarks, K, dist, conf_thr0=0.95, min_pts=15, thr_
     elif dd.numel() != 5:
         raise nat.NativeError("pnp_epnp_ransac: %d distortion coefficients; supported are 4 or 5 (k1,k2,p1,p2[,k3])" % dd.numel())
     if rows is not None:
+        if want_rvec:     # the gather block has no rvec column: refuse instead of silently returning one tensor
+            raise nat.NativeError("pnp_epnp_ransac: rows=... excludes want_rvec (the (N, 13) block is [R, t, status]); call without rows for rvec")
         if tuple(rows.shape) != (n, 13) or rows.dtype != torch.float64 or not rows.is_contiguous() or rows.device != dev:
             raise nat.NativeError("pnp_epnp_ransac: rows must be a contiguous float64 (%d, 13) tensor on %s" % (n, dev))
         nat.check(nat.lib().scpose_pnp_epnp_ransac_rows(_ptr(kp), _ptr(lm), _ptr(Kd), _ptr(dd), n, j, conf_thr0, min_pts, thr_decay,

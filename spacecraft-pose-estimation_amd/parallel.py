@@ -94,15 +94,44 @@ def loader_worker_context(num_workers):
     forkserver context whose server has torch / NumPy / PIL / this package imported already.  Workers are then forked from that clean
     server -- never from this process: forking a process with a live HIP context is unsupported, and measured here a loader whose
     workers were forked from the GPU process decoded 5x slower in steady state (profiles/round5_pipeline.json) -- and start in
-    tens of milliseconds each instead of re-importing torch (8 s for 8 workers, 29 s for 32 without the preload)."""
+    tens of milliseconds each instead of re-importing torch (8 s for 8 workers, 29 s for 32 without the preload).
+    CPython 3.10's fork server does not apply the parent's sys.path before it imports the preload list (and swallows the
+    ImportError), so the repository root -- where the `scpose` alias module lives, which the CLIs add with sys.path.insert -- is
+    put on PYTHONPATH for the server; tests/test_host.py checks that a worker starts with the package imported."""
     if not num_workers:
         return None
     import multiprocessing as mp
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    paths = os.environ.get("PYTHONPATH", "").split(os.pathsep) if os.environ.get("PYTHONPATH") else []
+    if root not in paths:
+        os.environ["PYTHONPATH"] = os.pathsep.join([root] + paths)
     try:
         mp.set_forkserver_preload(["torch", "numpy", "PIL.Image", "torch.utils.data", "scpose"])
     except Exception:      # the server is already running: its preload list stands
         pass
     return mp.get_context("forkserver")
+
+
+def auto_workers(n_frames, cfg_workers, keep=False):
+    """Loader worker processes for a data set of n_frames: cfg.WORKERS when it is set; the reference's YAML says WORKERS: 0
+    (events-config.yaml:10), which decodes every frame in the CLI's own process at ~100 frames/s -- for 512 frames or more the CLIs
+    use min(32, cores / 4) workers instead (same output; 8 workers 1 109, 32 workers 3 778 frames/s of decoding on a 256-core host,
+    profiles/round5_pipeline.json), unless --no_auto_workers (keep=True).  Smaller sets are not worth the workers' start-up."""
+    w = int(cfg_workers)
+    if w > 0 or keep or n_frames < 512:
+        return w
+    return max(1, min(32, (os.cpu_count() or 1) // 4))
+
+
+def valid_loader(dataset, lo, hi, world_size, batch_size, workers, device_crop):
+    """The DataLoader of tools/test.py:116-122 (shuffle=False, pinned) over this rank's shard [lo, hi) of `dataset`, with the build's two
+    extensions: workers from a clean pre-loaded fork server, and -- with GPU crop warp -- batches of packed frame windows."""
+    import torch.utils.data
+    subset = torch.utils.data.Subset(dataset, range(lo, hi)) if world_size > 1 else dataset
+    return torch.utils.data.DataLoader(subset, batch_size=batch_size, shuffle=False, num_workers=workers,
+                                       pin_memory=True,   # (the packed frame windows too: a background thread pins them, the copy to the device is then asynchronous)
+                                       multiprocessing_context=loader_worker_context(workers),
+                                       collate_fn=dataset.collate_device_crop if device_crop else None)
 
 
 def free_port():
@@ -163,37 +192,3 @@ def spawn_local_ranks(argv, nprocs, env=None, timeout=None):
         import shutil
         shutil.rmtree(rdzv_dir, ignore_errors=True)
     return worst
-
-
-class ThreadedLoader:
-    """A batch iterator over a map-style dataset that decodes with THREADS of this process instead of DataLoader worker processes.
-
-    Why: with GPU crop warp the loader's work per frame is image decoding (PIL releases the GIL while it decodes and converts) plus a
-    slice; worker processes pay for it twice more -- every batch is pickled through shared memory into the main process, and the
-    workers must never be forked from a process that holds a HIP context (loader_worker_context).  Threads share the address space: no
-    copies, no start-up, and the pool scales to the host's cores.  Order is the dataset's (`shuffle=False` semantics), batches are
-    collated with `collate_fn` (default: torch's default_collate), `prefetch` batches are decoded ahead of the consumer."""
-
-    def __init__(self, dataset, batch_size, threads, collate_fn=None, prefetch=4, indices=None):
-        self.dataset, self.batch_size, self.threads, self.prefetch = dataset, int(batch_size), max(1, int(threads)), max(1, int(prefetch))
-        self.indices = list(range(len(dataset))) if indices is None else list(indices)
-        if collate_fn is None:
-            from torch.utils.data import default_collate
-            collate_fn = default_collate
-        self.collate_fn = collate_fn
-
-    def __len__(self):
-        return (len(self.indices) + self.batch_size - 1) // self.batch_size
-
-    def __iter__(self):
-        from collections import deque
-        from concurrent.futures import ThreadPoolExecutor
-        batches = [self.indices[i:i + self.batch_size] for i in range(0, len(self.indices), self.batch_size)]
-        with ThreadPoolExecutor(self.threads) as pool:
-            pending = deque()
-            nxt = 0
-            while nxt < len(batches) or pending:
-                while nxt < len(batches) and len(pending) < self.prefetch:
-                    pending.append([pool.submit(self.dataset.__getitem__, k) for k in batches[nxt]])
-                    nxt += 1
-                yield self.collate_fn([f.result() for f in pending.popleft()])

@@ -97,6 +97,9 @@ def export(frames_dir, detection_annotations, pose_annotations, landmarks_file, 
     return poses
 
 
+_INF = float("inf")
+
+
 def dumps_poses(poses):
     """json.dumps(poses, indent=2) (:235-236) for a list of pose records, written out directly: the standard library formats indented
     output with its pure-Python encoder (0.11 ms per record); the records have a fixed shape, so the same text -- float repr, key order,
@@ -104,7 +107,15 @@ def dumps_poses(poses):
     with json.dumps byte for byte)."""
     if not poses:
         return "[]"
-    fr = float.__repr__
+
+    def fr(v, _repr=float.__repr__):
+        # json.dumps writes non-finite floats as NaN / Infinity / -Infinity (allow_nan=True), float.__repr__ as nan / inf / -inf,
+        # which json.loads rejects: one degenerate frame must not make the whole file unreadable (ADVICE r5)
+        if v != v:
+            return "NaN"
+        if v in (_INF, -_INF):
+            return "Infinity" if v > 0 else "-Infinity"
+        return _repr(v)
     recs = []
     for p in poses:
         t = ",\n".join("      [\n        %s\n      ]" % fr(float(row[0])) for row in p["T"])

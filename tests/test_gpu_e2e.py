@@ -227,7 +227,7 @@ def test_cli_tools_test_and_pose_export(pk, tmp_path):
         return loadmat(o / "EventsDataset" / "pose_hrnet" / "w32_256" / "pred_test.mat")["preds"], r2.stdout + r2.stderr
     assert "fused forward -> key-point path" in r.stdout + r.stderr                  # the default run above took the fused path
     for tag, flags, batch in (("ref_flow", ["--host_crop", "--log_metrics"], "4"), ("dev_crop_heatmaps", ["--log_metrics"], "4"),
-                              ("host_crop_fused", ["--host_crop"], "4"), ("graph_replay", [], "2"), ("legacy_flag", ["--device_crop"], "4")):
+                              ("host_crop_fused", ["--host_crop"], "4"), ("graph_replay", ["--engine_batch", "0"], "2"), ("legacy_flag", ["--device_crop"], "4")):
         preds_v, log = run(tag, flags, batch)
         assert np.array_equal(preds_v, preds), tag
         assert ("fused forward -> key-point path" in log) == ("--log_metrics" not in flags), tag
@@ -238,11 +238,13 @@ def test_cli_tools_test_and_pose_export(pk, tmp_path):
     assert np.array_equal(preds_w, preds)
     preds_w, _ = run("workers2_host_crop", ["--host_crop"], "4", workers="2")
     assert np.array_equal(preds_w, preds)
-    # ... or the frames are decoded by threads of the CLI's own process (parallel.ThreadedLoader)
-    preds_w, _ = run("threads3", ["--loader_threads", "3"], "4")
-    assert np.array_equal(preds_w, preds)
-    preds_w, _ = run("threads2_ref_flow", ["--loader_threads", "2", "--host_crop", "--log_metrics"], "4")
-    assert np.array_equal(preds_w, preds)
+    # engine-batch coalescing (core/function.py: _Coalescer): loader batches of 1 queued into engine batches of 2 (the second is captured, the
+    # third replays), one launch per loader batch (--engine_batch 0), and the reference's data flow, which keeps the loader's batches
+    for tag, flags, batch in (("coalesce_1_into_2", ["--engine_batch", "2"], "1"), ("no_coalescing", ["--engine_batch", "0"], "2"),
+                              ("coalesce_ignored_with_metrics", ["--engine_batch", "4", "--host_crop", "--log_metrics"], "1")):
+        preds_w, log = run(tag, flags, batch)
+        assert np.array_equal(preds_w, preds), tag
+        assert ("coalesced into engine batches" in log) == (tag == "coalesce_1_into_2"), tag
 
     # a data set of 512+ frames is decoded by worker processes even though the YAML says WORKERS: 0 (as the reference's events-config.yaml does);
     # rows follow annotations[] order whatever the workers' completion order

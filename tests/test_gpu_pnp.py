@@ -171,3 +171,48 @@ def test_pnp_rows_entry_point_writes_the_gather_block(gpu_ops):
     with pytest.raises(gpu_ops.nat.NativeError, match="rows"):
         gpu_ops.pnp_epnp_ransac(torch.from_numpy(kp).cuda(), torch.from_numpy(P.LANDMARKS).cuda(), torch.from_numpy(P.CAMERA_K).cuda(),
                                 torch.from_numpy(P.CAMERA_DIST).cuda(), rows=torch.zeros(64, 12, dtype=torch.float64, device="cuda"))
+
+
+def test_kernel_rodrigues_agrees_with_scipy_rotation(gpu_ops):
+    """The kernel's Rodrigues, both directions (csrc/pnp.hip: rvec = mat2vec(R of the final EPnP), R out = vec2mat(rvec), what
+    export_predicted_poses_real.py:203 gets from cv2.Rodrigues), against scipy.spatial.transform.Rotation -- an independent
+    implementation, since cv2 itself cannot be had.  Poses with rotation angles over the whole range, theta -> 0
+    (1e-3 .. 1e-7: below sin(theta) = 1e-5 OpenCV's Rodrigues returns the zero vector, restated and kept) and theta -> pi
+    (pi - 1e-3 .. pi - 1e-6), on exact projections, so the solve recovers them to ~1e-8:
+      vec -> mat: R_out = Rotation.from_rotvec(rvec_out).as_matrix() to 1e-13;
+      mat -> vec: rvec_out = Rotation.from_matrix(R_out).as_rotvec() up to the r ~ -r ambiguity at pi, to 1e-7;
+    and the -4 status for a non-finite solve never shows on these well-posed frames."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(123)
+    thetas = np.concatenate([rng.uniform(0.05, np.pi - 0.05, 40), [1e-3, 1e-4, 3e-5, 1e-6, 1e-7], np.pi - np.array([1e-3, 1e-4, 3e-5, 1e-6])])
+    kps, poses = [], []
+    for th in thetas:
+        for _ in range(3):
+            a = rng.standard_normal(3); a /= np.linalg.norm(a)
+            R = Rotation.from_rotvec(a * th).as_matrix()
+            t = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.2, 0.2), rng.uniform(4.0, 8.0)])
+            uv = P.project_numpy(R, t, P.LANDMARKS)
+            if uv.min() < 0 or uv[:, 0].max() > 1920 or uv[:, 1].max() > 1200:
+                continue
+            kps.append(np.concatenate([uv, np.ones((11, 1))], 1).astype(np.float32)); poses.append((th, R, t))
+    kp = np.stack(kps)
+    rot, tv, st, rv = _gpu(gpu_ops, kp)
+    assert (st == 11).all()
+    worst_v2m = worst_m2v = 0.0
+    for i, (th, R, t) in enumerate(poses):
+        assert P.rot_angle(rot[i:i + 1], R[None])[0] < 2e-5 and np.linalg.norm(tv[i] - t) / np.linalg.norm(t) < 2e-5
+        v2m = np.abs(Rotation.from_rotvec(rv[i]).as_matrix() - rot[i]).max()
+        worst_v2m = max(worst_v2m, v2m)
+        assert v2m <= 1e-13, (th, v2m)
+        if np.sin(th) < 2e-5 and np.cos(th) > 0:      # OpenCV's cut: the zero vector (and so the identity) below sin(theta) = 1e-5
+            assert np.all(rv[i] == 0) or np.linalg.norm(rv[i]) > 0.9e-5
+            continue
+        r_sp = Rotation.from_matrix(rot[i]).as_rotvec()
+        d = min(np.abs(r_sp - rv[i]).max(), np.abs(r_sp + rv[i]).max() if th > np.pi - 1e-2 else np.inf)
+        worst_m2v = max(worst_m2v, d)
+        assert d <= 1e-7, (th, d, r_sp, rv[i])
+    print("kernel Rodrigues vs scipy Rotation over %d poses: vec->mat max %.2e, mat->vec max %.2e" % (len(poses), worst_v2m, worst_m2v))
+    # the rows= entry point has no rvec column: asking for both is refused (ADVICE r5)
+    with pytest.raises(gpu_ops.nat.NativeError, match="want_rvec"):
+        gpu_ops.pnp_epnp_ransac(torch.from_numpy(kp).cuda(), torch.from_numpy(P.LANDMARKS).cuda(), torch.from_numpy(P.CAMERA_K).cuda(),
+                                torch.from_numpy(P.CAMERA_DIST).cuda(), rows=torch.zeros(len(kp), 13, dtype=torch.float64, device="cuda"), want_rvec=True)

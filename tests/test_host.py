@@ -659,7 +659,35 @@ def test_dumps_poses_is_json_dumps_indent_2_byte_for_byte():
               "rotation_matrix": (rng.standard_normal((3, 3)) * 10.0 ** float(rng.integers(-8, 8))).tolist()} for i in range(200)]
     poses[3]["T"] = [[0.0], [-0.0], [1e-320]]
     poses[4]["rotation_matrix"] = [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]
+    # a degenerate frame (non-finite pose): json.dumps writes NaN / Infinity / -Infinity, and the file must stay loadable
+    poses[5]["T"] = [[float("nan")], [float("inf")], [float("-inf")]]
+    poses[6]["rotation_matrix"] = [[float("nan"), 0.0, float("-inf")], [0.0, float("inf"), 0.0], [0.0, 0.0, 1.0]]
     assert pe.dumps_poses(poses) == json.dumps(poses, indent=2)
+    back = json.loads(pe.dumps_poses(poses))
+    assert back[5]["T"][1] == [float("inf")] and back[5]["T"][0][0] != back[5]["T"][0][0] and back[7] == poses[7]
     with_status = [dict(p, status=i - 3) for i, p in enumerate(poses)]
     assert pe.dumps_poses(with_status) == json.dumps(with_status, indent=2)
     assert pe.dumps_poses([]) == json.dumps([], indent=2)
+
+
+def test_loader_workers_start_with_the_package_imported(tmp_path):
+    """parallel.loader_worker_context: DataLoader workers are forked from a fork server that has torch AND this package
+    imported already.  CPython 3.10's fork server imports its preload list without the parent's sys.path, so the repository root has
+    to be on PYTHONPATH for it.  The probe's target is the builtin exec (unpickling it imports nothing), so what it reports is what the
+    worker had at start."""
+    import scpose  # noqa: F401
+    from importlib import import_module
+    par = import_module("spacecraft-pose-estimation_amd.parallel")
+    ctx = par.loader_worker_context(2)
+    assert ROOT in os.environ["PYTHONPATH"].split(os.pathsep)
+    out = tmp_path / "mods.json"
+    code = ("import sys, json; json.dump({k: k in sys.modules for k in ('torch', 'numpy', 'PIL.Image', 'scpose', "
+            "'spacecraft-pose-estimation_amd')}, open(%r, 'w'))" % str(out))
+    p = ctx.Process(target=exec, args=(code,))
+    p.start(); p.join(120)
+    assert p.exitcode == 0
+    mods = json.loads(out.read_text())
+    assert all(mods.values()), mods
+    assert par.loader_worker_context(0) is None
+    assert par.auto_workers(100, 0) == 0 and par.auto_workers(5000, 3) == 3 and par.auto_workers(5000, 0, keep=True) == 0
+    assert par.auto_workers(5000, 0) == max(1, min(32, (os.cpu_count() or 1) // 4))

@@ -110,6 +110,11 @@ def test_bench_step_loop_two_ranks_over_gloo(capfd):
     assert line["n_gpus"] == 2 and line["config"]["frames_per_step"] == 32 and line["poses_total"] == 32 and line["poses_ok"] == 32
     assert line["stub_check"] is True and line["steps"] == 4 and line["metric"].startswith("STUB")
     assert line["ms_per_step"] > 0 and line["roofline"]["profiled_steps"] >= 1
+    # the line proves who took part: one report per rank, gathered over the process group, and every rank's block its own
+    rc = line["rccl"]
+    assert rc["world_size"] == 2 and rc["backend"] == "gloo" and [x["rank"] for x in rc["ranks_reporting"]] == [0, 1]
+    assert len({x["pid"] for x in rc["ranks_reporting"]}) == 2 and all(x["ms_per_step"] > 0 for x in rc["ranks_reporting"])
+    assert rc["rank_blocks_distinct"] is True
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args,
                        capture_output=True, text=True, timeout=300, env=env, cwd="/tmp")

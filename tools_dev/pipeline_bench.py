@@ -102,11 +102,9 @@ def run(frames=2048, workers=8, batch=64, model="w48", keep=None, mp_ctx="forkse
     net = net.cuda().eval()
     tf = transforms.Compose([transforms.ToTensor(), transforms.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])])
 
-    def loader(device_crop, nworkers, want_target, threads=0, pin=True):
+    def loader(device_crop, nworkers, want_target, pin=True):
         ds = getattr(dataset, cfg.DATASET.DATASET)(cfg, cfg.DATASET.ROOT, cfg.DATA_DIR, cfg.DATASET.TEST_SET, False, tf)
         ds.device_crop = device_crop; ds.want_target = want_target
-        if threads > 0:      # tools/test.py --loader_threads N: decoding threads of this process instead of worker processes
-            return ds, parallel.ThreadedLoader(ds, batch, threads, collate_fn=ds.collate_device_crop if device_crop else None)
         return ds, torch.utils.data.DataLoader(ds, batch_size=batch, shuffle=False, num_workers=nworkers, pin_memory=pin,
                                                # as tools/test.py: workers from a clean, pre-loaded fork server, never forked from this (HIP) process
                                                multiprocessing_context=(parallel.loader_worker_context(nworkers) if mp_ctx == "forkserver" else mp_ctx) if nworkers > 0 else None,
@@ -149,23 +147,25 @@ def run(frames=2048, workers=8, batch=64, model="w48", keep=None, mp_ctx="forkse
     # one-off costs of a process (BN folding + weight packing of 63.6 M parameters, the capture of the forward for this batch shape),
     # like the reference's model load: paid here, reported, and not part of the frames/s below
     t0 = time.perf_counter()
-    u8w = torch.zeros((batch, image, image, 3), dtype=torch.uint8, device="cuda")
-    cw = torch.full((batch, 2), image / 2.0, device="cuda"); sw = torch.full((batch, 2), image / 200.0 * 1.5, device="cuda")
-    for _ in range(3):
-        net.forward_decode(u8w, cw, sw, True)
-    torch.cuda.synchronize()
+    for eb in sorted({batch, function.ENGINE_BATCH}):     # the loader's batch shape and the coalesced engine batch
+        u8w = torch.zeros((eb, image, image, 3), dtype=torch.uint8, device="cuda")
+        cw = torch.full((eb, 2), image / 2.0, device="cuda"); sw = torch.full((eb, 2), image / 200.0 * 1.5, device="cuda")
+        for _ in range(3):
+            net.forward_decode(u8w, cw, sw, True)
+        torch.cuda.synchronize()
+        del u8w
     out["one_off_engine_build_and_capture_s"] = round(time.perf_counter() - t0, 2)
     more = [workers] + ([4 * workers] if (os.cpu_count() or 1) >= 8 * workers else [])
-    thr = [t for t in (16, 64) if (os.cpu_count() or 1) >= t] or [os.cpu_count() or 1]
-    for tag, dc, nw, nt, pin in [("product_device_crop_workers%d" % w, True, w, 0, True) for w in more] + [("product_device_crop_workers0", True, 0, 0, True)] + \
-                                [("product_device_crop_threads%d" % t, True, 0, t, True) for t in thr] + [("product_device_crop_workers%d_unpinned" % workers, True, workers, 0, False)]:
-        ds, ld = loader(dc, nw, False, nt, pin)
+    # engine_batch: frames per engine launch (core/function.py: _Coalescer; 0 = one launch per loader batch, what round 5 did)
+    for tag, dc, nw, eb, pin in [("product_workers%d_engine_batch%d" % (w, e), True, w, e, True) for w in more for e in (function.ENGINE_BATCH, 0)] + \
+                                [("product_workers0_engine_batch%d" % function.ENGINE_BATCH, True, 0, function.ENGINE_BATCH, True)]:
+        ds, ld = loader(dc, nw, False, pin)
         ts = time.perf_counter()
         started = _Started(ld)        # workers up and the first batch decoded: start-up is reported separately, the clock starts behind it
         t_start = time.perf_counter() - ts
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        function.validate(cfg, started, ds, net, crit, final, final, pred_file_name="pred_test", log_metrics=False)
+        function.validate(cfg, started, ds, net, crit, final, final, pred_file_name="pred_test", log_metrics=False, engine_batch=eb)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         pose_export.export(os.path.join(root, "frames"), os.path.join(root, "data", "real_test.json"), os.path.join(final, "pred_test.mat"),
