@@ -104,6 +104,7 @@ def parse():
                          "validate() -> pred.mat -> export -> opencv_poses.json), frames/s per stage beside the reference-style host loader "
                          "(tools_dev/pipeline_bench.py)")
     ap.add_argument("--pipeline-frames", type=int, default=2048)
+    ap.add_argument("--pipeline-batch", type=int, default=16, help="the loader's batch (TEST.BATCH_SIZE_PER_GPU; 16 in the reference's shipped events-config.yaml:74)")
     ap.add_argument("--pipeline-workers", type=int, default=max(1, min(32, (os.cpu_count() or 1) // 4)), help="loader workers (default: what the CLI picks, parallel.auto_workers)")
     ap.add_argument("--no-chain-check", action="store_true",
                     help="skip the post-run key-point / pose check on the 64 W48 fixture frames (about 15 s: the constructed checkpoint is rebuilt from its seed)")
@@ -151,16 +152,34 @@ def cpu_baseline(cfg, sd, image, nframes, kp_sample):
             "stage_s_per_frame": {"hrnet": t_net / nframes, "decode": t_dec / nframes, "pnp": t_pnp / nframes}}
 
 
+def pci_address(index):
+    """'dddd:bb:dd' of visible device `index` (torch device properties), or None"""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        return "%04x:%02x:%02x" % (p.pci_domain_id, p.pci_bus_id & 0xff, p.pci_device_id)
+    except Exception:
+        return None
+
+
 class DeviceSampler:
     """Shader clock and board power of one GPU while the timed region runs, read from sysfs (what rocm-smi reads) by a thread of this
     process every 25 ms: lets a reader of the line tell a slow BOX (low clock / power cap) from a slow BUILD.  None when the
     files are not readable; the figures are a report, nothing is computed from them."""
 
-    def __init__(self, index):
+    def __init__(self, index, pci=None):
         import threading
         self.sclk, self.power, self._stop, self._thread = [], [], threading.Event(), None
-        cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(d, "pp_dpm_sclk")))
-        self.dev = cards[index] if index < len(cards) else None
+        # the device's own sysfs node, by PCI address (a box can hold more cards than this process may use: the n-th visible device
+        # is not the n-th card in sysfs); fall back to the n-th card with a pp_dpm_sclk file
+        self.dev = None
+        if pci:
+            for cand in (os.path.join("/sys/bus/pci/devices", pci + ".0"), os.path.join("/sys/bus/pci/devices", pci)):
+                if os.path.exists(os.path.join(cand, "pp_dpm_sclk")):
+                    self.dev = cand
+                    break
+        if self.dev is None:
+            cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(d, "pp_dpm_sclk")))
+            self.dev = cards[index] if index < len(cards) else None
         hw = glob.glob(os.path.join(self.dev, "hwmon", "hwmon*")) if self.dev else []
         self.pfile = next((os.path.join(h, f) for h in hw for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, f))), None)
         self._threading = threading
@@ -194,6 +213,7 @@ class DeviceSampler:
         return {"sclk_mhz_median": float(np.median(self.sclk)), "sclk_mhz_min": int(min(self.sclk)), "sclk_mhz_max": int(max(self.sclk)),
                 "power_w_mean": round(float(np.mean(self.power)), 1) if self.power else None,
                 "power_w_max": round(float(max(self.power)), 1) if self.power else None, "samples": len(self.sclk),
+                "sysfs": self.dev,
                 "source": "sysfs pp_dpm_sclk / hwmon power1_average, sampled every 25 ms during the timed region"}
 
 
@@ -314,7 +334,7 @@ def main():
     if args.pipeline:
         sys.path.insert(0, os.path.join(ROOT, "tools_dev"))
         import pipeline_bench
-        res = pipeline_bench.run(args.pipeline_frames, args.pipeline_workers, 16 if args.batch == BATCH_PER_GPU else args.batch, args.model)   # 16: the reference's shipped TEST.BATCH_SIZE_PER_GPU
+        res = pipeline_bench.run(args.pipeline_frames, args.pipeline_workers, args.pipeline_batch, args.model)
         print(json.dumps({"metric": "frames/sec files -> poses (product CLI path)", "unit": "frames/s", **res}))
         return
     if args.events:
@@ -470,6 +490,8 @@ def main():
         if profile:   # per-launch HIP events of this forward (blocks the host until the forward has finished)
             recs = eng.profile_read()
             for rec, cls in zip(recs, eng.kernel_classes(recs)):
+                if rec["kind"] == 9 and rec["bytes_per_frame"] == 0:
+                    continue      # a convolution inside a branch chain: launched nothing, accounted under the chain's first op
                 key = (rec["kind"], rec["a"], rec["cin"], rec["cout"], cls)
                 e = prof_ms.setdefault(key, [0.0, 0, 0.0, 0.0])
                 e[0] += rec["ms"]; e[1] += 1; e[2] += rec["flops_per_frame"] * B; e[3] += rec["bytes_per_frame"] * B
@@ -483,7 +505,7 @@ def main():
     for _ in range(args.warmup):
         step(False)
     barrier()
-    sampler = DeviceSampler(local_rank) if (rank == 0 and not stub) else None
+    sampler = DeviceSampler(local_rank, pci_address(local_rank)) if (rank == 0 and not stub) else None
     if sampler:
         sampler.start()
     t0 = time.perf_counter()
@@ -502,7 +524,7 @@ def main():
         # who took part: every rank reports its device, so that the line itself shows N ranks on N distinct devices
         props = None if stub else torch.cuda.get_device_properties(local_rank)
         me = {"rank": rank, "local_rank": local_rank, "device": "cpu (stub)" if stub else props.name,
-              "pci_bus_id": None if stub else "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1) & 0xff, getattr(props, "pci_device_id", 0)),
+              "pci_bus_id": None if stub else pci_address(local_rank),
               "uuid": None if stub else str(getattr(props, "uuid", "")), "ms_per_step": round(elapsed_own / args.steps * 1e3, 3), "pid": os.getpid()}
         reports = [None] * world
         dist.all_gather_object(reports, me)
@@ -546,7 +568,8 @@ def main():
                     4: "head_gather_kernel (k%d s%d, C=%d)" % (a // 10, a % 10, cin),
                     5: "stem_fused_kernel: conv1 + conv2 of the stem (3->64->64, both 3x3 s2), image read once + output written once",
                     6: "bottleneck_kernel: fused Bottleneck 1x1 %d->64, 3x3 64->64, 1x1 64->%d + residual, input read once + output written once" % (cin, cout),
-                    8: "fuse_down_kernel: fuse row 0 + the first 3x3 s2 hop of every down path from branch 0 (%d->%d), branch 0 read once" % (cin, cout)}.get(
+                    8: "fuse_down_kernel: fuse row 0 + the first 3x3 s2 hop of every down path from branch 0 (%d->%d), branch 0 read once" % (cin, cout),
+                    9: "conv_chain_kernel: the %d 3x3 convolutions (%d->%d) of one branch's BasicBlocks in one launch, a frame per workgroup, activations in LDS" % (a, cin, cout)}.get(
                 kind, "conv %dx%d s%d %d->%d (MFMA implicit-GEMM)" % (a // 10, a // 10, a % 10, cin, cout))
             ai = flops / byts if byts else float("inf")
             sec = ms / 1e3
@@ -589,7 +612,7 @@ def main():
         roof["dispatch_gap_us_per_launch"] = round(gap_us, 2)
         roof["src_sha"] = sha
         # the next kernel classes by share of the forward, each against its own roofline (same definitions);
-        # class = kind:10*ksize+stride|nterms:Cin:Cout (kind 0 stem, 1 conv, 2 fuse sum, 3 fused BasicBlock, 4 head gather, 5 fused stem, 6 fused Bottleneck, 7 fused tail, 8 fuse row 0 + down hops of branch 0; '@pixels' where a layer shape runs at two map sizes)
+        # class = kind:10*ksize+stride|nterms:Cin:Cout (kind 0 stem, 1 conv, 2 fuse sum, 3 fused BasicBlock, 4 head gather, 5 fused stem, 6 fused Bottleneck, 7 fused tail, 8 fuse row 0 + down hops of branch 0, 9 branch chain (all BasicBlocks of a branch); '@pixels' where a layer shape runs at two map sizes)
         roof["next_classes"] = [{k: v for k, v in describe(k2, *v2).items()
                                  if k in ("class", "share_of_forward", "avg_launch_us", "avg_launch_us_gap_corrected", "bound", "achieved", "unit", "frac", "frac_gap_corrected", "frac_of_sustained", "traffic")}
                                 for k2, v2 in ranked[1:6]]

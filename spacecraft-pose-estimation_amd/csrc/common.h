@@ -186,6 +186,12 @@ bool block_fusable(const PackedConv& c1, const PackedConv& c2);
 int32_t block_launch(const PackedConv& c1, const PackedConv& c2, const void* in, int N, int H, int W, void* out,
                      hipStream_t stream);
 int conv_device_cus();
+// branch chain (conv_chain.hip): the BasicBlocks of one low-resolution branch in one launch, a frame per workgroup, activations in LDS
+bool conv_chain_channels(int C);                 // channel counts with a chain kernel (the weights are packed at create time)
+bool conv_chain_supported(int C, int H, int W);  // ... and the map sizes it runs at (decided per forward)
+size_t conv_chain_pack(const float* w, int nconv, int C, int dtype, uint16_t* dst);   // nconv folded OIHW 3x3 weights back to back; bytes
+int32_t conv_chain_launch(const void* in, void* out, const void* wpk, const float* bias, int nconv, int N, int C, int H, int W,
+                          int dtype, uint32_t* sched, hipStream_t stream);
 unsigned long long* conv_dbg_buffer(hipStream_t stream);   // development instrumentation
 void conv_dbg_set_grid(int grid);
 // PackedConv::mrep value of the 48-row Cout block of the producer/consumer kernel's 3 x 8 form (conv_m32p_kernel.h, M16 = 3): one and

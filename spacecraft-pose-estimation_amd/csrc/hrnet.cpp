@@ -71,7 +71,7 @@ static bool fold(Weights& W, const std::string& conv, const std::string& bn, int
   return true;
 }
 
-enum OpKind { OP_STEM = 0, OP_CONV = 1, OP_FUSE = 2, OP_BLOCK = 3, OP_HEAD = 4, OP_STEM2 = 5, OP_BNECK = 6, OP_FDOWN = 8 };   // OP_FDOWN: fuse row 0 + first down hops of branch 0 (fuse_down.hip; 7 is the fused tail's profile signature)   // OP_STEM2: fused stem (stem_fused.hip); OP_BNECK: fused Bottleneck (bottleneck.hip)   // OP_BLOCK: fused BasicBlock (conv_block_kernel.h); OP_HEAD: head.hip
+enum OpKind { OP_STEM = 0, OP_CONV = 1, OP_FUSE = 2, OP_BLOCK = 3, OP_HEAD = 4, OP_STEM2 = 5, OP_BNECK = 6, OP_FDOWN = 8 };   // (9 is the profile signature of a branch chain: the OP_CONVs of a branch run as one launch, see scpose_hrnet::Chain)   // OP_FDOWN: fuse row 0 + first down hops of branch 0 (fuse_down.hip; 7 is the fused tail's profile signature)   // OP_STEM2: fused stem (stem_fused.hip); OP_BNECK: fused Bottleneck (bottleneck.hip)   // OP_BLOCK: fused BasicBlock (conv_block_kernel.h); OP_HEAD: head.hip
 
 struct TensorDesc {
   int C, ds;       // channels, log2 spatial downscale w.r.t. the network input
@@ -119,6 +119,11 @@ struct scpose_hrnet {
   float* d_stemf_b2 = nullptr;
   struct Bneck { void* w1 = nullptr; void* w2 = nullptr; void* w3 = nullptr; float* bias = nullptr; int cin = 256; };   // fused Bottlenecks (bottleneck.hip)
   std::vector<Bneck> bnecks;
+  // branch chains (conv_chain.hip): ops[first_op .. first_op + nops) are the 3x3 convolutions of the BasicBlocks of one branch of a module;
+  // at map sizes the chain kernel supports they run as ONE launch at first_op and the others launch nothing (decided per forward)
+  struct Chain { int first_op = -1, nops = 0, C = 0; void* d_w = nullptr; float* d_b = nullptr; };
+  std::vector<Chain> chains;
+  std::vector<int> chain_at;    // per op: index into chains of the chain that STARTS there, else -1
   std::vector<scpose::FuseDownPacked> fdowns;   // fuse row 0 + first down hops of branch 0 (fuse_down.hip), one per module that qualifies
   float* d_head_bias = nullptr; // [4][16] folded biases of the hrnet_cms heads
   uint32_t* d_sched = nullptr;  // 16 zero-initialised words per op: dynamic tile queues of the persistent kernels (conv_device.h: tile_claim)
@@ -265,6 +270,41 @@ struct Builder {
     op.out = t;
     push(op);
     return t;
+  }
+  // The ops pushed since first_op are the convolutions of `names.size() / 2` BasicBlocks of one branch (C -> C, 3x3, stride 1, each
+  // its own OP_CONV): pack them a second time for the branch-chain kernel (conv_chain.hip).  names: (conv, bn) pairs in op order.
+  void chain(size_t first_op, const std::vector<std::pair<std::string, std::string>>& names, int C) {
+    if (status != SCPOSE_OK || !conv_chain_channels(C)) return;
+    const size_t nops = net->ops.size() - first_op;
+    if (nops != names.size() || nops < 2 || nops % 2) return;
+    for (size_t k = 0; k < nops; ++k) {
+      const Op& op = net->ops[first_op + k];
+      if (op.kind != OP_CONV || op.in2 > 0 || op.out_f32) return;
+      const PackedConv& pc = net->convs[op.conv];
+      if (pc.ks != 3 || pc.stride != 1 || pc.cin != C || pc.cout != C || !op.relu) return;
+      if ((k & 1) ? (op.res != net->ops[first_op + k - 1].in) : (op.res != -1)) return;     // conv2's residual is its block's input
+      if (k > 0 && op.in != net->ops[first_op + k - 1].out) return;
+    }
+    std::vector<float> w((size_t)nops * C * C * 9), b((size_t)nops * C);
+    for (size_t k = 0; k < nops; ++k) {
+      std::vector<float> wk, bk;
+      if (!fold(*W, names[k].first, names[k].second, C, C, 3, false, &wk, &bk)) { status = SCPOSE_E_MISSING; return; }
+      memcpy(w.data() + k * C * C * 9, wk.data(), wk.size() * sizeof(float));
+      memcpy(b.data() + k * C, bk.data(), (size_t)C * sizeof(float));
+    }
+    std::vector<uint16_t> pk(conv_chain_pack(w.data(), (int)nops, C, net->desc.dtype, nullptr) / 2);
+    conv_chain_pack(w.data(), (int)nops, C, net->desc.dtype, pk.data());
+    scpose_hrnet::Chain ch;
+    ch.first_op = (int)first_op; ch.nops = (int)nops; ch.C = C;
+    if (hipMalloc(&ch.d_w, pk.size() * 2) != hipSuccess || hipMalloc(&ch.d_b, b.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(ch.d_w, pk.data(), pk.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ch.d_b, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+      set_error("hrnet_create: uploading the branch-chain weights failed");
+      net->chains.push_back(ch);   // (hrnet_free releases whatever was allocated)
+      status = SCPOSE_E_HIP;
+      return;
+    }
+    net->chains.push_back(ch);
   }
   // x_b = Conv2d(32->J,1x1)(ConvTranspose2d(C->32,K,S,p1,op1)(y)) [+ bilinear_x2(prev)]  (hrnet_cms.py:353-368, :551-557)
   // folded into one transposed convolution C -> J: an MFMA 1x1 convolution to the tap map + the gather of head.hip.
@@ -477,10 +517,14 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
       for (int b = 0; b < nb; ++b) {
         B.lane = b;
         int t = xs[b];
+        const size_t branch_first_op = net->ops.size();
+        std::vector<std::pair<std::string, std::string>> branch_names;
         for (int k = 0; k < d.num_blocks[si][b]; ++k) {
           const std::string p = fmt("%s.branches.%d.%d", mp.c_str(), b, k);
           t = bneck_stage ? B.stage_bottleneck(t, p, d.num_channels[si][b]) : B.basic_block(t, p, cur[b]);
+          branch_names.emplace_back(p + ".conv1", p + ".bn1"); branch_names.emplace_back(p + ".conv2", p + ".bn2");
         }
+        if (!bneck_stage) B.chain(branch_first_op, branch_names, cur[b]);
         xs[b] = t;
       }
       B.parallel_end();
@@ -604,6 +648,8 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
   if (B.status != SCPOSE_OK) return B.status;
   SCP_CHECK_HIP(hipMalloc(&net->d_sched, net->ops.size() * 16 * sizeof(uint32_t)));
   SCP_CHECK_HIP(hipMemset(net->d_sched, 0, net->ops.size() * 16 * sizeof(uint32_t)));
+  net->chain_at.assign(net->ops.size(), -1);
+  for (size_t c = 0; c < net->chains.size(); ++c) net->chain_at[net->chains[c].first_op] = (int)c;
 
   // liveness
   for (size_t i = 0; i < net->ops.size(); ++i) {
@@ -614,6 +660,20 @@ int32_t hrnet_build(scpose_hrnet* net, Weights& W) {
     for (int k = 0; k < op.nterms; ++k) use(op.term[k]);
   }
   return SCPOSE_OK;
+}
+
+// does a branch chain start at op oi, and does its kernel run at this input size?
+static bool hrnet_chain_active(const scpose_hrnet* net, int oi, int h, int w) {
+  if (oi < 0 || (size_t)oi >= net->chain_at.size() || net->chain_at[oi] < 0) return false;
+  const scpose_hrnet::Chain& ch = net->chains[net->chain_at[oi]];
+  const TensorDesc& ti = net->tensors[net->ops[oi].in];
+  return conv_chain_supported(ch.C, h >> ti.ds, w >> ti.ds);
+}
+// ... or is op oi one of the later convolutions of such a chain (it launches nothing)?
+static bool hrnet_chain_member(const scpose_hrnet* net, int oi, int h, int w) {
+  for (const scpose_hrnet::Chain& ch : net->chains)
+    if (oi > ch.first_op && oi < ch.first_op + ch.nops) return hrnet_chain_active(net, ch.first_op, h, w);
+  return false;
 }
 
 static size_t tensor_bytes(const TensorDesc& t, int n, int h, int w) {
@@ -668,6 +728,7 @@ size_t hrnet_plan(scpose_hrnet* net, int n, int h, int w, int mode = 0) {
   P.off.assign(net->tensors.size(), 0);
   std::vector<char> released(net->tensors.size(), 0);
   std::vector<int> pending;   // mode 1: tensors whose last reader ran in the current epoch
+  int chain_out = -1;         // output tensor of the branch chain being walked (allocated at the chain's first op)
   int cur_epoch = net->ops.empty() ? 0 : net->ops[0].epoch;
   for (size_t i = 0; i < net->ops.size(); ++i) {
     const Op& op = net->ops[i];
@@ -676,7 +737,14 @@ size_t hrnet_plan(scpose_hrnet* net, int n, int h, int w, int mode = 0) {
       pending.clear();
       cur_epoch = op.epoch;
     }
-    if (op.out >= 0) P.off[op.out] = alloc(tensor_bytes(net->tensors[op.out], n, h, w));
+    // A branch chain (conv_chain.hip) launched at its first op writes the LAST op's output tensor, frame by frame, while other
+    // workgroups still read the chain's input: that output is born here, beside the (still live) input, not at the last op
+    if (hrnet_chain_active(net, (int)i, h, w)) {
+      const int t_out = net->ops[i + net->chains[net->chain_at[i]].nops - 1].out;
+      P.off[t_out] = alloc(tensor_bytes(net->tensors[t_out], n, h, w));
+      chain_out = t_out;
+    }
+    if (op.out >= 0 && op.out != chain_out) P.off[op.out] = alloc(tensor_bytes(net->tensors[op.out], n, h, w));
     for (int k = 0; k < op.nouts; ++k) P.off[op.outs[k]] = alloc(tensor_bytes(net->tensors[op.outs[k]], n, h, w));
     auto done = [&](int t) {
       if (t >= 0 && net->tensors[t].last_use == (int)i && !released[t]) {
@@ -742,6 +810,7 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
   hipStream_t const st0 = st;
   int cur_epoch = -1, par_index = -1;
   unsigned open_lanes = 0;   // side lanes forked in the current epoch
+  int chain_end = 0;         // ops below this index belong to a branch chain that has been launched
   auto join_lanes = [&]() -> int32_t {
     for (int l = 1; l < 4; ++l)
       if (open_lanes & (1u << l)) {
@@ -774,7 +843,16 @@ int32_t hrnet_forward(scpose_hrnet* net, const void* in, int in_fmt, int n, int 
     if (profile) SCP_CHECK_HIP(hipEventRecord(net->events[opi], st));
     ++opi;
     int32_t rc = SCPOSE_OK;
-    if (fused_tail && (int)oi == net->headf.fuse_op) {
+    if ((int)oi < chain_end) {
+      // nothing: a convolution inside a branch chain that was launched at the chain's first op
+      if (stop_tensor >= 0 && op.out == stop_tensor && (int)oi + 1 < chain_end) { set_error("hrnet_forward: tensor %d lies inside a branch chain", stop_tensor); return SCPOSE_E_INVALID; }
+    } else if (hrnet_chain_active(net, (int)oi, h, w)) {
+      const scpose_hrnet::Chain& ch = net->chains[net->chain_at[oi]];
+      const TensorDesc& ti = net->tensors[op.in];
+      chain_end = ch.first_op + ch.nops;
+      rc = conv_chain_launch(ptr(op.in), ptr(net->ops[chain_end - 1].out), ch.d_w, ch.d_b, ch.nops, n, ch.C, h >> ti.ds, w >> ti.ds,
+                             net->desc.dtype, net->d_sched + 16 * oi, st);
+    } else if (fused_tail && (int)oi == net->headf.fuse_op) {
       // nothing: its sum is formed in registers by the next op
     } else if (fused_tail && (int)oi == net->headf.conv_op) {
       const Op& fo = net->ops[net->headf.fuse_op];
@@ -862,6 +940,18 @@ static void op_work(const scpose_hrnet* net, const Op& op, int h, int w, double*
     *by = J * ho * wo * 4;
     for (int k = 0; k < fo.nterms; ++k) *by += to.C * (ho / (1 << fo.shift[k])) * (wo / (1 << fo.shift[k])) * 2;
     sig[0] = 7; sig[1] = fo.nterms; sig[2] = to.C; sig[3] = (int)J;
+  } else if (!unfused && hrnet_chain_active(net, (int)(&op - net->ops.data()), h, w)) {
+    // branch chain (conv_chain.hip): every convolution of the branch in this one launch (kind 9); it reads the branch input once and
+    // writes the branch output once
+    const scpose_hrnet::Chain& ch = net->chains[net->chain_at[&op - net->ops.data()]];
+    const TensorDesc& ti = net->tensors[op.in];
+    const double hi = h >> ti.ds, wi = w >> ti.ds;
+    *f = ch.nops * 2.0 * ch.C * ch.C * 9 * hi * wi;
+    *by = 2.0 * ch.C * hi * wi * 2;
+    sig[0] = 9; sig[1] = ch.nops; sig[2] = ch.C; sig[3] = ch.C;
+  } else if (!unfused && hrnet_chain_member(net, (int)(&op - net->ops.data()), h, w)) {
+    // launched nothing: accounted under the chain's first op
+    sig[0] = 9; sig[1] = 0; sig[2] = net->convs[op.conv].cin; sig[3] = net->convs[op.conv].cout;
   } else if (op.kind == OP_STEM) {
     *f = 2.0 * 27 * 64 * (h / 2) * (w / 2);
     *by = (double)64 * (h / 2) * (w / 2) * 2 + 3.0 * h * w;   // u8 in (f32 in: 4x) + 16-bit out
@@ -932,7 +1022,10 @@ void hrnet_stats(scpose_hrnet* net, int h, int w, int* launches, double* flops, 
     if (op.kind == OP_STEM || op.kind == OP_STEM2) ob -= 3.0 * h * w;   // network input is not an inter-layer activation
     f += of; by += ob;
   }
-  if (launches) *launches = (int)net->ops.size() - (hrnet_tail_fused(net, 1, h, w) ? 1 : 0);   // the fused tail absorbs the last fuse row
+  int skipped = hrnet_tail_fused(net, 1, h, w) ? 1 : 0;   // the fused tail absorbs the last fuse row
+  for (const scpose_hrnet::Chain& ch : net->chains)
+    if (hrnet_chain_active(net, ch.first_op, h, w)) skipped += ch.nops - 1;   // a branch chain is one launch
+  if (launches) *launches = (int)net->ops.size() - skipped;
   if (flops) *flops = f;
   if (bytes) *bytes = by;
 }
@@ -949,6 +1042,7 @@ void hrnet_free(scpose_hrnet* net) {
     if (bn.bias) (void)hipFree(bn.bias);
   }
   for (auto& fd : net->fdowns) fuse_down_free(&fd);
+  for (auto& ch : net->chains) { if (ch.d_w) (void)hipFree(ch.d_w); if (ch.d_b) (void)hipFree(ch.d_b); }
   if (net->d_stemf_w1) (void)hipFree(net->d_stemf_w1);
   if (net->d_stemf_w2) (void)hipFree(net->d_stemf_w2);
   if (net->d_stemf_b1) (void)hipFree(net->d_stemf_b1);

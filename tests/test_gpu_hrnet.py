@@ -446,3 +446,58 @@ def test_batch_2048_equals_eight_batches_of_256(gpu_ops):
     assert torch.equal(gpu_ops.decode(hm, c[:512], s[:512], True), kp[1024:1536])
     print("batch 2048: workspace %.1f GB" % (need / 1e9))
     eng.close()
+
+
+def test_branch_chain_kernel_under_its_development_switch(gpu_ops):
+    """conv_chain.hip (round 6): the four BasicBlocks of a 128-channel / 16 x 16 or 256-channel / 8 x 8 branch in one launch, a frame per
+    workgroup, activations in LDS -- off by default (measured -1 ... -4 % at BASELINE's batch 64, +8.6 % at batch 256:
+    profiles/round6_chain_ab.txt), switched on with SCPOSE_DEV=1 SCPOSE_CHAIN=1 in a sub-process (switches are read once per process).
+    HRNet-W32 at 256 x 256 (the one shipped geometry whose deep branches fit LDS), product library: 70 launches fewer; heat-maps against
+    the storage-model oracle and the fp32 reference within the bounds of the per-layer path (same rounding points, another fp32
+    summation order); a frame's maps bit-identical at batch 5 / 1 / as frame 0 or 4 (frame queue, no batch-dependent arithmetic); the
+    captured forward = the eager one; f16 too."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys; sys.path.insert(0, %r)
+import torch, scpose
+from importlib import import_module
+ops = import_module("spacecraft-pose-estimation_amd.ops")
+from oracle import hrnet_ref as R
+cfg = R.w32_cfg(); sd = R.make_state_dict(cfg, seed=3)
+x = torch.randn(5, 3, 256, 256, generator=torch.Generator().manual_seed(4))
+for dt in ("bf16", "f16"):
+    eng = ops.HrnetEngine(cfg, sd, dtype=dt)
+    got = eng(x.cuda()).cpu()
+    one = eng(x[4:5].cuda()).cpu()
+    first = eng(x[[4, 0, 1]].cuda()).cpu()
+    g = eng.capture(x.cuda(), concurrent=True)
+    cap = g.replay().cpu()
+    with torch.no_grad():
+        emu = R.forward(sd, cfg, x[:2], emulate=dt); ref = R.forward(sd, cfg, x[:2])
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    print("RES", dt, eng.stats(256, 256)["launches"], rel(got[:2], emu), rel(got[:2], ref), int(torch.equal(got[4:5], one)), int(torch.equal(first[0], got[4])),
+          int(torch.equal(cap, got)), int(torch.isfinite(got).all()))
+    eng.close()
+''' % root
+
+    def run(extra):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("SCPOSE_")}
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900, cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return {l.split()[1]: l.split()[2:] for l in r.stdout.splitlines() if l.startswith("RES")}
+
+    from importlib import import_module
+    nat = import_module("spacecraft-pose-estimation_amd._native")
+    on = run({"SCPOSE_DEV": "1", "SCPOSE_CHAIN": "1", "SCPOSE_LIB": nat.LIB_PATH})
+    off = run({})
+    for dt, e_logic, e_prec in (("bf16", E_LOGIC_BF16, E_PREC_BF16), ("f16", E_LOGIC_F16, E_PREC_F16)):
+        launches, r_emu, r_ref, same_one, same_first, same_cap, finite = on[dt]
+        print("chain %s: %s launches (per-layer: %s), rel-L2 vs storage-model oracle %s, vs fp32 %s" % (dt, launches, off[dt][0], r_emu, r_ref))
+        assert int(launches) == int(off[dt][0]) - 70          # 7 + 3 chains of 8 convolutions each
+        assert float(r_emu) <= e_logic and float(r_ref) <= e_prec
+        assert (same_one, same_first, same_cap, finite) == ("1", "1", "1", "1")
+        assert off[dt][3:] == ["1", "1", "1", "1"]
