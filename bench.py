@@ -653,7 +653,9 @@ def main():
                             "t_err_rel_median": float(np.median(terr)), "t_err_rel_max": float(terr.max()),
                             "inliers_min": int(hb[:, 12].min()),
                             "note": "landmarks are drawn up to one crop pixel (side / 128 frame px) from their projection (synthetic.landmark_frames)"}
-        if chain_report is None and not stub and not args.events and args.model == "w48" and args.dtype in ("bf16", "f16") and not args.no_chain_check:
+        # (N = 1 only: it is a property of one device's kernels, and the other ranks of a multi-GPU run should not wait ~15 s at the process
+        # group's tear-down while rank 0 rebuilds the constructed checkpoint)
+        if chain_report is None and world == 1 and not stub and not args.events and args.model == "w48" and args.dtype in ("bf16", "f16") and not args.no_chain_check:
             chain_report = chain_check(ops, syn, dev, args.dtype)
         line = {
             "metric": "STUB: multi-rank step loop on CPU tensors over gloo, nothing is computed or measured (--cpu-stub)" if stub else
