@@ -691,3 +691,30 @@ def test_loader_workers_start_with_the_package_imported(tmp_path):
     assert par.loader_worker_context(0) is None
     assert par.auto_workers(100, 0) == 0 and par.auto_workers(5000, 3) == 3 and par.auto_workers(5000, 0, keep=True) == 0
     assert par.auto_workers(5000, 0) == max(1, min(32, (os.cpu_count() or 1) // 4))
+
+
+@pytest.mark.parametrize("loader,engine,total", [(5, 2, 23), (16, 256, 1000), (7, 7, 21), (3, 10, 31), (4, 6, 4), (256, 16, 600)])
+def test_engine_batch_coalescer_keeps_order_and_sizes(loader, engine, total):
+    """core.function._Coalescer on CPU tensors (no engine: the step echoes its frames): every engine call but the last gets exactly `engine`
+    frames, loader batches that straddle engine batches are sliced, nothing is lost or reordered, centres / scales travel with their
+    frames -- whatever the ratio of the two batch sizes (the GPU test compares real rows, tests/test_gpu_validate_golden.py)."""
+    import scpose  # noqa: F401
+    from importlib import import_module
+    fn = import_module("spacecraft-pose-estimation_amd.core.function")
+    calls = []
+
+    def step(x, c, s):
+        assert x.shape[0] == c.shape[0] == s.shape[0] and torch.equal(c[:, 0], x[:, 0]) and torch.equal(s[:, 1], x[:, 0] * 2)
+        calls.append(int(x.shape[0]))
+        return x.clone()
+    co = fn._Coalescer(engine, step)
+    out = []
+    for i in range(0, total, loader):
+        ids = torch.arange(i, min(i + loader, total), dtype=torch.float32)
+        x = ids.view(-1, 1).repeat(1, 3)
+        out.extend(co.push(x, torch.stack([ids, ids], 1), torch.stack([ids, ids * 2], 1)))
+    out.extend(co.drain(True))
+    got = torch.cat(out)[:, 0]
+    assert torch.equal(got, torch.arange(total, dtype=torch.float32))
+    assert all(n == engine for n in calls[:-1]) and 0 < calls[-1] <= engine and sum(calls) == total
+    assert co.n == 0 and co.q == [] and co.drain(True) == []
