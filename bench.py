@@ -103,6 +103,7 @@ def parse():
                     help="side line: files -> poses through the product CLI path (synthetic 1920x1200 JPEG frames on disk -> data loader -> "
                          "validate() -> pred.mat -> export -> opencv_poses.json), frames/s per stage beside the reference-style host loader "
                          "(tools_dev/pipeline_bench.py)")
+    ap.add_argument("--pipeline-quick", action="store_true", help="--pipeline without the 4 x workers variants (their worker start-up takes minutes on a big host)")
     ap.add_argument("--pipeline-frames", type=int, default=2048)
     ap.add_argument("--pipeline-batch", type=int, default=16, help="the loader's batch (TEST.BATCH_SIZE_PER_GPU; 16 in the reference's shipped events-config.yaml:74)")
     ap.add_argument("--pipeline-workers", type=int, default=max(1, min(32, (os.cpu_count() or 1) // 4)), help="loader workers (default: what the CLI picks, parallel.auto_workers)")
@@ -334,7 +335,7 @@ def main():
     if args.pipeline:
         sys.path.insert(0, os.path.join(ROOT, "tools_dev"))
         import pipeline_bench
-        res = pipeline_bench.run(args.pipeline_frames, args.pipeline_workers, args.pipeline_batch, args.model)
+        res = pipeline_bench.run(args.pipeline_frames, args.pipeline_workers, args.pipeline_batch, args.model, quick=args.pipeline_quick)
         print(json.dumps({"metric": "frames/sec files -> poses (product CLI path)", "unit": "frames/s", **res}))
         return
     if args.events:

@@ -123,15 +123,33 @@ def auto_workers(n_frames, cfg_workers, keep=False):
     return max(1, min(32, (os.cpu_count() or 1) // 4))
 
 
+class _UnpackingLoader:
+    """A DataLoader whose worker-side collate packed each batch into two tensors (dataset.collate_device_crop_packed); iterating it yields
+    the usual (input, target, target_weight, meta) tuples again.  len() and the batch order are the DataLoader's."""
+
+    def __init__(self, loader, unpack):
+        self.loader, self.unpack = loader, unpack
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for packed in self.loader:
+            yield self.unpack(packed)
+
+
 def valid_loader(dataset, lo, hi, world_size, batch_size, workers, device_crop):
-    """The DataLoader of tools/test.py:116-122 (shuffle=False, pinned) over this rank's shard [lo, hi) of `dataset`, with the build's two
-    extensions: workers from a clean pre-loaded fork server, and -- with GPU crop warp -- batches of packed frame windows."""
+    """The DataLoader of tools/test.py:116-122 (shuffle=False, pinned) over this rank's shard [lo, hi) of `dataset`, with the build's
+    extensions: workers from a clean pre-loaded fork server; with GPU crop warp, batches of packed frame windows -- and, when worker
+    processes are used, every small tensor of a batch in one blob (two shared-memory segments per batch instead of fifteen)."""
     import torch.utils.data
     subset = torch.utils.data.Subset(dataset, range(lo, hi)) if world_size > 1 else dataset
-    return torch.utils.data.DataLoader(subset, batch_size=batch_size, shuffle=False, num_workers=workers,
-                                       pin_memory=True,   # (the packed frame windows too: a background thread pins them, the copy to the device is then asynchronous)
-                                       multiprocessing_context=loader_worker_context(workers),
-                                       collate_fn=dataset.collate_device_crop if device_crop else None)
+    packed = bool(device_crop) and workers > 0 and hasattr(dataset, "collate_device_crop_packed")
+    collate = (dataset.collate_device_crop_packed if packed else dataset.collate_device_crop) if device_crop else None
+    loader = torch.utils.data.DataLoader(subset, batch_size=batch_size, shuffle=False, num_workers=workers,
+                                         pin_memory=True,   # (the packed frame windows too: a background thread pins them, the copy to the device is then asynchronous)
+                                         multiprocessing_context=loader_worker_context(workers), collate_fn=collate)
+    return _UnpackingLoader(loader, dataset.unpack_device_crop_batch) if packed else loader
 
 
 def free_port():

@@ -718,3 +718,51 @@ def test_engine_batch_coalescer_keeps_order_and_sizes(loader, engine, total):
     assert torch.equal(got, torch.arange(total, dtype=torch.float32))
     assert all(n == engine for n in calls[:-1]) and 0 < calls[-1] <= engine and sum(calls) == total
     assert co.n == 0 and co.q == [] and co.drain(True) == []
+
+
+def test_packed_loader_batches_equal_the_plain_ones(tmp_path):
+    """dataset.collate_device_crop_packed / unpack_device_crop_batch (round 6): a device-crop batch crosses the worker -> main-process
+    boundary as TWO tensors (the frame windows and one blob of everything small) instead of fifteen, because every tensor costs the
+    feeding thread an authenticated descriptor hand-over.  The 4-tuple rebuilt from the blob must equal collate_device_crop's, field
+    for field, dtype for dtype; and the loader the CLIs build (parallel.valid_loader: worker processes from the pre-loaded fork server)
+    must yield the same batches as the dataset iterated in this process."""
+    import scpose  # noqa: F401
+    from importlib import import_module
+    from PIL import Image
+    P = "spacecraft-pose-estimation_amd"
+    dataset = import_module(P + ".dataset"); config_mod = import_module(P + ".config"); par = import_module(P + ".parallel")
+    T = import_module(P + ".utils.transforms")
+    rng = np.random.default_rng(2)
+    (tmp_path / "frames").mkdir(); (tmp_path / "data").mkdir()
+    images, anns = [], []
+    for i in range(11):
+        Image.fromarray(rng.integers(0, 256, (120, 160, 3), dtype=np.uint8)).save(tmp_path / "frames" / ("f%02d.png" % i))
+        images.append({"id": i + 1, "file_name": "f%02d.png" % i, "width": 160, "height": 120})
+        anns.append({"image_id": i + 1, "bbox": [10.0 + i, 8.0, 90.0, 70.0 + i], "keypoints": [2.0] * 33, "id": i, "category_id": 1})
+    (tmp_path / "data" / "real_test.json").write_text(json.dumps({"images": images, "annotations": anns}))
+    cfg = config_mod._defaults()
+    config_mod.update_config(cfg, types.SimpleNamespace(cfg=os.path.join(ROOT, "landmark_regression", "experiments", "events", "events-config.yaml"),
+                                                        opts=["DATA_DIR", str(tmp_path / "frames"), "DATASET.ROOT", str(tmp_path / "data"), "DATASET.TEST_SET", "test",
+                                                              "MODEL.NUM_JOINTS", "11", "OUTPUT_DIR", str(tmp_path / "o"), "LOG_DIR", str(tmp_path / "l")], modelDir="", logDir="", dataDir=""))
+    ds = dataset.EventsDataset(cfg, cfg.DATASET.ROOT, cfg.DATA_DIR, "test", False, T.Compose([T.ToTensor()]))
+    ds.device_crop = True; ds.want_target = False
+
+    def same(x, y):
+        if torch.is_tensor(x):
+            return torch.is_tensor(y) and x.dtype == y.dtype and x.shape == y.shape and torch.equal(x, y)
+        if isinstance(x, dict):
+            return x.keys() == y.keys() and all(same(x[k], y[k]) for k in x)
+        if isinstance(x, (list, tuple)):
+            return len(x) == len(y) and all(same(p, q) for p, q in zip(x, y))
+        return x == y
+    items = [ds[i] for i in range(11)]
+    plain = ds.collate_device_crop(items[:4])
+    packed = ds.collate_device_crop_packed(items[:4])
+    assert sum(torch.is_tensor(v) for v in packed.values()) == 2            # the windows and the blob
+    assert same(plain, ds.unpack_device_crop_batch(packed))
+    ld = par.valid_loader(ds, 0, len(ds), 1, 4, 2, True)                    # two worker processes, batches of 4 + a ragged one of 3
+    got = list(ld)
+    assert len(ld) == 3 and len(got) == 3
+    for k, b in enumerate(got):
+        assert same(ds.collate_device_crop(items[4 * k:4 * k + 4]), b), k
+    assert same(list(par.valid_loader(ds, 0, len(ds), 1, 4, 0, True)), got)   # no workers: the plain collate, same batches

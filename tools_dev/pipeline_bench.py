@@ -72,7 +72,7 @@ class _Started:
         yield from self.it
 
 
-def run(frames=2048, workers=8, batch=64, model="w48", keep=None, mp_ctx="forkserver"):
+def run(frames=2048, workers=8, batch=64, model="w48", keep=None, mp_ctx="forkserver", quick=False):
     import numpy as np
     import torch
     import torch.utils.data
@@ -105,9 +105,10 @@ def run(frames=2048, workers=8, batch=64, model="w48", keep=None, mp_ctx="forkse
     def loader(device_crop, nworkers, want_target, pin=True):
         ds = getattr(dataset, cfg.DATASET.DATASET)(cfg, cfg.DATASET.ROOT, cfg.DATA_DIR, cfg.DATASET.TEST_SET, False, tf)
         ds.device_crop = device_crop; ds.want_target = want_target
+        if mp_ctx == "forkserver" and pin:      # exactly the loader tools/test.py builds (workers from the pre-loaded fork server, packed batches)
+            return ds, parallel.valid_loader(ds, 0, len(ds), 1, batch, nworkers, device_crop)
         return ds, torch.utils.data.DataLoader(ds, batch_size=batch, shuffle=False, num_workers=nworkers, pin_memory=pin,
-                                               # as tools/test.py: workers from a clean, pre-loaded fork server, never forked from this (HIP) process
-                                               multiprocessing_context=(parallel.loader_worker_context(nworkers) if mp_ctx == "forkserver" else mp_ctx) if nworkers > 0 else None,
+                                               multiprocessing_context=mp_ctx if nworkers > 0 else None,
                                                collate_fn=ds.collate_device_crop if device_crop else None)
 
     startup = {}
@@ -138,7 +139,7 @@ def run(frames=2048, workers=8, batch=64, model="w48", keep=None, mp_ctx="forkse
         "host_crop_workers%d" % workers: round(time_loader(False, workers, True, small), 1),
         "decode_only_workers0": round(time_loader(True, 0, False, min(small, 64)), 1),                    # product default: the loader only decodes
         "decode_only_workers%d" % workers: round(time_loader(True, workers, False, frames), 1)}
-    if (os.cpu_count() or 1) >= 8 * workers:
+    if (os.cpu_count() or 1) >= 8 * workers and not quick:
         out["loader_fps"]["decode_only_workers%d" % (4 * workers)] = round(time_loader(True, 4 * workers, False, frames), 1)
     # ---- product path, files -> pred.mat -> opencv_poses.json ----
     crit = None
@@ -155,7 +156,7 @@ def run(frames=2048, workers=8, batch=64, model="w48", keep=None, mp_ctx="forkse
         torch.cuda.synchronize()
         del u8w
     out["one_off_engine_build_and_capture_s"] = round(time.perf_counter() - t0, 2)
-    more = [workers] + ([4 * workers] if (os.cpu_count() or 1) >= 8 * workers else [])
+    more = [workers] + ([4 * workers] if (os.cpu_count() or 1) >= 8 * workers and not quick else [])   # (quick: the 4 x workers variants cost minutes of worker start-up)
     # engine_batch: frames per engine launch (core/function.py: _Coalescer; 0 = one launch per loader batch, what round 5 did)
     for tag, dc, nw, eb, pin in [("product_workers%d_engine_batch%d" % (w, e), True, w, e, True) for w in more for e in (function.ENGINE_BATCH, 0)] + \
                                 [("product_workers0_engine_batch%d" % function.ENGINE_BATCH, True, 0, function.ENGINE_BATCH, True)]:
@@ -171,8 +172,12 @@ def run(frames=2048, workers=8, batch=64, model="w48", keep=None, mp_ctx="forkse
         pose_export.export(os.path.join(root, "frames"), os.path.join(root, "data", "real_test.json"), os.path.join(final, "pred_test.mat"),
                            os.path.join(root, "landmarks.csv"), os.path.join(root, "calib.json"), os.path.join(root, "poses"), overlay=False)
         t2 = time.perf_counter()
+        # (the steady-state clock starts when the first batch has arrived -- by then the workers have prefetched 2 x workers x batch frames,
+        # which is the whole scene for large loader batches: the `_from_loader_creation` figure, start-up included, is the one to compare
+        # across loader batch sizes)
         stages[tag] = {"worker_startup_plus_first_batch_s": round(t_start, 2), "files_to_pred_mat_fps": round(frames / (t1 - t0), 1), "pred_mat_to_poses_json_fps": round(frames / (t2 - t1), 1),
-                       "files_to_poses_fps": round(frames / (t2 - t0), 1)}
+                       "files_to_poses_fps": round(frames / (t2 - t0), 1), "files_to_pred_mat_fps_from_loader_creation": round(frames / (t1 - ts), 1),
+                       "frames_prefetched_before_the_clock": min(frames, 2 * nw * batch) if nw else 0}
     out["pipeline"] = stages
     out["worker_startup_plus_first_batch_s"] = {"%s_workers%d" % k: v for k, v in startup.items()}
     out["mp_context"] = mp_ctx
