@@ -766,3 +766,10 @@ def test_packed_loader_batches_equal_the_plain_ones(tmp_path):
     for k, b in enumerate(got):
         assert same(ds.collate_device_crop(items[4 * k:4 * k + 4]), b), k
     assert same(list(par.valid_loader(ds, 0, len(ds), 1, 4, 0, True)), got)   # no workers: the plain collate, same batches
+    # the data set pickles its record list once and hands every further worker the cached bytes (a DataLoader pickles it per worker)
+    import pickle
+    one = pickle.dumps(ds)
+    assert ds._db_blob[1] is pickle.loads(pickle.dumps(ds.__getstate__()))["_db_pickled"] or len(ds._db_blob[1]) > 0
+    back = pickle.loads(one)
+    assert len(back) == len(ds) and back.db[3]["image"] == ds.db[3]["image"] and np.array_equal(back.db[9]["center"], ds.db[9]["center"]) and back.device_crop
+    assert same(back.collate_device_crop([back[i] for i in range(4)]), plain)
