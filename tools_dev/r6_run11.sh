@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 6, GPU run 11: the fused C = 48 BasicBlock with the input tile's LDS-DMA issued by the conv1 waves (SCPOSE_BLOCK_DMA=0) instead of the conv2 waves
+# (SCPOSE_BLOCK_DMA was an experimental template switch of conv_block2_kernel.h, measured here and NOT kept in the sources: profiles/round6_block_dma_role_ab.txt)
 cd $GRAFT_REPO_ROOT; root=$PWD
 out=$root/gpurun_out/${1:-r6_run11}; mkdir -p $out
 lib=$root/spacecraft-pose-estimation_amd/libscpose_hip.so
